@@ -1,0 +1,213 @@
+"""Pin the CPU oracle: the reference's own known answers, the committed golden
+vectors, scipy, and MKL (when the shared library is present).  CPU only."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from oracle import mmio
+from conftest import GOLDEN, golden_matrix_files
+
+
+def dense_to_csr(rows):
+    a = sp.csr_matrix(np.array(rows, dtype=np.float64))
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+
+
+def ulp_close(a, b, ulps=4):
+    """gtest ASSERT_DOUBLE_EQ: within 4 units in the last place."""
+    a, b = np.float64(a), np.float64(b)
+    return abs(a - b) <= ulps * np.spacing(max(abs(a), abs(b)))
+
+
+# ---- known answers from test/SparseMatrix.cpp -------------------------------------
+
+def test_csr_dot_known_answers(known_answers):
+    for key in ("dok_dot", "csr_dot"):
+        ka = known_answers[key]
+        rp, ci, v = dense_to_csr(ka["dense_rows"])
+        assert oracle.csr_spmv(rp, ci, v, ka["b"]).tolist() == ka["expected"]
+
+
+def test_symcsr_dot_known_answer(known_answers):
+    ka = known_answers["symcsr_dot"]
+    rp, ci, v = dense_to_csr(ka["lower_dense_rows"])
+    assert oracle.symcsr_spmv(rp, ci, v, ka["b"]).tolist() == ka["expected"]
+
+
+def test_transpose_product_matches_scipy():
+    rng = np.random.default_rng(5)
+    a = sp.random(37, 23, 0.2, format="csr", random_state=rng)
+    a.sort_indices()
+    x = rng.standard_normal(37)
+    y = oracle.csr_spmv_t(23, a.indptr, a.indices, a.data, x)
+    np.testing.assert_allclose(y, a.T @ x, rtol=1e-13, atol=1e-14)
+
+
+# ---- MatrixMarket restatement vs test/Io.cpp ---------------------------------------
+
+def test_io_dense_4_exact_values(known_answers):
+    ka = known_answers["io_dense_4"]
+    m = mmio.read_matrix(GOLDEN / ka["file"])
+    assert (m.n, m.m, m.nnz) == (ka["n"], ka["m"], ka["nnz"])
+    dense = sp.csr_matrix((m.values, m.col_ind, m.row_ptr), shape=(m.n, m.m)).toarray()
+    assert dense.tolist() == ka["dense_rows"]          # exact, as EXPECT_EQ in Io.cpp
+
+
+def test_io_header(known_answers):
+    ka = known_answers["io_header"]
+    h = mmio.read_header(GOLDEN / ka["file"])
+    assert (h.type, h.format, h.data_type, h.symmetry) == (
+        ka["type"], ka["format"], ka["data_type"], ka["symmetry"])
+
+
+def test_io_sym_expansion(known_answers):
+    for case in known_answers["io_sym"]["cases"]:
+        low = mmio.read_sym_matrix(GOLDEN / case["file"])
+        assert (low.n, low.m) == (case["n"], case["m"])
+        full = mmio.read_matrix(GOLDEN / case["file"])
+        assert full.nnz == case["sym_nnz"]
+        dense = sp.csr_matrix((full.values, full.col_ind, full.row_ptr), shape=(4, 4)).toarray()
+        assert dense.tolist() == case["expanded_dense_rows"]
+
+
+def test_io_rejects_bad_header(tmp_path):
+    p = tmp_path / "bad.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1 0\n")
+    with pytest.raises(ValueError, match="Not a valid MatrixMarket"):
+        mmio.read_header(p)
+    with pytest.raises(ValueError, match="File not found"):
+        mmio.read_header(tmp_path / "missing.mtx")
+    g = tmp_path / "gen.mtx"
+    g.write_text("%%MatrixMarket matrix coordinate real general\n1 1 1\n1 1 2.0\n")
+    with pytest.raises(ValueError, match="not symmetric"):
+        mmio.read_sym_matrix(g)
+
+
+def test_io_duplicate_entry_last_wins(tmp_path):
+    p = tmp_path / "dup.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n2 2 5.0\n1 1 7.0\n")
+    m = mmio.read_matrix(p)
+    assert m.values.tolist() == [7.0, 5.0] and m.nnz == 2
+
+
+def test_io_asymmetric_symmetric_file_rejected(tmp_path):
+    p = tmp_path / "asym.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 2 2\n2 1 1.0\n1 2 3.0\n")
+    with pytest.raises(ValueError, match="not symmetric"):
+        mmio.read_matrix(p)
+
+
+# ---- golden vectors ---------------------------------------------------------------
+
+@pytest.mark.parametrize("key,path", golden_matrix_files(), ids=lambda v: v if isinstance(v, str) else "")
+def test_oracle_reproduces_golden(key, path, expected_y):
+    m = mmio.read_matrix(path)
+    x = mmio.test_vector(m.m)
+    y = oracle.csr_spmv(m.row_ptr, m.col_ind, m.values, x)
+    assert np.array_equal(y, expected_y[key])          # bit-exact: same code, same order
+    a = sp.csr_matrix((m.values, m.col_ind, m.row_ptr), shape=(m.n, m.m))
+    oracle.assert_almost_equal(a @ x, y, what=f"scipy vs oracle on {key}")
+
+
+def _mkl():
+    for cand in (os.environ.get("MKLROOT", "") + "/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.1",
+                 "/opt/conda/lib/libmkl_rt.so.2"):
+        if os.path.exists(cand):
+            os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
+            return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    return None
+
+
+@pytest.mark.parametrize("key", ["matrices/OPF_6000", "matrices/test_cage6", "benchmark/t2d_q9_A_01",
+                                 "matrices/test_wa"])
+def test_oracle_vs_mkl(key, expected_y):
+    L = _mkl()
+    if L is None:
+        pytest.skip("MKL shared library not present")
+    path = dict(golden_matrix_files())[key]
+    m = mmio.read_matrix(path)
+    x, y = mmio.test_vector(m.m), np.zeros(m.n)
+    tr, nn = ctypes.c_char(b"N"), ctypes.c_int(m.n)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    L.mkl_cspblas_dcsrgemv(ctypes.byref(tr), ctypes.byref(nn), p(m.values), p(m.row_ptr),
+                           p(m.col_ind), p(x), p(y))
+    oracle.assert_almost_equal(y, expected_y[key], what=f"MKL vs golden on {key}")
+
+
+# ---- tolerance function -----------------------------------------------------------
+
+def test_almost_equal_semantics():
+    assert oracle.almost_equal(1.0, 1.0)
+    assert oracle.almost_equal(0.0, 5e-12)                  # inside abs 1e-11
+    assert not oracle.almost_equal(0.0, 5e-11)
+    assert oracle.almost_equal(1e6, 1e6 * (1 + 5e-9))       # inside rel 1e-8
+    assert not oracle.almost_equal(1e6, 1e6 * (1 + 5e-8))
+    assert not oracle.almost_equal(float("nan"), 1.0)
+    cnt, first = oracle.mismatches([1, 2, 3], [1, 2.1, 3.5])
+    assert (cnt, first) == (2, 1)
+
+
+# ---- CG known answers (test/LinearSolvers.cpp) -------------------------------------
+
+def test_pcg_identity_known_answers(known_answers):
+    for case in known_answers["cg_identity"]["cases"]:
+        low = mmio.read_sym_matrix(GOLDEN / case["matrix"])
+        rhs = mmio.read_vector(GOLDEN / case["rhs"])
+        x, iters, conv = oracle.pcg_identity(low.row_ptr, low.col_ind, low.values, rhs)
+        assert conv
+        for got, exp in zip(x, case["expected"]):
+            assert ulp_close(got, exp), (case["matrix"], x)
+        # the same system through the expanded matrix
+        full = mmio.read_matrix(GOLDEN / case["matrix"])
+        x2, _, conv2 = oracle.cg_full(full.row_ptr, full.col_ind, full.values, rhs)
+        assert conv2 and all(ulp_close(g, e) for g, e in zip(x2, case["expected"]))
+
+
+def test_pcg_iteration_reporting():
+    """`iterations` is only written at the end of a non-converged pass
+    (SparseLinearSolvers.hpp:231): identity system converges in pass 0 -> 0."""
+    low = mmio.read_sym_matrix(GOLDEN / "systems/tiny.mtx")
+    _, iters, conv = oracle.pcg_identity(low.row_ptr, low.col_ind, low.values, [1, 2, 3, 4])
+    assert conv and iters == 0
+
+
+def test_solver_harness_protocol_bfwb62():
+    """test_utils.hpp:61-70,120-163: b = A x0 with x0_i = 0.25 i, solution must
+    come back almost_equal to x0 (CG: bfwb62 is symmetric positive definite?  it
+    is symmetric; use BiCG which the reference's test_bicg.cpp:11 targets)."""
+    m = mmio.read_matrix(GOLDEN / "matrices/bfwb62.mtx")
+    x0 = mmio.test_vector(m.n)
+    b = oracle.csr_spmv(m.row_ptr, m.col_ind, m.values, x0)
+    x, iters, conv = oracle.bicg(m.row_ptr, m.col_ind, m.values, b, tol=1e-14, maxiters=500)
+    assert conv
+    np.testing.assert_allclose(x, x0, rtol=1e-6, atol=1e-8)
+
+
+def test_bicg_nonsymmetric_small():
+    rng = np.random.default_rng(3)
+    n = 60
+    a = sp.random(n, n, 0.1, format="csr", random_state=rng) + sp.diags(np.full(n, 4.0))
+    a = sp.csr_matrix(a)
+    a.sort_indices()
+    x0 = rng.standard_normal(n)
+    b = a @ x0
+    x, _, conv = oracle.bicg(a.indptr, a.indices, a.data, b, tol=1e-12)
+    assert conv
+    np.testing.assert_allclose(x, x0, rtol=1e-8, atol=1e-10)
+
+
+# ---- DSE sweep order (test/TestUtils.cpp) ------------------------------------------
+
+def test_sweep_order_known_answers(known_answers):
+    ka = known_answers["sweep_order"]
+    pts = oracle.sweep_order([tuple(r) for r in ka["ranges"]])
+    as_pairs = [[p["numPipes"], p["frequency"]] for p in pts]
+    assert as_pairs[:4] == ka["first_four"]
+    assert as_pairs[15] == ka["after_15_from_start"]
+    assert as_pairs[16:18] == ka["then"]
+    assert len(pts) == 18                              # every point, last included
