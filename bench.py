@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp64 CSR SpMV on the cant-like matrix (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: y = A x over the whole matrix resident in
+HBM (for N > 1: all-gather of the x slices over RCCL, then the local row-block
+product; weak scaling -- every rank owns one cant-sized row block of a block-
+banded global matrix).  To make the number an HBM number and not an Infinity-
+Cache number the steps rotate through enough device copies of the matrix to
+exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one copy is
+reported next to it.  The K timed steps are captured once into a HIP graph
+(one kernel node per step) so the host's launch rate is not what is measured.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline      -- algorithmic bytes per launch / mean launch time (HIP events on
+                   the launch stream) against the 8 TB/s HBM peak
+  cpu_baseline  -- the CPU oracle (1 core, "port") and MKL's dcsrgemv on all host
+                   cores, both on the same matrix, bounded to ~10 s each.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="cant", choices=["cant", "G3_circuit", "webbase-1M", "atmosmodd"])
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--copies", type=int, default=0, help="matrix copies to rotate through (0 = auto)")
+    ap.add_argument("--variant", default=None, help="force a design point: vector|merge")
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--items", type=int, default=0)
+    ap.add_argument("--wg", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
+    """Time the CPU oracle (sequential C restatement) and MKL on the same matrix."""
+    import oracle
+    out = {}
+    n = rp.size - 1
+    nnz = int(ci.size)
+    y = oracle.csr_spmv(rp, ci, va, x)                  # warm-up + the checker
+    bad, first = oracle.mismatches(y_gpu, y)
+    t0 = time.perf_counter()
+    calls = 0
+    while True:
+        oracle.csr_spmv(rp, ci, va, x)
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or calls >= 5000:
+            break
+    out.update({"value": round(2.0 * nnz * calls / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                "sample": f"{calls} sequential CSR SpMVs of the same {n}x{n} matrix in {el:.1f} s (oracle/cask_oracle.c)",
+                "parity_gpu_vs_cpu_mismatches": bad})
+    # MKL, the CPU library the reference calls (fpgaNaiveCpuCode.cpp:33, SparseLinearSolvers.hpp:189)
+    mkl = None
+    for cand in (os.environ.get("MKLROOT", "/nonexistent") + "/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.1",
+                 "/opt/conda/lib/libmkl_rt.so.2"):
+        if os.path.exists(cand):
+            try:
+                mkl = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                break
+            except OSError:
+                pass
+    if mkl is not None and x.size == n:
+        try:
+            mkl.MKL_Get_Max_Threads.restype = ctypes.c_int
+            threads = int(mkl.MKL_Get_Max_Threads())
+            tr, nn = ctypes.c_char(b"N"), ctypes.c_int(n)
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+            ym = np.zeros(n)
+            args = (ctypes.byref(tr), ctypes.byref(nn), p(va), p(rp), p(ci), p(x), p(ym))
+            for _ in range(3):
+                mkl.mkl_cspblas_dcsrgemv(*args)
+            mbad, _ = oracle.mismatches(ym, y)
+            t0 = time.perf_counter()
+            calls = 0
+            while True:
+                mkl.mkl_cspblas_dcsrgemv(*args)
+                calls += 1
+                el = time.perf_counter() - t0
+                if el >= seconds or calls >= 20000:
+                    break
+            out["mkl"] = {"value": round(2.0 * nnz * calls / el / 1e9, 4), "unit": "GFLOP/s", "threads": threads,
+                          "host_cores": os.cpu_count(), "routine": "mkl_cspblas_dcsrgemv",
+                          "sample": f"{calls} calls in {el:.1f} s", "mismatches_vs_oracle": mbad}
+        except Exception as e:  # pragma: no cover - diagnostic only
+            out["mkl"] = {"error": repr(e)}
+    else:
+        out["mkl"] = None
+    return out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+    os.environ.setdefault("OMP_PROC_BIND", "true")
+
+    import torch
+    import torch.distributed as dist
+    from cask_amd import capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload -----------------------------------------------------------
+    if args.workload == "cant":
+        n_local, n_global, rp, ci, va = synth.cant_like_shard(rank, world)
+        source = "synthetic"
+    else:
+        if world > 1:
+            raise SystemExit("multi-GPU bench is defined for the cant workload")
+        n_local, rp, ci, va, source = synth.load_or_make(args.workload)
+        n_global = n_local
+    nnz_local = int(ci.size)
+    alg_bytes = synth.algorithmic_bytes(n_local, n_global, nnz_local)
+    matrix_bytes = 12 * nnz_local + 4 * (n_local + 1)
+    copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // matrix_bytes) + 1)
+
+    forced = capi.make_params(variant=args.variant or 0, lanes_per_row=args.lanes, tile_width=args.tile,
+                              items_per_thread=args.items, wg_size=args.wg)
+    mats, keep = [], []
+    rp_t = torch.from_numpy(rp).to(dev)
+    for _ in range(copies):
+        ci_t, va_t = torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev)
+        mats.append(capi.CsrMatrix.from_device(n_local, n_global, rp_t, ci_t, va_t, forced))
+    x_host = np.arange(n_global, dtype=np.float64) * 0.25 / n_global        # test_spmv.cpp operand, scaled
+    x_local = torch.from_numpy(x_host[rank * n_local:(rank + 1) * n_local].copy()).to(dev)
+    x_full = torch.from_numpy(x_host).to(dev) if world == 1 else torch.zeros(n_global, dtype=torch.float64, device=dev)
+    y = torch.zeros(n_local, dtype=torch.float64, device=dev)
+
+    # ---- measured DSE on the first copy, applied to all ---------------------------
+    tune_info = None
+    if not args.no_tune and args.variant is None:
+        pts, best = mats[0].tune(warmup=3, iters=30)
+        chosen = mats[0].params
+        for m in mats[1:]:
+            m.set_params(chosen)
+        tune_info = {"points": len(pts), "best_usec_warm": round(pts[best]["usec"], 3)}
+    design = mats[0].params.as_dict()
+    info = mats[0].info
+
+    def step(i):
+        if world > 1:
+            dist.all_gather_into_tensor(x_full, x_local)
+        mats[i % copies].spmv_device(x_full, y)
+
+    # ---- warm-up (eager) -------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    launch_mode = args.launch if world == 1 else "eager"
+    graph = None
+    if launch_mode == "graph":
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(3):
+                    step(i)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for i in range(args.steps):
+                    step(i)
+            graph.replay()                                  # one untimed replay (graph upload)
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
+            graph, launch_mode = None, "eager"
+
+    # ---- timed region: exactly K steps -------------------------------------------
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(args.steps):
+            step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        z = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
+        dist.all_reduce(z, op=dist.ReduceOp.SUM)
+        nnz_total = float(z[0])
+    else:
+        nnz_total = float(nnz_local)
+    y_gpu = y.cpu().numpy()
+
+    # ---- cache-warm rate of ONE copy (what a CG iteration on this matrix sees) ------
+    warm_med, warm_min = mats[0].time(x_full, y, warmup=10, iters=200)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        gflops = 2.0 * nnz_total * args.steps / elapsed / 1e9
+        launch_us = dev_ms * 1e3 / args.steps              # HIP events on the launch stream, whole timed region
+        achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tfile = REPO / "profiles" / f"traffic_{args.workload}.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "SpMV GFLOP/s (fp64 CSR, 2*nnz/t), SuiteSparse cant-like", "value": round(gflops, 2),
+            "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if source == "synthetic" else source,
+            "config": {"workload": f"{args.workload}-like CSR SpMV, {n_local} rows x {n_global} cols per GPU, "
+                                   f"{nnz_local} nnz per GPU, x_i = 0.25 i / n",
+                       "rows": n_local * world, "nnz": int(nnz_total), "parallelism": f"row-blocks x{world}",
+                       "exchange": "none" if world == 1 else "RCCL all_gather(x) per step",
+                       "matrix_copies_rotated": copies, "launch": launch_mode, "design_point": design,
+                       "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info},
+            "hbm_gbs_algorithmic": round(achieved * world, 1),
+            "hbm_pct_of_peak": round(100.0 * achieved / HBM_PEAK_GBS, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_spmv_" + design["variant"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "launch_usec": round(launch_us, 3)},
+            "warm_cache": {"usec_median": round(warm_med, 3), "usec_min": round(warm_min, 3),
+                           "gflops": round(2.0 * nnz_local / warm_med * 1e-3, 2),
+                           "gbs_algorithmic": round(alg_bytes / warm_med * 1e-3, 1),
+                           "note": "one 49 MB copy replayed: served by L2/Infinity Cache, not an HBM figure"},
+        }
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(rp, ci, va, x_host, y_gpu, args.cpu_seconds)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,296 @@
+"""ctypes face of ``libcask_hip.so`` (the C ABI in ``include/cask_hip.h``).
+
+This is plumbing for tests, ``bench.py`` and the multi-GPU driver -- the product
+is the shared library.  There is NO CPU fallback: if the library is missing,
+or no GPU is visible when a matrix is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, byref, c_char, c_double, c_int32, c_int64, c_void_p
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
+
+VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE = 0, 1, 2
+VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge"}
+
+# Every symbol include/cask_hip.h declares (tests check the library exports all of them).
+EXPORTED_SYMBOLS = (
+    "cask_hip_last_error", "cask_hip_abi_version", "cask_hip_device_count", "cask_hip_device_props_get",
+    "cask_hip_csr_create", "cask_hip_csr_create_device", "cask_hip_csr_destroy", "cask_hip_csr_set_params",
+    "cask_hip_csr_get_params", "cask_hip_csr_get_info", "cask_hip_spmv", "cask_hip_spmv_device",
+    "cask_hip_spmv_transpose_device", "cask_hip_spmv_time", "cask_hip_tune", "cask_hip_ddot_device",
+    "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
+)
+
+
+class Params(Structure):
+    _fields_ = [("variant", c_int32), ("lanes_per_row", c_int32), ("tile_width", c_int32),
+                ("wg_size", c_int32), ("items_per_thread", c_int32), ("xcd_remap", c_int32),
+                ("nontemporal", c_int32), ("reserved", c_int32)]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d["variant"] = VARIANT_NAMES.get(d["variant"], d["variant"])
+        return d
+
+
+class CsrInfo(Structure):
+    _fields_ = [("n_rows", c_int32), ("n_cols", c_int32), ("nnz", c_int64), ("grid", c_int32),
+                ("lds_bytes", c_int32), ("n_long_rows", c_int32), ("n_split_rows", c_int32),
+                ("max_row_nnz", c_int32), ("empty_rows", c_int32), ("mean_row_nnz", c_double),
+                ("algorithmic_bytes", c_int64)]
+
+
+class DeviceProps(Structure):
+    _fields_ = [("name", c_char * 64), ("arch", c_char * 32), ("compute_units", c_int32),
+                ("lds_bytes_per_cu", c_int32), ("wavefront_size", c_int32), ("clock_mhz", c_int32),
+                ("hbm_bytes", c_int64), ("l2_bytes", c_int32), ("reserved", c_int32)]
+
+
+class TunePoint(Structure):
+    _fields_ = [("params", Params), ("usec", c_double), ("gflops", c_double), ("gbytes_per_s", c_double),
+                ("valid", c_int32), ("reserved", c_int32)]
+
+
+class CaskHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the engine; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise CaskHipError(f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
+                           "the engine has no CPU fallback")
+    L = ctypes.CDLL(str(LIB_PATH))
+    vp, i32, i64, dbl = c_void_p, c_int32, c_int64, c_double
+    L.cask_hip_last_error.restype = ctypes.c_char_p
+    L.cask_hip_abi_version.restype = ctypes.c_int
+    L.cask_hip_device_count.argtypes = [POINTER(i32)]
+    L.cask_hip_device_props_get.argtypes = [i32, POINTER(DeviceProps)]
+    L.cask_hip_csr_create.argtypes = [i32, i32, i64, vp, vp, vp, POINTER(Params), POINTER(vp)]
+    L.cask_hip_csr_create_device.argtypes = [i32, i32, i64, vp, vp, vp, POINTER(Params), POINTER(vp)]
+    L.cask_hip_csr_destroy.argtypes = [vp]
+    L.cask_hip_csr_set_params.argtypes = [vp, POINTER(Params)]
+    L.cask_hip_csr_get_params.argtypes = [vp, POINTER(Params)]
+    L.cask_hip_csr_get_info.argtypes = [vp, POINTER(CsrInfo)]
+    L.cask_hip_spmv.argtypes = [vp, vp, vp]
+    L.cask_hip_spmv_device.argtypes = [vp, vp, vp, vp]
+    L.cask_hip_spmv_transpose_device.argtypes = [vp, vp, vp, vp]
+    L.cask_hip_spmv_time.argtypes = [vp, vp, vp, i32, i32, POINTER(dbl), POINTER(dbl)]
+    L.cask_hip_tune.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32,
+                                POINTER(TunePoint), i32, POINTER(i32), POINTER(i32)]
+    L.cask_hip_ddot_device.argtypes = [i64, vp, vp, vp, vp]
+    L.cask_hip_daxpy_device.argtypes = [i64, dbl, vp, vp, vp, vp, vp]
+    L.cask_hip_daxpby_device.argtypes = [i64, dbl, vp, dbl, dbl, vp, vp, vp, vp]
+    for name in ("cask_hip_cg", "cask_hip_bicg"):
+        getattr(L, name).argtypes = [vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
+    for name in EXPORTED_SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("cask_hip_last_error",):
+            f.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = load().cask_hip_last_error().decode(errors="replace")
+    if rc == 1:                      # CASK_HIP_ERR_INVALID <-> std::invalid_argument
+        raise ValueError(msg)
+    raise CaskHipError(f"cask_hip error {rc}: {msg}")
+
+
+def device_count() -> int:
+    n = c_int32(0)
+    _check(load().cask_hip_device_count(byref(n)))
+    return n.value
+
+
+def device_props(device: int = 0) -> dict:
+    p = DeviceProps()
+    _check(load().cask_hip_device_props_get(device, byref(p)))
+    return {"name": p.name.decode(), "arch": p.arch.decode(), "compute_units": p.compute_units,
+            "lds_bytes_per_cu": p.lds_bytes_per_cu, "wavefront_size": p.wavefront_size,
+            "clock_mhz": p.clock_mhz, "hbm_bytes": p.hbm_bytes, "l2_bytes": p.l2_bytes}
+
+
+def make_params(variant=0, lanes_per_row=0, tile_width=0, wg_size=0, items_per_thread=0,
+                xcd_remap=0, nontemporal=0) -> Params:
+    if isinstance(variant, str):
+        variant = {v: k for k, v in VARIANT_NAMES.items()}[variant]
+    return Params(variant, lanes_per_row, tile_width, wg_size, items_per_thread, xcd_remap, nontemporal, 0)
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p) if a.size else None
+
+
+def _int_array(vals):
+    if vals is None:
+        return None, 0
+    a = np.ascontiguousarray(list(vals), dtype=np.int32)
+    return a, a.size
+
+
+class CsrMatrix:
+    """A device-resident CSR matrix + launch plan (``cask_hip_matrix*``)."""
+
+    def __init__(self, handle, n_rows, n_cols, nnz, keep=()):
+        self._h = handle
+        self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
+        self._keep = keep            # device tensors borrowed by the handle
+
+    @classmethod
+    def from_host(cls, n_rows, n_cols, row_ptr, col_ind, values, params: Params | None = None):
+        rp, ci, va = _np(row_ptr, np.int32), _np(col_ind, np.int32), _np(values, np.float64)
+        if rp.size != n_rows + 1:
+            raise ValueError("row_ptr must have n_rows+1 entries")
+        if ci.size != va.size:
+            raise ValueError("col_ind and values differ in length")
+        h = c_void_p()
+        _check(load().cask_hip_csr_create(n_rows, n_cols, ci.size, _p(rp), _p(ci), _p(va),
+                                          byref(params) if params is not None else None, byref(h)))
+        return cls(h, n_rows, n_cols, int(ci.size))
+
+    @classmethod
+    def from_device(cls, n_rows, n_cols, row_ptr_t, col_ind_t, values_t, params: Params | None = None):
+        """torch CUDA tensors (int32, int32, float64); borrowed, kept alive by this object."""
+        h = c_void_p()
+        nnz = int(col_ind_t.numel())
+        _check(load().cask_hip_csr_create_device(
+            n_rows, n_cols, nnz, c_void_p(row_ptr_t.data_ptr()),
+            c_void_p(col_ind_t.data_ptr()) if nnz else None,
+            c_void_p(values_t.data_ptr()) if nnz else None,
+            byref(params) if params is not None else None, byref(h)))
+        return cls(h, n_rows, n_cols, nnz, keep=(row_ptr_t, col_ind_t, values_t))
+
+    def close(self):
+        if self._h:
+            load().cask_hip_csr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- design point ---------------------------------------------------------
+    def set_params(self, params: Params | None = None, **kw):
+        if params is None:
+            params = make_params(**kw)
+        _check(load().cask_hip_csr_set_params(self._h, byref(params)))
+
+    @property
+    def params(self) -> Params:
+        p = Params()
+        _check(load().cask_hip_csr_get_params(self._h, byref(p)))
+        return p
+
+    @property
+    def info(self) -> CsrInfo:
+        i = CsrInfo()
+        _check(load().cask_hip_csr_get_info(self._h, byref(i)))
+        return i
+
+    # -- products ---------------------------------------------------------------
+    def spmv(self, x) -> np.ndarray:
+        """Host vectors (the Spmv::spmv contract, Spmv.cpp:185-328)."""
+        x = _np(x, np.float64)
+        if x.size != self.n_cols:
+            raise ValueError(f"x has {x.size} entries, matrix has {self.n_cols} columns")
+        y = np.empty(self.n_rows, dtype=np.float64)
+        _check(load().cask_hip_spmv(self._h, _p(x), _p(y)))
+        return y
+
+    def spmv_device(self, x_t, y_t, stream=None):
+        """torch CUDA tensors; launches on ``stream`` (default: torch's current stream)."""
+        _check(load().cask_hip_spmv_device(self._h, c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                           c_void_p(_stream_ptr(stream))))
+
+    def spmv_transpose_device(self, x_t, y_t, stream=None):
+        _check(load().cask_hip_spmv_transpose_device(self._h, c_void_p(x_t.data_ptr()),
+                                                     c_void_p(y_t.data_ptr()), c_void_p(_stream_ptr(stream))))
+
+    def time(self, x_t, y_t, warmup=5, iters=50):
+        med, mn = c_double(0), c_double(0)
+        _check(load().cask_hip_spmv_time(self._h, c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                         warmup, iters, byref(med), byref(mn)))
+        return med.value, mn.value
+
+    def tune(self, variants=None, lanes=None, tiles=None, wg_sizes=None, items=None, warmup=3, iters=20,
+             max_results=4096):
+        """Measured DSE; leaves the best point active. Returns (points, best_index)."""
+        arrs = [_int_array(v) for v in (variants, lanes, tiles, wg_sizes, items)]
+        res = (TunePoint * max_results)()
+        n, best = c_int32(0), c_int32(-1)
+        args = []
+        for a, cnt in arrs:
+            args += [_p(a) if a is not None else None, cnt]
+        _check(load().cask_hip_tune(self._h, *args, warmup, iters, res, max_results, byref(n), byref(best)))
+        pts = [{"params": res[i].params.as_dict(), "usec": res[i].usec, "gflops": res[i].gflops,
+                "gbytes_per_s": res[i].gbytes_per_s, "valid": bool(res[i].valid)} for i in range(n.value)]
+        return pts, best.value
+
+    # -- solvers ----------------------------------------------------------------
+    def _solve(self, fn, rhs, x0, maxiters, tol):
+        rhs = _np(rhs, np.float64)
+        x = np.zeros(self.n_rows) if x0 is None else _np(x0, np.float64).copy()
+        if rhs.size != self.n_rows or x.size != self.n_rows:
+            raise ValueError("rhs/x0 size mismatch")
+        it, conv, us = c_int32(0), c_int32(0), c_double(0)
+        _check(fn(self._h, _p(rhs), _p(x), int(maxiters), float(tol), byref(it), byref(conv), byref(us)))
+        return x, it.value, bool(conv.value), us.value
+
+    def cg(self, rhs, x0=None, maxiters=2000, tol=1e-5):
+        """(x, iterations, converged, usec_per_iteration); pcg semantics (SparseLinearSolvers.hpp:162-239)."""
+        return self._solve(load().cask_hip_cg, rhs, x0, maxiters, tol)
+
+    def bicg(self, rhs, x0=None, maxiters=2000, tol=1e-5):
+        return self._solve(load().cask_hip_bicg, rhs, x0, maxiters, tol)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+def ddot_device(x_t, y_t, out_t, stream=None):
+    _check(load().cask_hip_ddot_device(x_t.numel(), c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                       c_void_p(out_t.data_ptr()), c_void_p(_stream_ptr(stream))))
+
+
+def daxpy_device(x_t, y_t, sign=1.0, num_t=None, den_t=None, stream=None):
+    """y += sign * (num/den) * x with device-resident scalars."""
+    _check(load().cask_hip_daxpy_device(
+        x_t.numel(), float(sign), c_void_p(num_t.data_ptr()) if num_t is not None else None,
+        c_void_p(den_t.data_ptr()) if den_t is not None else None,
+        c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()), c_void_p(_stream_ptr(stream))))
+
+
+def daxpby_device(alpha, x_t, y_t, beta=0.0, sign=1.0, num_t=None, den_t=None, stream=None):
+    """y = alpha*x + b*y, b = beta or sign*(num/den)."""
+    _check(load().cask_hip_daxpby_device(
+        x_t.numel(), float(alpha), c_void_p(x_t.data_ptr()), float(sign), float(beta),
+        c_void_p(num_t.data_ptr()) if num_t is not None else None,
+        c_void_p(den_t.data_ptr()) if den_t is not None else None,
+        c_void_p(y_t.data_ptr()), c_void_p(_stream_ptr(stream))))

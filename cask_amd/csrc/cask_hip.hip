@@ -1,0 +1,860 @@
+// libcask_hip.so -- the C ABI of include/cask_hip.h: device-resident CSR, launch
+// planning (merge-path cuts, x-window spans), kernel dispatch, measured DSE,
+// BLAS-1 and the CG/BiCG drivers.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "blas1_kernels.hpp"
+#include "cask_hip.h"
+#include "spmv_kernels.hpp"
+
+using namespace caskhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(CASK_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int pow2_floor(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
+}
+
+constexpr int MAX_LDS_BYTES = 64 * 1024;      // per workgroup; keeps >= 2 workgroups per CU (160 KiB LDS)
+constexpr int DEFAULT_TILE = 4096;            // doubles (32 KiB)
+constexpr int LONG_PIECE_FACTOR = 16;         // a long-row piece is at most 16*CAP nonzeros
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+  }
+  hipError_t upload(const T *h, size_t count) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  hipError_t upload(const std::vector<T> &h) { return upload(h.data(), h.size()); }
+};
+
+struct Plan {
+  cask_hip_params prm{};          // resolved
+  int grid = 0;
+  int lds_bytes = 0;
+  bool ldsx = false;
+  // MERGE
+  DevBuf<BlockDesc> blocks;
+  DevBuf<SplitRow> split_rows;
+  DevBuf<double> partials;
+  int n_long_rows = 0, n_split_rows = 0;
+  // VECTOR
+  DevBuf<int2v> xspan;
+};
+
+}  // namespace
+
+struct cask_hip_matrix {
+  int32_t n_rows = 0, n_cols = 0;
+  int64_t nnz = 0;
+  int device = 0;
+  const int *d_rp = nullptr, *d_ci = nullptr;
+  const double *d_val = nullptr;
+  DevBuf<int> own_rp, own_ci;
+  DevBuf<double> own_val;
+  std::vector<int> h_rp;           // row_ptr kept on the host for (re)planning
+  int max_row = 0, empty_rows = 0;
+  cask_hip_params requested{};
+  Plan plan;
+  hipStream_t stream = nullptr;    // for the host-vector entry points and timing
+  DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
+  std::unique_ptr<cask_hip_matrix> transpose;
+  ~cask_hip_matrix() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ planning
+int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip_params &out) {
+  out = in;
+  const double mean = m.n_rows ? (double)m.nnz / m.n_rows : 0.0;
+  if (out.wg_size == 0) out.wg_size = 256;
+  if (!(out.wg_size == 64 || out.wg_size == 128 || out.wg_size == 256 || out.wg_size == 512 ||
+        out.wg_size == 1024))
+    return fail(CASK_HIP_ERR_INVALID, "wg_size must be 64, 128, 256, 512 or 1024");
+  if (out.variant == CASK_HIP_VARIANT_AUTO) {
+    // Regular, moderately long rows: lanes-per-row kernel; short or skewed rows: merge-based.
+    const bool skewed = m.max_row > 8 * std::max(mean, 1.0) + 64;
+    out.variant = (mean >= 12.0 && !skewed) ? CASK_HIP_VARIANT_VECTOR : CASK_HIP_VARIANT_MERGE;
+  }
+  if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE)
+    return fail(CASK_HIP_ERR_INVALID, "unknown variant");
+  if (out.lanes_per_row == 0) {
+    int l = pow2_floor(std::max(1, (int)std::lround(mean / 4.0)));
+    out.lanes_per_row = std::min(64, std::max(out.variant == CASK_HIP_VARIANT_VECTOR ? 2 : 1, l));
+  }
+  if (!is_pow2(out.lanes_per_row) || out.lanes_per_row > 64)
+    return fail(CASK_HIP_ERR_INVALID, "lanes_per_row must be a power of two in 1..64");
+  if (out.items_per_thread == 0) out.items_per_thread = 8;
+  if (!(out.items_per_thread == 2 || out.items_per_thread == 4 || out.items_per_thread == 8 ||
+        out.items_per_thread == 16))
+    return fail(CASK_HIP_ERR_INVALID, "items_per_thread must be 2, 4, 8 or 16");
+  if (out.tile_width == 0) out.tile_width = DEFAULT_TILE;
+  if (out.tile_width < -1) return fail(CASK_HIP_ERR_INVALID, "tile_width must be -1 (off), 0 (default) or > 0");
+  if (out.xcd_remap == 0) out.xcd_remap = 1;
+  if (out.nontemporal == 0) out.nontemporal = 1;
+  if (out.variant == CASK_HIP_VARIANT_MERGE) {
+    const long cap = (long)out.wg_size * out.items_per_thread;
+    if (12 * cap + 24 > MAX_LDS_BYTES)
+      return fail(CASK_HIP_ERR_INVALID, "wg_size*items_per_thread needs more than 64 KiB of LDS");
+  }
+  return CASK_HIP_OK;
+}
+
+// Cut the merge path of (row ends) against (nonzero indices) into workgroup
+// shares of at most CAP items, snapped to row boundaries; rows longer than
+// CAP/2 become long-row pieces of at most 16*CAP nonzeros.
+void build_merge_blocks(const cask_hip_matrix &m, int cap, std::vector<BlockDesc> &blocks,
+                        std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots) {
+  const int *rp = m.h_rp.data();
+  const int long_t = cap / 2;
+  const long piece = (long)cap * LONG_PIECE_FACTOR;
+  n_long = 0;
+  n_partial_slots = 0;
+  int cur_start = 0, cur_rows = 0, cur_nnz = 0;
+  auto close = [&](int next_row) {
+    if (cur_rows == 0) return;
+    BlockDesc d{};
+    d.row_start = cur_start;
+    d.n_rows = cur_rows;
+    d.nnz_start = rp[cur_start];
+    d.nnz_count = cur_nnz;
+    const int mean = cur_nnz / cur_rows;
+    d.kind_g = std::min(64, std::max(1, pow2_floor(std::max(1, mean / 4))));
+    blocks.push_back(d);
+    cur_rows = 0;
+    cur_nnz = 0;
+    cur_start = next_row;
+  };
+  for (int r = 0; r < m.n_rows; r++) {
+    const int len = rp[r + 1] - rp[r];
+    if (len > long_t) {
+      close(r);
+      n_long++;
+      const int n_pieces = (int)((len + piece - 1) / piece);
+      if (n_pieces > 1) splits.push_back(SplitRow{r, n_partial_slots, n_pieces, 0});
+      for (int pc = 0; pc < n_pieces; pc++) {
+        BlockDesc d{};
+        d.row_start = r;
+        d.n_rows = 1;
+        d.nnz_start = rp[r] + (int)(pc * piece);
+        d.nnz_count = (int)std::min<long>(piece, len - pc * piece);
+        d.kind_g = KIND_LONG | (n_pieces > 1 ? KIND_PARTIAL : 0);
+        d.aux = n_pieces > 1 ? n_partial_slots++ : 0;
+        blocks.push_back(d);
+      }
+      cur_start = r + 1;
+      continue;
+    }
+    if (cur_rows > 0 && cur_rows + 1 + cur_nnz + len > cap) close(r);
+    if (cur_rows == 0) cur_start = r;
+    cur_rows++;
+    cur_nnz += len;
+  }
+  close(m.n_rows);
+}
+
+int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
+  cask_hip_params prm;
+  int rc = resolve_params(m, requested, prm);
+  if (rc) return rc;
+  Plan &pl = m.plan;
+  pl.prm = prm;
+  pl.blocks.release();
+  pl.split_rows.release();
+  pl.partials.release();
+  pl.xspan.release();
+  pl.n_long_rows = pl.n_split_rows = 0;
+  pl.grid = 0;
+  pl.lds_bytes = 0;
+  pl.ldsx = false;
+  if (m.n_rows == 0) return CASK_HIP_OK;
+
+  const int tile = prm.tile_width > 0 ? prm.tile_width : 0;
+  if (prm.variant == CASK_HIP_VARIANT_MERGE) {
+    const int cap = prm.wg_size * prm.items_per_thread;
+    std::vector<BlockDesc> blocks;
+    std::vector<SplitRow> splits;
+    int n_long = 0, n_slots = 0;
+    build_merge_blocks(m, cap, blocks, splits, n_long, n_slots);
+    pl.n_long_rows = n_long;
+    pl.n_split_rows = (int)splits.size();
+    pl.grid = (int)blocks.size();
+    HIP_TRY(pl.blocks.upload(blocks));
+    if (!splits.empty()) {
+      HIP_TRY(pl.split_rows.upload(splits));
+      HIP_TRY(pl.partials.alloc(n_slots));
+    }
+    const int base_lds = 12 * cap + 24;
+    int max_width = 0;
+    if (tile > 0 && m.nnz > 0) {
+      hipLaunchKernelGGL(k_col_span_blocks, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid, m.d_ci);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(blocks.data(), pl.blocks.p, blocks.size() * sizeof(BlockDesc),
+                             hipMemcpyDeviceToHost, m.stream));
+      HIP_TRY(hipStreamSynchronize(m.stream));
+      const int budget = (MAX_LDS_BYTES - base_lds) / 8;
+      const int eff_tile = std::min(tile, budget);
+      pl.prm.tile_width = eff_tile;
+      for (const BlockDesc &d : blocks)
+        if (!(d.kind_g & KIND_LONG) && d.cwidth <= eff_tile) max_width = std::max(max_width, d.cwidth);
+    }
+    pl.ldsx = max_width > 0;
+    pl.lds_bytes = base_lds + 8 * max_width;
+  } else {
+    const int rows_per_wg = prm.wg_size / prm.lanes_per_row;
+    pl.grid = (m.n_rows + rows_per_wg - 1) / rows_per_wg;
+    int max_width = 0;
+    if (tile > 0 && m.nnz > 0) {
+      HIP_TRY(pl.xspan.alloc(pl.grid));
+      hipLaunchKernelGGL(k_col_span_rows, dim3(pl.grid), dim3(256), 0, m.stream, pl.xspan.p, pl.grid,
+                         rows_per_wg, m.n_rows, m.d_rp, m.d_ci);
+      HIP_TRY(hipGetLastError());
+      std::vector<int2v> spans(pl.grid);
+      HIP_TRY(hipMemcpyAsync(spans.data(), pl.xspan.p, spans.size() * sizeof(int2v), hipMemcpyDeviceToHost,
+                             m.stream));
+      HIP_TRY(hipStreamSynchronize(m.stream));
+      const int eff_tile = std::min(tile, MAX_LDS_BYTES / 8);
+      pl.prm.tile_width = eff_tile;
+      for (const int2v &s : spans)
+        if (s.y <= eff_tile) max_width = std::max(max_width, (int)s.y);
+    }
+    pl.ldsx = max_width > 0;
+    pl.lds_bytes = 8 * max_width;
+  }
+  if (!pl.ldsx && pl.prm.tile_width > 0 && m.nnz > 0) {
+    // no block fits the tile: run the plain-gather kernels
+  }
+  return CASK_HIP_OK;
+}
+
+// ------------------------------------------------------------------ dispatch
+template <int L>
+int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+  const Plan &pl = m.plan;
+  const dim3 grid(pl.grid), block(pl.prm.wg_size);
+  const int remap = pl.prm.xcd_remap > 0, tile = std::max(0, pl.prm.tile_width);
+  const bool nt = pl.prm.nontemporal > 0;
+#define CASK_LAUNCH_V(LDSX, NT)                                                                          \
+  hipLaunchKernelGGL((k_spmv_vector<L, LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, remap, \
+                     tile, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y)
+  if (pl.ldsx) { if (nt) CASK_LAUNCH_V(true, true); else CASK_LAUNCH_V(true, false); }
+  else         { if (nt) CASK_LAUNCH_V(false, true); else CASK_LAUNCH_V(false, false); }
+#undef CASK_LAUNCH_V
+  return CASK_HIP_OK;
+}
+
+template <int IPT>
+int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+  const Plan &pl = m.plan;
+  const dim3 grid(pl.grid), block(pl.prm.wg_size);
+  const int remap = pl.prm.xcd_remap > 0, tile = std::max(0, pl.prm.tile_width);
+  const bool nt = pl.prm.nontemporal > 0;
+#define CASK_LAUNCH_M(LDSX, NT)                                                                          \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, LDSX, NT>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid,  \
+                     remap, tile, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p)
+  if (pl.ldsx) { if (nt) CASK_LAUNCH_M(true, true); else CASK_LAUNCH_M(true, false); }
+  else         { if (nt) CASK_LAUNCH_M(false, true); else CASK_LAUNCH_M(false, false); }
+#undef CASK_LAUNCH_M
+  if (pl.n_split_rows > 0)
+    hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
+                       pl.n_split_rows, pl.partials.p, y);
+  return CASK_HIP_OK;
+}
+
+int launch_spmv(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+  const Plan &pl = m.plan;
+  if (m.n_rows == 0 || pl.grid == 0) return CASK_HIP_OK;
+  if (pl.prm.variant == CASK_HIP_VARIANT_VECTOR) {
+    switch (pl.prm.lanes_per_row) {
+      case 1:  launch_vector_l<1>(m, x, y, s); break;
+      case 2:  launch_vector_l<2>(m, x, y, s); break;
+      case 4:  launch_vector_l<4>(m, x, y, s); break;
+      case 8:  launch_vector_l<8>(m, x, y, s); break;
+      case 16: launch_vector_l<16>(m, x, y, s); break;
+      case 32: launch_vector_l<32>(m, x, y, s); break;
+      default: launch_vector_l<64>(m, x, y, s); break;
+    }
+  } else {
+    switch (pl.prm.items_per_thread) {
+      case 2:  launch_merge_i<2>(m, x, y, s); break;
+      case 4:  launch_merge_i<4>(m, x, y, s); break;
+      case 8:  launch_merge_i<8>(m, x, y, s); break;
+      default: launch_merge_i<16>(m, x, y, s); break;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
+int check_csr(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row_ptr) {
+  if (n_rows < 0 || n_cols < 0 || nnz < 0) return fail(CASK_HIP_ERR_INVALID, "negative dimension");
+  if (nnz >= (int64_t)std::numeric_limits<int32_t>::max())
+    return fail(CASK_HIP_ERR_INVALID, "nnz must fit int32 (CsrMatrix uses int indices)");
+  if (row_ptr[0] != 0) return fail(CASK_HIP_ERR_INVALID, "row_ptr[0] must be 0");
+  for (int32_t r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] < row_ptr[r]) return fail(CASK_HIP_ERR_INVALID, "row_ptr must be non-decreasing");
+  if (row_ptr[n_rows] != nnz) return fail(CASK_HIP_ERR_INVALID, "row_ptr[n_rows] must equal nnz");
+  return CASK_HIP_OK;
+}
+
+int finish_create(std::unique_ptr<cask_hip_matrix> &m, const cask_hip_params *params, cask_hip_matrix **out) {
+  m->max_row = 0;
+  m->empty_rows = 0;
+  for (int r = 0; r < m->n_rows; r++) {
+    const int len = m->h_rp[r + 1] - m->h_rp[r];
+    m->max_row = std::max(m->max_row, len);
+    m->empty_rows += len == 0;
+  }
+  HIP_TRY(hipGetDevice(&m->device));
+  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  if (params) m->requested = *params;
+  int rc = build_plan(*m, m->requested);
+  if (rc) return rc;
+  *out = m.release();
+  return CASK_HIP_OK;
+}
+
+int ensure_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(CASK_HIP_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+  return CASK_HIP_OK;
+}
+
+int blas_grid(int64_t n) {
+  const int64_t want = (n / 2 + BLAS_WG - 1) / BLAS_WG;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(BLAS_MAX_PARTIALS, want));
+}
+
+// Scratch owned by a solver run.
+struct SolverScratch {
+  DevBuf<double> partials_a, partials_b, scalars;   // scalars: [0..7]
+  DevBuf<int> flags;                                // [0] done, [1] iterations
+};
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+const char *cask_hip_last_error(void) { return g_err.c_str(); }
+int cask_hip_abi_version(void) { return CASK_HIP_ABI_VERSION; }
+
+int cask_hip_device_count(int32_t *count) {
+  if (!count) return fail(CASK_HIP_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  *count = n;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_device_props_get(int32_t device, cask_hip_device_props *out) {
+  if (!out) return fail(CASK_HIP_ERR_INVALID, "out is NULL");
+  int rc = ensure_device();
+  if (rc) return rc;
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  std::memset(out, 0, sizeof(*out));
+  std::snprintf(out->name, sizeof(out->name), "%s", p.name);
+  std::snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+  out->compute_units = p.multiProcessorCount;
+  out->lds_bytes_per_cu = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+  out->wavefront_size = p.warpSize;
+  out->clock_mhz = p.clockRate / 1000;
+  out->hbm_bytes = (int64_t)p.totalGlobalMem;
+  out->l2_bytes = p.l2CacheSize;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_csr_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row_ptr,
+                        const int32_t *col_ind, const double *values, const cask_hip_params *params,
+                        cask_hip_matrix **out) {
+  if (!out) return fail(CASK_HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!row_ptr || (nnz > 0 && (!col_ind || !values))) return fail(CASK_HIP_ERR_INVALID, "NULL array");
+  int rc = check_csr(n_rows, n_cols, nnz, row_ptr);
+  if (rc) return rc;
+  for (int64_t k = 0; k < nnz; k++)
+    if (col_ind[k] < 0 || col_ind[k] >= n_cols) return fail(CASK_HIP_ERR_INVALID, "column index out of range");
+  rc = ensure_device();
+  if (rc) return rc;
+  std::unique_ptr<cask_hip_matrix> m(new cask_hip_matrix);
+  m->n_rows = n_rows;
+  m->n_cols = n_cols;
+  m->nnz = nnz;
+  m->h_rp.assign(row_ptr, row_ptr + n_rows + 1);
+  HIP_TRY(m->own_rp.upload(row_ptr, (size_t)n_rows + 1));
+  HIP_TRY(m->own_ci.upload(col_ind, (size_t)nnz));
+  HIP_TRY(m->own_val.upload(values, (size_t)nnz));
+  m->d_rp = m->own_rp.p;
+  m->d_ci = m->own_ci.p;
+  m->d_val = m->own_val.p;
+  return finish_create(m, params, out);
+}
+
+int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *d_row_ptr,
+                               const int32_t *d_col_ind, const double *d_values,
+                               const cask_hip_params *params, cask_hip_matrix **out) {
+  if (!out) return fail(CASK_HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!d_row_ptr || (nnz > 0 && (!d_col_ind || !d_values))) return fail(CASK_HIP_ERR_INVALID, "NULL array");
+  if (n_rows < 0 || n_cols < 0 || nnz < 0) return fail(CASK_HIP_ERR_INVALID, "negative dimension");
+  int rc = ensure_device();
+  if (rc) return rc;
+  std::unique_ptr<cask_hip_matrix> m(new cask_hip_matrix);
+  m->n_rows = n_rows;
+  m->n_cols = n_cols;
+  m->nnz = nnz;
+  m->h_rp.resize((size_t)n_rows + 1);
+  HIP_TRY(hipMemcpy(m->h_rp.data(), d_row_ptr, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  rc = check_csr(n_rows, n_cols, nnz, m->h_rp.data());
+  if (rc) return rc;
+  m->d_rp = d_row_ptr;
+  m->d_ci = d_col_ind;
+  m->d_val = d_values;
+  return finish_create(m, params, out);
+}
+
+int cask_hip_csr_destroy(cask_hip_matrix *m) {
+  delete m;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_csr_set_params(cask_hip_matrix *m, const cask_hip_params *params) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  cask_hip_params p{};
+  if (params) p = *params;
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = build_plan(*m, p);
+  if (rc) {
+    (void)build_plan(*m, m->requested);       // keep the handle usable with its previous design point
+    return rc;
+  }
+  m->requested = p;
+  if (m->transpose) return cask_hip_csr_set_params(m->transpose.get(), params);
+  return CASK_HIP_OK;
+}
+
+int cask_hip_csr_get_params(const cask_hip_matrix *m, cask_hip_params *out) {
+  if (!m || !out) return fail(CASK_HIP_ERR_INVALID, "NULL argument");
+  *out = m->plan.prm;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out) {
+  if (!m || !out) return fail(CASK_HIP_ERR_INVALID, "NULL argument");
+  std::memset(out, 0, sizeof(*out));
+  out->n_rows = m->n_rows;
+  out->n_cols = m->n_cols;
+  out->nnz = m->nnz;
+  out->grid = m->plan.grid;
+  out->lds_bytes = m->plan.lds_bytes;
+  out->n_long_rows = m->plan.n_long_rows;
+  out->n_split_rows = m->plan.n_split_rows;
+  out->max_row_nnz = m->max_row;
+  out->empty_rows = m->empty_rows;
+  out->mean_row_nnz = m->n_rows ? (double)m->nnz / m->n_rows : 0.0;
+  out->algorithmic_bytes = 12 * m->nnz + 4 * ((int64_t)m->n_rows + 1) + 8 * (int64_t)m->n_cols + 8 * (int64_t)m->n_rows;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  if ((m->n_cols > 0 && !d_x) || (m->n_rows > 0 && !d_y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  return launch_spmv(*m, d_x, d_y, static_cast<hipStream_t>(stream));
+}
+
+int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  if ((m->n_cols > 0 && !x) || (m->n_rows > 0 && !y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  HIP_TRY(hipSetDevice(m->device));
+  if (m->d_x.n != (size_t)m->n_cols || !m->d_x.p) HIP_TRY(m->d_x.alloc(m->n_cols));
+  if (m->d_y.n != (size_t)m->n_rows || !m->d_y.p) HIP_TRY(m->d_y.alloc(m->n_rows));
+  if (m->n_cols)
+    HIP_TRY(hipMemcpyAsync(m->d_x.p, x, (size_t)m->n_cols * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  int rc = launch_spmv(*m, m->d_x.p, m->d_y.p, m->stream);
+  if (rc) return rc;
+  if (m->n_rows)
+    HIP_TRY(hipMemcpyAsync(y, m->d_y.p, (size_t)m->n_rows * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return CASK_HIP_OK;
+}
+
+static int ensure_transpose(cask_hip_matrix *m) {
+  if (m->transpose) return CASK_HIP_OK;
+  // Explicit transpose by counting sort on the host (once); rows of A^T come
+  // out with ascending column (= original row) order.
+  std::vector<int> ci((size_t)m->nnz);
+  std::vector<double> val((size_t)m->nnz);
+  if (m->nnz) {
+    HIP_TRY(hipMemcpy(ci.data(), m->d_ci, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(val.data(), m->d_val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  std::vector<int> trp((size_t)m->n_cols + 1, 0), tci((size_t)m->nnz);
+  std::vector<double> tval((size_t)m->nnz);
+  for (int64_t k = 0; k < m->nnz; k++) trp[ci[k] + 1]++;
+  for (int c = 0; c < m->n_cols; c++) trp[c + 1] += trp[c];
+  std::vector<int> fill(trp.begin(), trp.end() - 1);
+  for (int r = 0; r < m->n_rows; r++)
+    for (int k = m->h_rp[r]; k < m->h_rp[r + 1]; k++) {
+      const int dst = fill[ci[k]]++;
+      tci[dst] = r;
+      tval[dst] = val[k];
+    }
+  cask_hip_matrix *t = nullptr;
+  int rc = cask_hip_csr_create(m->n_cols, m->n_rows, m->nnz, trp.data(), tci.data(), tval.data(), &m->requested, &t);
+  if (rc) return rc;
+  m->transpose.reset(t);
+  return CASK_HIP_OK;
+}
+
+int cask_hip_spmv_transpose_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = ensure_transpose(m);
+  if (rc) return rc;
+  return cask_hip_spmv_device(m->transpose.get(), d_x, d_y, stream);
+}
+
+int cask_hip_spmv_time(cask_hip_matrix *m, const double *d_x, double *d_y, int32_t warmup, int32_t iters,
+                       double *usec_median, double *usec_min) {
+  if (!m || iters <= 0) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(m->device));
+  for (int i = 0; i < warmup; i++) {
+    int rc = launch_spmv(*m, d_x, d_y, m->stream);
+    if (rc) return rc;
+  }
+  std::vector<hipEvent_t> ev((size_t)iters + 1);
+  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipEventRecord(ev[0], m->stream));
+  for (int i = 0; i < iters; i++) {
+    int rc = launch_spmv(*m, d_x, d_y, m->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[i + 1], m->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  std::vector<double> us((size_t)iters);
+  for (int i = 0; i < iters; i++) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    us[i] = ms * 1e3;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  std::sort(us.begin(), us.end());
+  if (usec_median) *usec_median = us[us.size() / 2];
+  if (usec_min) *usec_min = us[0];
+  return CASK_HIP_OK;
+}
+
+int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variants, const int32_t *lanes,
+                  int32_t n_lanes, const int32_t *tiles, int32_t n_tiles, const int32_t *wg_sizes,
+                  int32_t n_wg_sizes, const int32_t *items, int32_t n_items, int32_t warmup, int32_t iters,
+                  cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE};
+  static const int32_t def_lanes[] = {2, 4, 8, 16, 32, 64};
+  static const int32_t def_tiles[] = {-1, 4096};
+  static const int32_t def_wg[] = {256};
+  static const int32_t def_items[] = {4, 8, 16};
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 2; }
+  if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 6; }
+  if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 2; }
+  if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 1; }
+  if (!items || n_items <= 0) { items = def_items; n_items = 3; }
+  if (warmup < 0) warmup = 0;
+  if (iters <= 0) iters = 20;
+  HIP_TRY(hipSetDevice(m->device));
+  DevBuf<double> x, y;
+  HIP_TRY(x.alloc(m->n_cols));
+  HIP_TRY(y.alloc(m->n_rows));
+  {
+    std::vector<double> hx((size_t)m->n_cols);
+    for (int i = 0; i < m->n_cols; i++) hx[i] = 0.25 * i;     // the reference's test operand (test_spmv.cpp:27-28)
+    if (m->n_cols) HIP_TRY(hipMemcpy(x.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const cask_hip_params saved = m->requested;
+  cask_hip_csr_info info;
+  cask_hip_csr_get_info(m, &info);
+  int count = 0, best = -1;
+  double best_us = 0.0;
+  cask_hip_params best_params{};
+  // Odometer over the ranges, first range fastest (Utils.hpp:173-192); unlike
+  // Dse.cpp:40-47 the last point is evaluated too.  lanes only matter for
+  // VECTOR and items only for MERGE: irrelevant repeats are skipped.
+  for (int iv = 0; iv < n_items; iv++)
+    for (int iw = 0; iw < n_wg_sizes; iw++)
+      for (int it = 0; it < n_tiles; it++)
+        for (int il = 0; il < n_lanes; il++)
+          for (int iva = 0; iva < n_variants; iva++) {
+            const int variant = variants[iva];
+            if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
+            if (variant == CASK_HIP_VARIANT_MERGE && il != 0) continue;
+            cask_hip_tune_point pt{};
+            pt.params = saved;
+            pt.params.variant = variant;
+            pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
+            pt.params.items_per_thread = variant == CASK_HIP_VARIANT_MERGE ? items[iv] : 0;
+            pt.params.tile_width = tiles[it];
+            pt.params.wg_size = wg_sizes[iw];
+            int rc = build_plan(*m, pt.params);
+            if (rc == CASK_HIP_OK && m->plan.prm.variant == CASK_HIP_VARIANT_VECTOR &&
+                m->plan.prm.wg_size < m->plan.prm.lanes_per_row)
+              rc = CASK_HIP_ERR_INVALID;
+            if (rc == CASK_HIP_OK) {
+              double med = 0, mn = 0;
+              rc = cask_hip_spmv_time(m, x.p, y.p, warmup, iters, &med, &mn);
+              if (rc == CASK_HIP_OK) {
+                pt.params = m->plan.prm;
+                pt.usec = med;
+                pt.gflops = med > 0 ? 2.0 * m->nnz / med * 1e-3 : 0.0;
+                pt.gbytes_per_s = med > 0 ? info.algorithmic_bytes / med * 1e-3 : 0.0;
+                pt.valid = 1;
+                if (best < 0 || med < best_us) { best = count; best_us = med; best_params = pt.params; }
+              }
+            }
+            if (results && count < max_results) results[count] = pt;
+            count++;
+          }
+  if (n_results) *n_results = std::min(count, max_results);
+  if (best_index) *best_index = (best < max_results) ? best : -1;
+  int rc;
+  if (best >= 0) {
+    rc = build_plan(*m, best_params);
+    if (rc == CASK_HIP_OK) m->requested = best_params;
+  } else {
+    rc = build_plan(*m, saved);
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------- BLAS-1
+int cask_hip_ddot_device(int64_t n, const double *d_x, const double *d_y, double *d_result, void *stream) {
+  if (n < 0 || !d_result || (n > 0 && (!d_x || !d_y))) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // partial buffer: one allocation per (thread, device) kept for reuse
+  static thread_local double *scratch = nullptr;
+  static thread_local int scratch_dev = -1;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (!scratch || scratch_dev != dev) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), BLAS_MAX_PARTIALS * sizeof(double)));
+    scratch_dev = dev;
+  }
+  const int grid = blas_grid(n);
+  hipLaunchKernelGGL(k_dot_partial, dim3(grid), dim3(BLAS_WG), 0, s, n, d_x, d_y, scratch, (const int *)nullptr);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(BLAS_WG), 0, s, grid, scratch, d_result, 0, 0.0, (int *)nullptr,
+                     (int *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
+int cask_hip_daxpy_device(int64_t n, double sign, const double *d_num, const double *d_den, const double *d_x,
+                          double *d_y, void *stream) {
+  if (n < 0 || (n > 0 && (!d_x || !d_y))) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_axpy, dim3(blas_grid(n)), dim3(BLAS_WG), 0, static_cast<hipStream_t>(stream), n, sign, d_num,
+                     d_den, d_x, d_y, (const int *)nullptr);
+  HIP_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
+int cask_hip_daxpby_device(int64_t n, double alpha, const double *d_x, double sign, double beta,
+                           const double *d_num, const double *d_den, double *d_y, void *stream) {
+  if (n < 0 || (n > 0 && (!d_x || !d_y))) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_axpby, dim3(blas_grid(n)), dim3(BLAS_WG), 0, static_cast<hipStream_t>(stream), n, alpha, d_x,
+                     sign, beta, d_num, d_den, d_y, (const int *)nullptr);
+  HIP_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
+// ---------------------------------------------------------------------- solvers
+static int solver_common_checks(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol) {
+  if (!m || !rhs || !x) return fail(CASK_HIP_ERR_INVALID, "NULL argument");
+  if (m->n_rows != m->n_cols) return fail(CASK_HIP_ERR_INVALID, "solver needs a square matrix");
+  if (maxiters < 0 || !(tol >= 0)) return fail(CASK_HIP_ERR_INVALID, "bad maxiters/tol");
+  return CASK_HIP_OK;
+}
+
+int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+  int rc = solver_common_checks(m, rhs, x, maxiters, tol);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  const int64_t n = m->n_rows;
+  hipStream_t s = m->stream;
+  DevBuf<double> dx, db, r, p, Ap, partials, scal;
+  DevBuf<int> flags;
+  HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
+  HIP_TRY(r.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
+  HIP_TRY(partials.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  double *rs[2] = {scal.p, scal.p + 1};
+  double *pAp = scal.p + 2;
+  int *done = flags.p, *iters = flags.p + 1;
+  const int g = blas_grid(n);
+  const dim3 bg(g), bw(BLAS_WG);
+  // r = b - A x ; p = r ; rsold = r.r      (SparseLinearSolvers.hpp:189-198)
+  rc = launch_spmv(*m, dx.p, r.p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
+                     r.p, (const int *)nullptr);
+  HIP_TRY(hipMemcpyAsync(p.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, r.p, partials.p, (const int *)nullptr);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  const int check_every = 16;
+  int h_flags[2] = {0, 0};
+  int launched = 0;
+  for (int i = 0; i < maxiters; i++) {
+    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
+    rc = launch_spmv(*m, p.p, Ap.p, s);                                                 // :206
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, pAp, 0, 0.0, done, (int *)nullptr, 0);
+    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp, p.p, Ap.p, dx.p, r.p, partials.p,
+                       (const int *)done);                                              // :208-218
+    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rsnew, 1, tol * tol, done, iters, i);  // :220-231
+    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, rsnew, rsold, r.p, p.p, (const int *)done);  // :229
+    launched = i + 1;
+    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h_flags[0]) break;
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (iterations) *iterations = h_flags[1];
+  if (converged) *converged = h_flags[0];
+  if (usec_per_iteration) *usec_per_iteration = launched ? ms * 1e3 / launched : 0.0;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                  int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+  int rc = solver_common_checks(m, rhs, x, maxiters, tol);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  rc = ensure_transpose(m);
+  if (rc) return rc;
+  cask_hip_matrix &mt = *m->transpose;
+  const int64_t n = m->n_rows;
+  hipStream_t s = m->stream;
+  DevBuf<double> dx, db, r, rt, p, pt, q, qt, part_a, part_b, scal;
+  DevBuf<int> flags;
+  HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
+  HIP_TRY(r.alloc(n)); HIP_TRY(rt.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(pt.alloc(n));
+  HIP_TRY(q.alloc(n)); HIP_TRY(qt.alloc(n));
+  HIP_TRY(part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_b.alloc(BLAS_MAX_PARTIALS));
+  HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  double *rho[2] = {scal.p, scal.p + 1};
+  double *ptq = scal.p + 2, *rr = scal.p + 3;
+  int *done = flags.p, *iters = flags.p + 1;
+  const int g = blas_grid(n);
+  const dim3 bg(g), bw(BLAS_WG);
+  rc = launch_spmv(*m, dx.p, r.p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
+                     r.p, (const int *)nullptr);
+  HIP_TRY(hipMemcpyAsync(rt.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(p.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(pt.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, rt.p, r.p, part_a.p, (const int *)nullptr);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, rho[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  const int check_every = 16;
+  int h_flags[2] = {0, 0};
+  int launched = 0;
+  for (int i = 0; i < maxiters; i++) {
+    double *rho_old = rho[i & 1], *rho_new = rho[(i + 1) & 1];
+    rc = launch_spmv(*m, p.p, q.p, s);
+    if (rc) return rc;
+    rc = launch_spmv(mt, pt.p, qt.p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_a.p, (const int *)done);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, ptq, 0, 0.0, done, (int *)nullptr, 0);
+    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, ptq, p.p, q.p, qt.p, dx.p, r.p, rt.p, part_a.p,
+                       part_b.p, (const int *)done);
+    // rho_new first (no test), then r.r with the convergence test, so that a
+    // converged pass leaves rho_new written but p/pt untouched.
+    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_b.p, rho_new, 0, 0.0, done, (int *)nullptr, 0);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, rr, 1, tol * tol, done, iters, i);
+    hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, rho_new, rho_old, r.p, rt.p, p.p, pt.p, (const int *)done);
+    launched = i + 1;
+    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h_flags[0]) break;
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (iterations) *iterations = h_flags[1];
+  if (converged) *converged = h_flags[0];
+  if (usec_per_iteration) *usec_per_iteration = launched ? ms * 1e3 / launched : 0.0;
+  return CASK_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""Row-sharded SpMV / CG across the GPUs of one node: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
+CPU tests).  Plumbing only -- the arithmetic is the C-ABI engine.
+
+The reference has no multi-device code at all; its only
+precedent is the per-pipe contiguous row split of Spmv::preprocess
+(src/runtime/Spmv.cpp:334-364), which splits by ROW COUNT.  Here blocks are
+nnz-balanced, each rank owns rows [r_g, r_{g+1}) with global column indices,
+the matching slice of every vector, and one exchange per product:
+
+    x_full = all_gather(x_local)          (RCCL; 8*n bytes in total)
+    y_local = A_g @ x_full                (local HIP kernel)
+
+Dot products are a local two-stage reduction plus a one-element all_reduce.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition_rows_by_nnz(row_ptr, world: int):
+    """Contiguous row blocks with ~equal nnz (+1 per row so empty rows spread too).
+    Returns world+1 boundaries; deterministic, identical on every rank."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    n = row_ptr.size - 1
+    work = row_ptr + np.arange(n + 1, dtype=np.int64)       # merge-path diagonal: nnz + rows
+    total = work[-1]
+    bounds = [0]
+    for g in range(1, world):
+        target = total * g // world
+        r = int(np.searchsorted(work, target, side="left"))
+        bounds.append(min(max(r, bounds[-1]), n))
+    bounds.append(n)
+    return bounds
+
+
+def partition_rows_even(n: int, world: int):
+    """Equal row counts (the reference's rule, remainder to the last block; Spmv.cpp:334,353-364)."""
+    per = n // world
+    return [g * per for g in range(world)] + [n]
+
+
+def slice_rows(row_ptr, col_ind, values, r0: int, r1: int):
+    row_ptr = np.asarray(row_ptr)
+    k0, k1 = int(row_ptr[r0]), int(row_ptr[r1])
+    return (row_ptr[r0:r1 + 1] - k0).astype(np.int32), np.asarray(col_ind[k0:k1], dtype=np.int32), \
+        np.asarray(values[k0:k1], dtype=np.float64)
+
+
+class ShardedSpmv:
+    """y_local = A[rows of this rank, :] @ all_gather(x_local).
+
+    ``local_product(x_full_tensor, y_local_tensor)`` performs the local block
+    product; on GPUs it is ``capi.CsrMatrix.spmv_device`` (built by
+    ``from_global``), in the gloo CPU tests the test injects a checker.
+    """
+
+    def __init__(self, bounds, rank: int, world: int, local_product, device, group=None):
+        import torch
+        self.torch = torch
+        self.bounds = list(bounds)
+        self.rank, self.world = rank, world
+        self.local_product = local_product
+        self.device = device
+        self.group = group
+        self.n = self.bounds[-1]
+        self.sizes = [self.bounds[g + 1] - self.bounds[g] for g in range(world)]
+        self.n_local = self.sizes[rank]
+        self.max_local = max(self.sizes) if self.sizes else 0
+        self.even = all(s == self.max_local for s in self.sizes)
+        self.x_full = torch.zeros(self.n, dtype=torch.float64, device=device)
+        if not self.even:
+            self._pad_in = torch.zeros(self.max_local, dtype=torch.float64, device=device)
+            self._pad_out = torch.zeros(self.max_local * world, dtype=torch.float64, device=device)
+
+    @classmethod
+    def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None):
+        """Build this rank's block of a globally known CSR matrix on the current GPU."""
+        import torch
+        from . import capi
+        n = len(row_ptr) - 1
+        bounds = partition_rows_by_nnz(row_ptr, world) if balance == "nnz" else partition_rows_even(n, world)
+        if n != n_cols:
+            raise ValueError("row sharding with an all-gathered x needs a square matrix")
+        rp, ci, va = slice_rows(row_ptr, col_ind, values, bounds[rank], bounds[rank + 1])
+        mat = capi.CsrMatrix.from_host(bounds[rank + 1] - bounds[rank], n_cols, rp, ci, va, params)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
+        obj.matrix = mat
+        return obj
+
+    # -- exchange ---------------------------------------------------------------
+    def gather_x(self, x_local):
+        """all-gather of the x slices into self.x_full (uneven slices are padded to the longest)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            self.x_full.copy_(x_local)
+            return self.x_full
+        if self.even:
+            dist.all_gather_into_tensor(self.x_full, x_local.contiguous(), group=self.group)
+            return self.x_full
+        self._pad_in[: self.n_local].copy_(x_local)
+        dist.all_gather_into_tensor(self._pad_out, self._pad_in, group=self.group)
+        for g in range(self.world):
+            self.x_full[self.bounds[g]: self.bounds[g + 1]].copy_(
+                self._pad_out[g * self.max_local: g * self.max_local + self.sizes[g]])
+        return self.x_full
+
+    def spmv(self, x_local, y_local=None):
+        if y_local is None:
+            y_local = self.torch.empty(self.n_local, dtype=self.torch.float64, device=self.device)
+        xf = self.gather_x(x_local)
+        self.local_product(xf, y_local)
+        return y_local
+
+    def dot(self, a_local, b_local):
+        """Global dot product as a 1-element tensor on the device (no host sync)."""
+        import torch.distributed as dist
+        s = (a_local * b_local).sum().reshape(1)
+        if self.world > 1:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return s
+
+    def cg(self, b_local, x_local=None, maxiters=2000, tol=1e-5):
+        """Distributed un-preconditioned CG with the recurrence, stopping rule and
+        `iterations` convention of pcg (src/runtime/SparseLinearSolvers.hpp:162-239).
+        Every rank sees the same all-reduced scalars, so all ranks stop in the same
+        pass.  Returns (x_local, iterations, converged)."""
+        torch = self.torch
+        x = torch.zeros_like(b_local) if x_local is None else x_local.clone()
+        r = b_local - self.spmv(x)                               # :189-190
+        p = r.clone()
+        rsold = self.dot(r, r)                                   # :198
+        iterations, tol2 = 0, tol * tol
+        for i in range(maxiters):
+            Ap = self.spmv(p)                                    # :206
+            alpha = rsold / self.dot(p, Ap)                      # :208
+            x = x + alpha * p                                    # :210
+            r = r - alpha * Ap                                   # :212
+            rsnew = self.dot(r, r)                               # :218
+            if float(rsnew) <= tol2:                             # :220
+                return x, iterations, True
+            p = r + (rsnew / rsold) * p                          # :229
+            rsold = rsnew
+            iterations = i                                       # :231
+        return x, iterations, False

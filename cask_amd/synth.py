@@ -1,0 +1,225 @@
+"""Seeded synthetic stand-ins for the SuiteSparse matrices BASELINE.json names.
+
+The real files (cant, G3_circuit, webbase-1M, atmosmodd) are not in the
+reference checkout and there is no network, so each generator reproduces the
+published shape statistics: dimension, nnz, row-length
+profile, bandedness, symmetry.  If ``$CASK_MATRIX_DIR/<name>.mtx`` exists the
+benchmark uses the real file instead (see ``load_or_make``).
+
+All generators return ``(n, row_ptr[int32], col_ind[int32], values[float64])``
+with sorted, duplicate-free rows, and are pure numpy so they run identically
+in the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+
+import numpy as np
+
+SPECS = {
+    # name: (n, nnz of the real SuiteSparse matrix)
+    "cant": (62_451, 4_007_383),
+    "G3_circuit": (1_585_478, 7_660_826),
+    "webbase-1M": (1_000_005, 3_105_536),
+    "atmosmodd": (1_270_432, 8_814_880),
+}
+
+
+def _coo_to_csr(n, rows, cols, vals):
+    """Sort by (row, col), keep the first of any duplicate."""
+    key = rows.astype(np.int64) * n + cols.astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    key, vals = key[order], vals[order]
+    first = np.ones(key.size, dtype=bool)
+    first[1:] = key[1:] != key[:-1]
+    key, vals = key[first], vals[first]
+    r = (key // n).astype(np.int64)
+    c = (key % n).astype(np.int32)
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(row_ptr, r + 1, 1)
+    return np.cumsum(row_ptr).astype(np.int32), c, vals.astype(np.float64)
+
+
+def cant_like(n=62_451, per_row=33, band=400, seed=0):
+    """Symmetric banded FEM-like SPD matrix, ~2*per_row+1 nnz per row (cant: ~64)."""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    cols = rows + rng.integers(1, band + 1, size=rows.size)
+    vals = rng.standard_normal(rows.size)
+    keep = cols < n
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    # unique upper-triangle pairs, then mirror
+    key = rows * n + cols
+    _, idx = np.unique(key, return_index=True)
+    rows, cols, vals = rows[idx], cols[idx], vals[idx]
+    absum = np.zeros(n)
+    np.add.at(absum, rows, np.abs(vals))
+    np.add.at(absum, cols, np.abs(vals))
+    diag = np.arange(n, dtype=np.int64)
+    R = np.concatenate([rows, cols, diag])
+    C = np.concatenate([cols, rows, diag])
+    V = np.concatenate([vals, vals, 1.0 + absum])
+    rp, ci, va = _coo_to_csr(n, R, C, V)
+    return n, rp, ci, va
+
+
+def g3_like(n=1_585_478, nx=1259, extra_frac=0.01, seed=2):
+    """2-D 5-point grid Laplacian + 1% random long-range symmetric edges, shifted SPD (~4.8 nnz/row)."""
+    rng = np.random.default_rng(seed)
+    i = np.arange(n, dtype=np.int64)
+    right = i[(i % nx != nx - 1) & (i + 1 < n)]
+    down = i[i + nx < n]
+    n_extra = int(extra_frac * n)
+    ea = rng.integers(0, n, size=n_extra)
+    eb = rng.integers(0, n, size=n_extra)
+    ok = ea != eb
+    ea, eb = ea[ok], eb[ok]
+    a = np.concatenate([right, down, np.minimum(ea, eb)])
+    b = np.concatenate([right + 1, down + nx, np.maximum(ea, eb)])
+    key = a * n + b
+    _, idx = np.unique(key, return_index=True)
+    a, b = a[idx], b[idx]
+    deg = np.zeros(n)
+    np.add.at(deg, a, 1.0)
+    np.add.at(deg, b, 1.0)
+    R = np.concatenate([a, b, i])
+    C = np.concatenate([b, a, i])
+    V = np.concatenate([-np.ones(a.size), -np.ones(a.size), deg + 1e-3])
+    rp, ci, va = _coo_to_csr(n, R, C, V)
+    return n, rp, ci, va
+
+
+def webbase_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, seed=3):
+    """Power-law row lengths (Zipf alpha, clipped), 70% of columns within +-1000 of the diagonal."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.zipf(alpha, size=n), max_row).astype(np.int64)
+    # rescale towards the target nnz while keeping every row >= 1 and the tail
+    scale = nnz_target / lens.sum()
+    lens = np.clip(np.rint(lens * scale), 1, max_row).astype(np.int64)
+    lens[rng.integers(0, n)] = max_row                       # make sure the longest row exists
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    local = rng.random(rows.size) < 0.7
+    cols = np.where(local, rows + rng.integers(-1000, 1001, size=rows.size),
+                    rng.integers(0, n, size=rows.size))
+    cols = np.clip(cols, 0, n - 1)
+    vals = rng.random(rows.size)
+    rp, ci, va = _coo_to_csr(n, rows, cols, vals)
+    return n, rp, ci, va
+
+
+def atmosmodd_like(n=1_270_432, nx=108, ny=108, seed=4):
+    """Nonsymmetric 3-D 7-point advection-diffusion stencil (~6.9 nnz/row), diagonally dominant."""
+    del seed
+    i = np.arange(n, dtype=np.int64)
+    plane = nx * ny
+    parts_r, parts_c, parts_v = [i], [i], [np.full(n, 6.5)]
+
+    def add(mask, off, coef):
+        src = i[mask]
+        parts_r.append(src)
+        parts_c.append(src + off)
+        parts_v.append(np.full(src.size, coef))
+
+    add((i % nx != nx - 1) & (i + 1 < n), 1, -1.0 - 0.2)
+    add(i % nx != 0, -1, -1.0 + 0.2)
+    add(((i // nx) % ny != ny - 1) & (i + nx < n), nx, -1.0 - 0.1)
+    add((i // nx) % ny != 0, -nx, -1.0 + 0.1)
+    add(i + plane < n, plane, -1.0 - 0.05)
+    add(i - plane >= 0, -plane, -1.0 + 0.05)
+    rp, ci, va = _coo_to_csr(n, np.concatenate(parts_r), np.concatenate(parts_c), np.concatenate(parts_v))
+    return n, rp, ci, va
+
+
+GENERATORS = {"cant": cant_like, "G3_circuit": g3_like, "webbase-1M": webbase_like, "atmosmodd": atmosmodd_like}
+
+
+def small(name, factor=16):
+    """A reduced-size instance of the same family (for parity tests)."""
+    n_full = SPECS[name][0]
+    n = max(64, n_full // factor)
+    if name == "cant":
+        return cant_like(n=n)
+    if name == "G3_circuit":
+        return g3_like(n=n, nx=max(8, int(round((n) ** 0.5))))
+    if name == "webbase-1M":
+        return webbase_like(n=n, nnz_target=int(SPECS[name][1] / factor), max_row=min(4700, n // 2))
+    if name == "atmosmodd":
+        side = max(4, int(round(n ** (1 / 3))))
+        return atmosmodd_like(n=n, nx=side, ny=side)
+    raise KeyError(name)
+
+
+def row_stats(row_ptr):
+    lens = np.diff(row_ptr)
+    return {"n": int(lens.size), "nnz": int(row_ptr[-1]), "row_min": int(lens.min()) if lens.size else 0,
+            "row_mean": float(lens.mean()) if lens.size else 0.0, "row_max": int(lens.max()) if lens.size else 0,
+            "row_std": float(lens.std()) if lens.size else 0.0, "empty_rows": int((lens == 0).sum())}
+
+
+def algorithmic_bytes(n_rows, n_cols, nnz):
+    """fp64 value + int32 column per nonzero, row_ptr, x read once, y written once."""
+    return 12 * nnz + 4 * (n_rows + 1) + 8 * n_cols + 8 * n_rows
+
+
+def load_or_make(name):
+    """Real SuiteSparse file from $CASK_MATRIX_DIR if present, else the synthetic look-alike.
+    Returns (n, row_ptr, col_ind, values, source)."""
+    d = os.environ.get("CASK_MATRIX_DIR")
+    if d:
+        p = Path(d) / f"{name}.mtx"
+        if p.exists():
+            import scipy.io
+            import scipy.sparse as sp
+            a = sp.csr_matrix(scipy.io.mmread(str(p)))
+            a.sort_indices()
+            return a.shape[0], a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64), str(p)
+    n, rp, ci, va = GENERATORS[name]()
+    return n, rp, ci, va, "synthetic"
+
+
+def cant_like_shard(rank, world, n_local=62_451, per_row=33, band=400, n_couple=4000):
+    """Row block `rank` of a (world*n_local)-square block-banded SPD matrix for weak scaling:
+    diagonal blocks are independent cant_like() instances (seed = rank), neighbouring blocks are
+    coupled through the band that crosses their seam, so the product needs the neighbours' x.
+    Columns are GLOBAL indices.  Returns (n_local, n_global, row_ptr, col_ind, values)."""
+    n, rp, ci, va = cant_like(n=n_local, per_row=per_row, band=band, seed=rank)
+    n_global = world * n_local
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    cols = ci.astype(np.int64) + rank * n_local
+    vals = va.copy()
+    extra_r, extra_c, extra_v = [], [], []
+
+    def seam(g):
+        """coupling between block g (last rows) and block g+1 (first columns): (i_in_g, j_in_g1, v)."""
+        rng = np.random.default_rng(10_000 + g)
+        i = rng.integers(n_local - band, n_local, size=n_couple)
+        off = rng.integers(1, band + 1, size=n_couple)
+        j = i + off - n_local
+        ok = j >= 0
+        i, j = i[ok], j[ok]
+        key = i * band + j
+        _, idx = np.unique(key, return_index=True)
+        return i[idx], j[idx], 0.01 * rng.standard_normal(idx.size)
+
+    diag_add = np.zeros(n)
+    if rank + 1 < world:
+        i, j, v = seam(rank)
+        extra_r.append(i); extra_c.append(j + (rank + 1) * n_local); extra_v.append(v)
+        np.add.at(diag_add, i, np.abs(v))
+    if rank > 0:
+        i, j, v = seam(rank - 1)                      # transpose side: row j of this block, column i of the previous
+        extra_r.append(j); extra_c.append(i + (rank - 1) * n_local); extra_v.append(v)
+        np.add.at(diag_add, j, np.abs(v))
+    if extra_r:
+        rows = np.concatenate([rows] + extra_r)
+        cols = np.concatenate([cols] + extra_c)
+        vals = np.concatenate([vals] + extra_v)
+    is_diag = cols == rows + rank * n_local
+    vals = vals + np.where(is_diag, diag_add[rows], 0.0)
+    key = rows * n_global + cols
+    order = np.argsort(key, kind="stable")
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(row_ptr, rows + 1, 1)
+    return n, n_global, np.cumsum(row_ptr).astype(np.int32), cols.astype(np.int32), vals

@@ -1,0 +1,191 @@
+/*
+ * cask_hip.h -- thin C ABI of the MI355X (gfx950) SpMV engine that replaces the
+ * Maxeler DFE backend of CASK.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes.  No C++
+ * types, no torch types.  Every entry point names the reference interface it
+ * stands in for (paths relative to the reference checkout).  Status 0 is
+ * success; on failure cask_hip_last_error() returns a thread-local message.
+ *
+ * Parameter mapping from the reference's architecture parameters
+ * (src/runtime/GeneratedImplSupport.hpp:56, src/frontend/params.json):
+ *   input_width     -> lanes_per_row   (rows per wavefront = 64 / lanes_per_row)
+ *   cache_size      -> tile_width      (x-vector tile staged in LDS, doubles)
+ *   num_pipes       -> workgroups      (derived: grid size; not a parameter)
+ *   num_controllers -> GPUs            (one process per GPU; see cask_amd/dist.py)
+ *   max_rows        -> no limit        (HBM holds any int32-indexed matrix)
+ */
+#ifndef CASK_HIP_H
+#define CASK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASK_HIP_ABI_VERSION 1
+
+/* status codes */
+#define CASK_HIP_OK               0
+#define CASK_HIP_ERR_INVALID      1   /* bad argument (maps to std::invalid_argument) */
+#define CASK_HIP_ERR_RUNTIME      2   /* HIP runtime failure (maps to std::runtime_error) */
+#define CASK_HIP_ERR_NO_DEVICE    3   /* no gfx950 device visible */
+#define CASK_HIP_ERR_ALLOC        4
+
+/* kernel variants */
+#define CASK_HIP_VARIANT_AUTO     0   /* pick from row-length statistics */
+#define CASK_HIP_VARIANT_VECTOR   1   /* lanes_per_row lanes of a wavefront per row (1 = thread per row) */
+#define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, streamed through LDS */
+
+typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launch plan */
+
+/* Architecture parameters of one SpMV "design point"; 0 in any field = default
+ * (tile_width, xcd_remap, nontemporal: 0 = default, -1 = off).
+ * The DSE (cask_hip_tune) sweeps these per matrix exactly as the reference's
+ * DSE sweeps num_pipes/input_width/cache_size (src/runtime/Dse.cpp:103-109). */
+typedef struct cask_hip_params {
+  int32_t variant;          /* CASK_HIP_VARIANT_*                                   */
+  int32_t lanes_per_row;    /* VECTOR: 1,2,4,...,64                                  */
+  int32_t tile_width;       /* doubles of x staged in LDS per workgroup; -1 = no tile */
+  int32_t wg_size;          /* threads per workgroup: 64,128,256,512,1024            */
+  int32_t items_per_thread; /* MERGE: merge items per thread: 2,4,8,16               */
+  int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off                 */
+  int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
+  int32_t reserved;
+} cask_hip_params;
+
+typedef struct cask_hip_csr_info {
+  int32_t n_rows, n_cols;
+  int64_t nnz;
+  int32_t grid;             /* workgroups per launch                  */
+  int32_t lds_bytes;        /* dynamic LDS per workgroup              */
+  int32_t n_long_rows;      /* rows handled by the long-row path      */
+  int32_t n_split_rows;     /* rows split over several workgroups     */
+  int32_t max_row_nnz;
+  int32_t empty_rows;
+  double  mean_row_nnz;
+  int64_t algorithmic_bytes;/* 12*nnz + 4*(n_rows+1) + 8*n_cols + 8*n_rows */
+} cask_hip_csr_info;
+
+typedef struct cask_hip_device_props {
+  char    name[64];
+  char    arch[32];
+  int32_t compute_units;
+  int32_t lds_bytes_per_cu;
+  int32_t wavefront_size;
+  int32_t clock_mhz;
+  int64_t hbm_bytes;
+  int32_t l2_bytes;
+  int32_t reserved;
+} cask_hip_device_props;
+
+/* one measured design point (the measured counterpart of the reference's
+ * estimated_gflops entries in dse_out.json, src/main.cpp:81-117) */
+typedef struct cask_hip_tune_point {
+  cask_hip_params params;
+  double  usec;             /* median kernel time per SpMV             */
+  double  gflops;           /* 2*nnz / t                               */
+  double  gbytes_per_s;     /* algorithmic bytes / t                   */
+  int32_t valid;            /* 0 = rejected (e.g. LDS over budget)     */
+  int32_t reserved;
+} cask_hip_tune_point;
+
+const char *cask_hip_last_error(void);
+int cask_hip_abi_version(void);
+
+/* Devices.  Replaces cask::model::DeviceModel's constants
+ * (src/runtime/Model.hpp:93-136) with what the HIP runtime reports. */
+int cask_hip_device_count(int32_t *count);
+int cask_hip_device_props_get(int32_t device, cask_hip_device_props *out);
+
+/* Upload a 0-based CSR matrix (host pointers, borrowed for the call) to the
+ * current HIP device and build the launch plan.  Replaces
+ * Spmv::preprocess (src/runtime/Spmv.cpp:329-365) together with the matrix
+ * half of writeDataForPartition / Spmv_<id>_dramWrite
+ * (Spmv.cpp:144-183, GeneratedImplSupport.hpp:44-49): the matrix is uploaded
+ * ONCE here, not on every spmv() call.  params may be NULL (all defaults). */
+int cask_hip_csr_create(int32_t n_rows, int32_t n_cols, int64_t nnz,
+                        const int32_t *row_ptr, const int32_t *col_ind, const double *values,
+                        const cask_hip_params *params, cask_hip_matrix **out);
+
+/* Same, but the three arrays already live in device memory and stay owned by
+ * the caller (they must outlive the handle). */
+int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz,
+                               const int32_t *d_row_ptr, const int32_t *d_col_ind,
+                               const double *d_values,
+                               const cask_hip_params *params, cask_hip_matrix **out);
+
+int cask_hip_csr_destroy(cask_hip_matrix *m);
+
+/* Change the design point (re-plans; the matrix is not re-uploaded). */
+int cask_hip_csr_set_params(cask_hip_matrix *m, const cask_hip_params *params);
+/* The resolved design point (AUTO and defaults filled in). */
+int cask_hip_csr_get_params(const cask_hip_matrix *m, cask_hip_params *out);
+int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out);
+
+/* y = A x with host vectors: copies x up, runs, copies y down, synchronously.
+ * Replaces Spmv::spmv (src/runtime/Spmv.cpp:185-328): the x half of
+ * dramWrite, the run function Spmv_<id>(...) and dramRead
+ * (GeneratedImplSupport.hpp:31-49). x has n_cols entries, y n_rows. */
+int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y);
+
+/* y = A x with device vectors on `stream` (a hipStream_t; NULL = default
+ * stream), asynchronously.  This is the device run function alone, the
+ * counterpart of the timed region in Spmv.cpp:270-285. */
+int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream);
+
+/* y = A^T x (device vectors; x has n_rows entries, y n_cols).  Built on first
+ * use as a second CSR (explicit transpose, no atomics).  No reference
+ * counterpart (DfeBiCgSolver is declared only, SparseLinearSolvers.hpp:56-61). */
+int cask_hip_spmv_transpose_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream);
+
+/* Time `iters` back-to-back launches (after `warmup`) with HIP events on the
+ * handle's own stream; median microseconds per launch. */
+int cask_hip_spmv_time(cask_hip_matrix *m, const double *d_x, double *d_y,
+                       int32_t warmup, int32_t iters, double *usec_median, double *usec_min);
+
+/* Measured design-space exploration: evaluates every point of the cross
+ * product variants x lanes x tiles x wg_sizes x items in the reference's
+ * sweep order (first list fastest; src/runtime/Utils.hpp:158-202), leaves the
+ * fastest valid point active on the handle and returns all measurements.
+ * Replaces dse_run/better (src/runtime/Dse.cpp:12-74), measured not modelled. */
+int cask_hip_tune(cask_hip_matrix *m,
+                  const int32_t *variants, int32_t n_variants,
+                  const int32_t *lanes, int32_t n_lanes,
+                  const int32_t *tiles, int32_t n_tiles,
+                  const int32_t *wg_sizes, int32_t n_wg_sizes,
+                  const int32_t *items, int32_t n_items,
+                  int32_t warmup, int32_t iters,
+                  cask_hip_tune_point *results, int32_t max_results, int32_t *n_results,
+                  int32_t *best_index);
+
+/* BLAS-1 on device vectors, the CG building blocks the reference takes from
+ * MKL (cblas_ddot / cblas_daxpy / cblas_daxpby,
+ * src/runtime/SparseLinearSolvers.hpp:190-229).  Scalars live in device
+ * memory so a solver iteration never synchronises with the host:
+ *   ddot  : *d_result = sum x_i*y_i   (deterministic two-stage reduction)
+ *   daxpy : y += sign * (*d_num / *d_den) * x        (d_den may be NULL => 1)
+ *   daxpby: y = alpha_h * x + sign * (*d_num / *d_den) * y  (d_num NULL => beta_h)
+ */
+int cask_hip_ddot_device(int64_t n, const double *d_x, const double *d_y, double *d_result, void *stream);
+int cask_hip_daxpy_device(int64_t n, double sign, const double *d_num, const double *d_den,
+                          const double *d_x, double *d_y, void *stream);
+int cask_hip_daxpby_device(int64_t n, double alpha, const double *d_x,
+                           double sign, double beta, const double *d_num, const double *d_den,
+                           double *d_y, void *stream);
+
+/* Un-preconditioned CG on a full symmetric CSR handle, the recurrence of
+ * pcg<double, IdentityPreconditioner> (SparseLinearSolvers.hpp:162-239):
+ * absolute test r.r <= tol^2, `iterations` written at the end of each
+ * non-converged pass.  Host vectors; x holds the initial guess. */
+int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                int32_t *iterations, int32_t *converged, double *usec_per_iteration);
+/* Classical BiCG with A and A^T (BASELINE config 5). */
+int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                  int32_t *iterations, int32_t *converged, double *usec_per_iteration);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASK_HIP_H */

@@ -1,0 +1,110 @@
+"""BLAS-1, CG and BiCG on the GPU (through the C ABI) against the oracle's
+restatement of the reference's pcg (src/runtime/SparseLinearSolvers.hpp:162-239)
+and its known answers (test/LinearSolvers.cpp:14-52)."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import mmio
+from cask_amd import capi, synth
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blas1_against_oracle():
+    import torch
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 63, 64, 1000, 1001, 262_144 + 7, 1_585_478):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        capi.ddot_device(xt, yt, out)
+        got = float(out.cpu()[0])
+        want = oracle.ddot(x, y)
+        assert abs(got - want) <= 1e-12 * max(1.0, np.abs(x * y).sum()), (n, got, want)
+        out2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        capi.ddot_device(xt, yt, out2)
+        assert torch.equal(out, out2)                      # deterministic reduction
+
+        num = torch.tensor([3.0], dtype=torch.float64, device="cuda")
+        den = torch.tensor([-4.0], dtype=torch.float64, device="cuda")
+        y1 = yt.clone()
+        capi.daxpy_device(xt, y1, sign=-1.0, num_t=num, den_t=den)       # y += -1*(3/-4)*x
+        np.testing.assert_allclose(y1.cpu().numpy(), oracle.daxpy(0.75, x, y), rtol=1e-15, atol=1e-15)
+        y2 = yt.clone()
+        capi.daxpby_device(2.0, xt, y2, beta=-0.5)
+        np.testing.assert_allclose(y2.cpu().numpy(), oracle.daxpby(2.0, x, -0.5, y), rtol=1e-15, atol=1e-15)
+        y3 = yt.clone()
+        capi.daxpby_device(1.0, xt, y3, num_t=num, den_t=den)            # y = x + (3/-4) y
+        np.testing.assert_allclose(y3.cpu().numpy(), oracle.daxpby(1.0, x, -0.75, y), rtol=1e-15, atol=1e-15)
+
+
+def test_cg_known_answers(known_answers):
+    for case in known_answers["cg_identity"]["cases"]:
+        full = mmio.read_matrix(GOLDEN / case["matrix"])
+        rhs = mmio.read_vector(GOLDEN / case["rhs"])
+        m = capi.CsrMatrix.from_host(full.n, full.m, full.row_ptr, full.col_ind, full.values)
+        x, iters, conv, _ = m.cg(rhs)
+        m.close()
+        assert conv
+        want, want_it, _ = oracle.cg_full(full.row_ptr, full.col_ind, full.values, rhs)
+        assert iters == want_it
+        oracle.assert_almost_equal(x, np.array(case["expected"], dtype=float), rel=1e-12, abs_=1e-14,
+                                   what=case["matrix"])
+
+
+@pytest.mark.parametrize("name", ["cant", "G3_circuit"])
+def test_cg_matches_oracle_on_spd_families(name):
+    n, rp, ci, va = synth.small(name, factor=16)
+    x0 = mmio.test_vector(n) / n
+    b = oracle.csr_spmv(rp, ci, va, x0)                      # harness of test_utils.hpp:61-70
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    got, it, conv, us = m.cg(b)
+    m.close()
+    assert conv == want_conv
+    assert abs(it - want_it) <= 2, (it, want_it)
+    res = np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, got))
+    assert res <= 2e-5, res                                  # tol 1e-5 absolute on sqrt(r.r)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+    assert us > 0
+
+
+def test_cg_not_converged_reports_last_iteration():
+    n, rp, ci, va = synth.small("G3_circuit", factor=64)
+    b = np.ones(n)
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b, maxiters=5)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    got, it, conv, _ = m.cg(b, maxiters=5)
+    m.close()
+    assert not conv and not want_conv
+    assert it == want_it == 4                                # iterations = i of the last pass (:231)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+
+
+def test_bicg_matches_oracle_nonsymmetric():
+    n, rp, ci, va = synth.small("atmosmodd", factor=16)
+    x0 = mmio.test_vector(n) / n
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    got, it, conv, _ = m.bicg(b)
+    m.close()
+    assert conv and want_conv
+    assert abs(it - want_it) <= 2, (it, want_it)
+    res = np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, got))
+    assert res <= 2e-5
+    np.testing.assert_allclose(got, x0, rtol=1e-5, atol=1e-6)
+
+
+def test_bicg_reference_harness_bfwb62():
+    """test/test_bicg.cpp:11 -> runTest(bfwb62): b = A x0, x0_i = 0.25 i, expect x0 back."""
+    a = mmio.read_matrix(GOLDEN / "matrices/bfwb62.mtx")
+    x0 = mmio.test_vector(a.n)
+    b = oracle.csr_spmv(a.row_ptr, a.col_ind, a.values, x0)
+    m = capi.CsrMatrix.from_host(a.n, a.m, a.row_ptr, a.col_ind, a.values)
+    got, it, conv, _ = m.bicg(b, tol=1e-14, maxiters=500)
+    m.close()
+    assert conv
+    np.testing.assert_allclose(got, x0, rtol=1e-6, atol=1e-8)

@@ -1,0 +1,217 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle and the committed golden vectors.  Tolerance is the reference's own
+(test/test_utils.hpp:36): relative 1e-8 / absolute 1e-11 -- summation order on
+the GPU (butterfly) differs from the sequential order of the oracle, so the
+comparison is never bitwise; run-to-run results of one design point ARE bitwise
+identical (no float atomics) and that is tested too."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import mmio
+from cask_amd import capi, synth
+from conftest import golden_matrix_files
+
+pytestmark = pytest.mark.gpu
+
+# design points that exercise every kernel family / template branch
+DESIGN_POINTS = [
+    dict(variant="vector", lanes_per_row=1, tile_width=-1),
+    dict(variant="vector", lanes_per_row=4, tile_width=-1, wg_size=64),
+    dict(variant="vector", lanes_per_row=16, tile_width=4096),
+    dict(variant="vector", lanes_per_row=64, tile_width=-1, nontemporal=-1),
+    dict(variant="vector", lanes_per_row=32, tile_width=512, xcd_remap=-1, wg_size=512),
+    dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=-1),
+    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096),
+    dict(variant="merge", items_per_thread=4, wg_size=128, tile_width=64, xcd_remap=-1),
+    dict(variant="merge", items_per_thread=16, wg_size=256, tile_width=-1, nontemporal=-1),
+    dict(),   # AUTO / all defaults
+]
+DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
+
+
+def run_host(n_rows, n_cols, rp, ci, va, x, dp):
+    m = capi.CsrMatrix.from_host(n_rows, n_cols, rp, ci, va, capi.make_params(**dp))
+    try:
+        return m.spmv(x)
+    finally:
+        m.close()
+
+
+@pytest.fixture(scope="module")
+def fixtures_loaded():
+    out = {}
+    for key, path in golden_matrix_files():
+        out[key] = mmio.read_matrix(path)
+    return out
+
+
+@pytest.mark.parametrize("dp", DESIGN_POINTS, ids=DP_IDS)
+def test_reference_fixtures_every_design_point(dp, fixtures_loaded, expected_y):
+    """test/test_spmv.cpp protocol over all 43 fixture matrices (incl. the two 'failing' ones)."""
+    for key, m in fixtures_loaded.items():
+        x = mmio.test_vector(m.m)
+        got = run_host(m.n, m.m, m.row_ptr, m.col_ind, m.values, x, dp)
+        oracle.assert_almost_equal(got, expected_y[key], what=f"{key} {dp}")
+
+
+@pytest.mark.parametrize("name", list(synth.GENERATORS))
+@pytest.mark.parametrize("dp", DESIGN_POINTS, ids=DP_IDS)
+def test_baseline_families_small(name, dp):
+    n, rp, ci, va = synth.small(name)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    got = run_host(n, n, rp, ci, va, x, dp)
+    oracle.assert_almost_equal(got, want, what=f"{name} {dp}")
+
+
+@pytest.mark.parametrize("name", list(synth.GENERATORS))
+def test_baseline_configs_full_size(name):
+    """BASELINE.json configs at full size: oracle comparison (the C oracle needs ~20 ms) plus
+    size-independent properties: linearity and the column-sum checksum 1'(Ax) = (A'1)'x."""
+    n, rp, ci, va = synth.GENERATORS[name]()
+    rng = np.random.default_rng(12)
+    x1, x2 = rng.uniform(-1, 1, n), mmio.test_vector(n) / n
+    want1 = oracle.csr_spmv(rp, ci, va, x1)
+    colsum = oracle.csr_spmv_t(n, rp, ci, va, np.ones(n))
+    for dp in (dict(variant="merge"), dict(variant="vector"), dict(variant="merge", tile_width=-1),
+               dict(variant="vector", lanes_per_row=8, tile_width=-1)):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
+        y1, y2 = m.spmv(x1), m.spmv(x2)
+        y12 = m.spmv(2.0 * x1 - 0.5 * x2)
+        again = m.spmv(x1)
+        m.close()
+        oracle.assert_almost_equal(y1, want1, what=f"{name} {dp}")
+        assert np.array_equal(y1, again), "SpMV must be bitwise reproducible run to run"
+        np.testing.assert_allclose(y12, 2.0 * y1 - 0.5 * y2, rtol=1e-9, atol=1e-9 * np.abs(y1).max())
+        np.testing.assert_allclose(y1.sum(), colsum @ x1, rtol=1e-9, atol=1e-8 * np.abs(y1).sum())
+
+
+def test_edge_shapes():
+    # no rows at all
+    m = capi.CsrMatrix.from_host(0, 0, [0], [], [])
+    assert m.spmv(np.zeros(0)).size == 0
+    m.close()
+    # rows but no nonzeros (test_large_empty-like)
+    for dp in (dict(variant="merge"), dict(variant="vector", lanes_per_row=2)):
+        y = run_host(1000, 7, np.zeros(1001, dtype=np.int32), [], [], np.ones(7), dp)
+        assert y.shape == (1000,) and not y.any()
+    # rectangular, wider than tall and taller than wide
+    rng = np.random.default_rng(2)
+    import scipy.sparse as sp
+    for shape in ((50, 3000), (3000, 50)):
+        a = sp.random(*shape, 0.05, format="csr", random_state=rng)
+        a.sort_indices()
+        x = rng.standard_normal(shape[1])
+        want = oracle.csr_spmv(a.indptr, a.indices, a.data, x)
+        for dp in DESIGN_POINTS:
+            got = run_host(shape[0], shape[1], a.indptr, a.indices, a.data, x, dp)
+            oracle.assert_almost_equal(got, want, what=f"rect {shape} {dp}")
+
+
+def test_long_rows_split_across_workgroups():
+    """One row far longer than a workgroup's share (webbase-like tail): long-row pieces + fix-up."""
+    rng = np.random.default_rng(4)
+    n = 3000
+    lens = np.full(n, 3)
+    lens[17] = 2900          # > 16*CAP for CAP=128 -> split into pieces
+    lens[18] = 0
+    lens[1500] = 700         # long but a single piece
+    lens[n - 1] = 1500
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int32)
+    va = rng.standard_normal(ci.size)
+    x = rng.standard_normal(n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    for dp in (dict(variant="merge", wg_size=64, items_per_thread=2),
+               dict(variant="merge", wg_size=64, items_per_thread=2, tile_width=256),
+               dict(variant="merge", wg_size=256, items_per_thread=8),
+               dict(variant="vector", lanes_per_row=64), dict(variant="vector", lanes_per_row=1)):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
+        info = m.info
+        got = m.spmv(x)
+        m.close()
+        oracle.assert_almost_equal(got, want, what=f"long rows {dp}")
+        if dp["variant"] == "merge" and dp["wg_size"] == 64:
+            assert info.n_long_rows == 3 and info.n_split_rows >= 1
+
+
+def test_device_vector_entry_point_and_streams():
+    import torch
+    n, rp, ci, va = synth.small("cant", factor=8)
+    x = mmio.test_vector(n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    m.spmv_device(xt, yt)                              # torch's current stream
+    torch.cuda.synchronize()
+    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="device entry")
+    side = torch.cuda.Stream()
+    yt2 = torch.zeros_like(yt)
+    with torch.cuda.stream(side):
+        m.spmv_device(xt, yt2, stream=side)
+    side.synchronize()
+    assert torch.equal(yt, yt2)
+    m.close()
+
+
+def test_borrowed_device_arrays():
+    import torch
+    n, rp, ci, va = synth.small("atmosmodd", factor=8)
+    x = mmio.test_vector(n) / n
+    want = oracle.csr_spmv(rp, ci, va, x)
+    rpt, cit, vat = (torch.from_numpy(a).cuda() for a in (rp, ci, va))
+    m = capi.CsrMatrix.from_device(n, n, rpt, cit, vat, capi.make_params(variant="merge"))
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.empty(n, dtype=torch.float64, device="cuda")
+    m.spmv_device(xt, yt)
+    torch.cuda.synchronize()
+    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="borrowed arrays")
+    m.close()
+
+
+def test_transpose_product():
+    import torch
+    n, rp, ci, va = synth.small("webbase-1M", factor=8)
+    x = np.random.default_rng(9).uniform(-1, 1, n)
+    want = oracle.csr_spmv_t(n, rp, ci, va, x)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.empty(n, dtype=torch.float64, device="cuda")
+    m.spmv_transpose_device(xt, yt)
+    torch.cuda.synchronize()
+    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="A^T x")
+    m.close()
+
+
+def test_size_mismatch_raises_like_the_reference():
+    """Spmv::spmv throws std::invalid_argument on shape violations (Spmv.cpp:189-207)."""
+    m = capi.CsrMatrix.from_host(3, 3, [0, 1, 2, 3], [0, 1, 2], [1.0, 1.0, 1.0])
+    with pytest.raises(ValueError):
+        m.spmv(np.ones(4))
+    with pytest.raises(ValueError):
+        m.set_params(capi.make_params(variant="vector", lanes_per_row=3))
+    with pytest.raises(ValueError):
+        m.set_params(capi.make_params(variant="merge", wg_size=1024, items_per_thread=16))
+    assert np.array_equal(m.spmv(np.array([1.0, 2.0, 3.0])), [1.0, 2.0, 3.0])   # handle still usable
+    m.close()
+
+
+def test_tune_sweeps_in_reference_order_and_keeps_the_best():
+    n, rp, ci, va = synth.small("cant", factor=8)
+    x = mmio.test_vector(n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[4, 16, 64], tiles=[-1, 2048],
+                       wg_sizes=[256], items=[4, 8], warmup=1, iters=5)
+    # first list (variants) fastest; lanes only swept for VECTOR, items only for MERGE
+    assert len(pts) == 3 * 2 + 2 * 2
+    assert pts[0]["params"]["variant"] == "vector" and pts[0]["params"]["lanes_per_row"] == 4
+    assert pts[1]["params"]["variant"] == "merge"
+    assert all(p["valid"] and p["usec"] > 0 for p in pts)
+    assert pts[best]["usec"] == min(p["usec"] for p in pts)
+    assert m.params.as_dict() == pts[best]["params"]
+    oracle.assert_almost_equal(m.spmv(x), want, what="after tune")
+    m.close()
