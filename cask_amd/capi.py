@@ -14,8 +14,9 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
 
-VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE = 0, 1, 2
-VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge"}
+VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE = 0, 1, 2, 3
+VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge",
+                 VARIANT_MERGE_WAVE: "merge_wave"}
 
 # Every symbol include/cask_hip.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = (

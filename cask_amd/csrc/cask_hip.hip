@@ -73,8 +73,11 @@ struct Plan {
   int grid = 0;
   int lds_bytes = 0;
   bool ldsx = false;
+  int xu = 0;                      // MERGE: 8-byte window loads per lane (window capacity = xu*wg_size)
   // MERGE
   DevBuf<BlockDesc> blocks;
+  DevBuf<BlockDesc> long_blocks;   // pipelined plan: long-row pieces get their own launch
+  int n_blocks = 0, n_long_blocks = 0;
   DevBuf<SplitRow> split_rows;
   DevBuf<double> partials;
   int n_long_rows = 0, n_split_rows = 0;
@@ -119,8 +122,10 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     const bool skewed = m.max_row > 8 * std::max(mean, 1.0) + 64;
     out.variant = (mean >= 12.0 && !skewed) ? CASK_HIP_VARIANT_VECTOR : CASK_HIP_VARIANT_MERGE;
   }
-  if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE)
+  if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE &&
+      out.variant != CASK_HIP_VARIANT_MERGE_WAVE)
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
+  if (m.nnz < 2) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
   if (out.lanes_per_row == 0) {
     int l = pow2_floor(std::max(1, (int)std::lround(mean / 4.0)));
     out.lanes_per_row = std::min(64, std::max(out.variant == CASK_HIP_VARIANT_VECTOR ? 2 : 1, l));
@@ -137,20 +142,21 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.variant == CASK_HIP_VARIANT_MERGE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
-    if (12 * cap + 24 > MAX_LDS_BYTES)
+    if (8 * (cap + 2) + 8 * out.wg_size > MAX_LDS_BYTES)
       return fail(CASK_HIP_ERR_INVALID, "wg_size*items_per_thread needs more than 64 KiB of LDS");
   }
   return CASK_HIP_OK;
 }
 
-// Cut the merge path of (row ends) against (nonzero indices) into workgroup
-// shares of at most CAP items, snapped to row boundaries; rows longer than
-// CAP/2 become long-row pieces of at most 16*CAP nonzeros.
-void build_merge_blocks(const cask_hip_matrix &m, int cap, std::vector<BlockDesc> &blocks,
+// Cut the merge path of (row ends) against (nonzero indices) into shares of at
+// most `cap` items (and at most `max_rows` rows), snapped to row boundaries;
+// rows longer than cap/2 become long-row pieces of at most `piece` nonzeros.
+// Long pieces go to `longs` when it is given (pipelined plan), else inline.
+void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long piece,
+                        std::vector<BlockDesc> &blocks, std::vector<BlockDesc> *longs,
                         std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots) {
   const int *rp = m.h_rp.data();
   const int long_t = cap / 2;
-  const long piece = (long)cap * LONG_PIECE_FACTOR;
   n_long = 0;
   n_partial_slots = 0;
   int cur_start = 0, cur_rows = 0, cur_nnz = 0;
@@ -183,17 +189,31 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, std::vector<BlockDesc
         d.nnz_count = (int)std::min<long>(piece, len - pc * piece);
         d.kind_g = KIND_LONG | (n_pieces > 1 ? KIND_PARTIAL : 0);
         d.aux = n_pieces > 1 ? n_partial_slots++ : 0;
-        blocks.push_back(d);
+        (longs ? *longs : blocks).push_back(d);
       }
       cur_start = r + 1;
       continue;
     }
-    if (cur_rows > 0 && cur_rows + 1 + cur_nnz + len > cap) close(r);
+    if (cur_rows > 0 && (cur_rows + 1 + cur_nnz + len > cap || cur_rows + 1 > max_rows)) close(r);
     if (cur_rows == 0) cur_start = r;
     cur_rows++;
     cur_nnz += len;
   }
   close(m.n_rows);
+}
+
+template <int IPT>
+const void *merge_wave_fn(bool nt) {
+  return nt ? reinterpret_cast<const void *>(&k_spmv_merge_wave<IPT, true>)
+            : reinterpret_cast<const void *>(&k_spmv_merge_wave<IPT, false>);
+}
+const void *merge_wave_fn(int ipt, bool nt) {
+  switch (ipt) {
+    case 2: return merge_wave_fn<2>(nt);
+    case 4: return merge_wave_fn<4>(nt);
+    case 8: return merge_wave_fn<8>(nt);
+    default: return merge_wave_fn<16>(nt);
+  }
 }
 
 int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
@@ -203,6 +223,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   Plan &pl = m.plan;
   pl.prm = prm;
   pl.blocks.release();
+  pl.long_blocks.release();
+  pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
   pl.xspan.release();
@@ -210,39 +232,80 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.grid = 0;
   pl.lds_bytes = 0;
   pl.ldsx = false;
+  pl.xu = 0;
   if (m.n_rows == 0) return CASK_HIP_OK;
 
   const int tile = prm.tile_width > 0 ? prm.tile_width : 0;
-  if (prm.variant == CASK_HIP_VARIANT_MERGE) {
+  if (prm.variant == CASK_HIP_VARIANT_MERGE_WAVE) {
+    // persistent pipelined waves: small per-wave blocks, long rows in their own launch
+    const int cap = 64 * prm.items_per_thread;
+    std::vector<BlockDesc> blocks, longs;
+    std::vector<SplitRow> splits;
+    int n_long = 0, n_slots = 0;
+    build_merge_blocks(m, cap, 127, 32768, blocks, &longs, splits, n_long, n_slots);
+    pl.n_long_rows = n_long;
+    pl.n_split_rows = (int)splits.size();
+    pl.n_blocks = (int)blocks.size();
+    pl.n_long_blocks = (int)longs.size();
+    HIP_TRY(pl.blocks.upload(blocks));
+    if (!longs.empty()) HIP_TRY(pl.long_blocks.upload(longs));
+    if (!splits.empty()) {
+      HIP_TRY(pl.split_rows.upload(splits));
+      HIP_TRY(pl.partials.alloc(n_slots));
+    }
+    const int waves_per_wg = prm.wg_size / 64;
+    pl.lds_bytes = waves_per_wg * ((cap + 2) * 8 + 128 * 4);
+    pl.prm.tile_width = -1;                                  // x comes from L2 in this kernel
+    int occ = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, merge_wave_fn(prm.items_per_thread, prm.nontemporal > 0),
+                                                         prm.wg_size, pl.lds_bytes));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m.device));
+    if (occ < 1) return fail(CASK_HIP_ERR_INVALID, "design point does not fit on a CU (LDS/registers)");
+    const int want = (pl.n_blocks + waves_per_wg - 1) / waves_per_wg;
+    pl.grid = std::max(1, std::min(want, occ * cus));
+    if (pl.n_blocks == 0) pl.grid = 0;
+    pl.ldsx = false;
+  } else if (prm.variant == CASK_HIP_VARIANT_MERGE) {
     const int cap = prm.wg_size * prm.items_per_thread;
     std::vector<BlockDesc> blocks;
     std::vector<SplitRow> splits;
     int n_long = 0, n_slots = 0;
-    build_merge_blocks(m, cap, blocks, splits, n_long, n_slots);
+    build_merge_blocks(m, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, blocks, nullptr, splits, n_long,
+                       n_slots);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
     pl.grid = (int)blocks.size();
+    pl.n_blocks = pl.grid;
     HIP_TRY(pl.blocks.upload(blocks));
     if (!splits.empty()) {
       HIP_TRY(pl.split_rows.upload(splits));
       HIP_TRY(pl.partials.alloc(n_slots));
     }
-    const int base_lds = 12 * cap + 24;
-    int max_width = 0;
+    const int base_lds = 8 * (cap + 2) + 8 * prm.wg_size;
+    pl.xu = 0;
+    pl.prm.tile_width = -1;
     if (tile > 0 && m.nnz > 0) {
       hipLaunchKernelGGL(k_col_span_blocks, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid, m.d_ci);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(blocks.data(), pl.blocks.p, blocks.size() * sizeof(BlockDesc),
                              hipMemcpyDeviceToHost, m.stream));
       HIP_TRY(hipStreamSynchronize(m.stream));
-      const int budget = (MAX_LDS_BYTES - base_lds) / 8;
-      const int eff_tile = std::min(tile, budget);
-      pl.prm.tile_width = eff_tile;
+      // window capacity is xu*wg_size doubles, xu in {1,2,4,8}: the smallest that holds the widest
+      // block window not exceeding the requested tile (wider blocks gather from L2)
+      int max_width = 0;
       for (const BlockDesc &d : blocks)
-        if (!(d.kind_g & KIND_LONG) && d.cwidth <= eff_tile) max_width = std::max(max_width, d.cwidth);
+        if (!(d.kind_g & KIND_LONG) && d.cwidth <= tile) max_width = std::max(max_width, d.cwidth);
+      int xu = 0;
+      if (max_width > 0) {
+        xu = 1;
+        while (xu < 8 && xu * prm.wg_size < max_width) xu *= 2;
+        while (xu > 0 && base_lds + 8 * xu * prm.wg_size > MAX_LDS_BYTES) xu /= 2;
+      }
+      pl.xu = xu;
+      if (xu > 0) pl.prm.tile_width = xu * prm.wg_size;
     }
-    pl.ldsx = max_width > 0;
-    pl.lds_bytes = base_lds + 8 * max_width;
+    pl.ldsx = pl.xu > 0;
+    pl.lds_bytes = base_lds + 8 * pl.xu * prm.wg_size;
   } else {
     const int rows_per_wg = prm.wg_size / prm.lanes_per_row;
     pl.grid = (m.n_rows + rows_per_wg - 1) / rows_per_wg;
@@ -286,18 +349,56 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   return CASK_HIP_OK;
 }
 
+template <int IPT, int XU>
+void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+  const Plan &pl = m.plan;
+  const dim3 grid(pl.grid), block(pl.prm.wg_size);
+  const int remap = pl.prm.xcd_remap > 0;
+  if (pl.prm.nontemporal > 0)
+    hipLaunchKernelGGL((k_spmv_merge<IPT, XU, true>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, remap,
+                       m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p);
+  else
+    hipLaunchKernelGGL((k_spmv_merge<IPT, XU, false>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, remap,
+                       m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p);
+}
+
 template <int IPT>
 int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
   const Plan &pl = m.plan;
-  const dim3 grid(pl.grid), block(pl.prm.wg_size);
-  const int remap = pl.prm.xcd_remap > 0, tile = std::max(0, pl.prm.tile_width);
+  switch (pl.xu) {
+    case 0:  launch_merge_ix<IPT, 0>(m, x, y, s); break;
+    case 1:  launch_merge_ix<IPT, 1>(m, x, y, s); break;
+    case 2:  launch_merge_ix<IPT, 2>(m, x, y, s); break;
+    case 4:  launch_merge_ix<IPT, 4>(m, x, y, s); break;
+    default: launch_merge_ix<IPT, 8>(m, x, y, s); break;
+  }
+  if (pl.n_split_rows > 0)
+    hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
+                       pl.n_split_rows, pl.partials.p, y);
+  return CASK_HIP_OK;
+}
+
+template <int IPT>
+int launch_merge_wave_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+  const Plan &pl = m.plan;
+  const int remap = pl.prm.xcd_remap > 0 && pl.grid >= 8;   // every XCD needs at least one workgroup
   const bool nt = pl.prm.nontemporal > 0;
-#define CASK_LAUNCH_M(LDSX, NT)                                                                          \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, LDSX, NT>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid,  \
-                     remap, tile, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p)
-  if (pl.ldsx) { if (nt) CASK_LAUNCH_M(true, true); else CASK_LAUNCH_M(true, false); }
-  else         { if (nt) CASK_LAUNCH_M(false, true); else CASK_LAUNCH_M(false, false); }
-#undef CASK_LAUNCH_M
+  if (pl.grid > 0) {
+    if (nt)
+      hipLaunchKernelGGL((k_spmv_merge_wave<IPT, true>), dim3(pl.grid), dim3(pl.prm.wg_size), pl.lds_bytes, s,
+                         pl.blocks.p, pl.n_blocks, remap, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y);
+    else
+      hipLaunchKernelGGL((k_spmv_merge_wave<IPT, false>), dim3(pl.grid), dim3(pl.prm.wg_size), pl.lds_bytes, s,
+                         pl.blocks.p, pl.n_blocks, remap, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y);
+  }
+  if (pl.n_long_blocks > 0) {
+    if (nt)
+      hipLaunchKernelGGL((k_spmv_long<true>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p,
+                         pl.n_long_blocks, m.d_ci, m.d_val, x, y, pl.partials.p);
+    else
+      hipLaunchKernelGGL((k_spmv_long<false>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p,
+                         pl.n_long_blocks, m.d_ci, m.d_val, x, y, pl.partials.p);
+  }
   if (pl.n_split_rows > 0)
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
                        pl.n_split_rows, pl.partials.p, y);
@@ -306,7 +407,17 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
 
 int launch_spmv(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
   const Plan &pl = m.plan;
-  if (m.n_rows == 0 || pl.grid == 0) return CASK_HIP_OK;
+  if (m.n_rows == 0 || (pl.grid == 0 && pl.n_long_blocks == 0)) return CASK_HIP_OK;
+  if (pl.prm.variant == CASK_HIP_VARIANT_MERGE_WAVE) {
+    switch (pl.prm.items_per_thread) {
+      case 2:  launch_merge_wave_i<2>(m, x, y, s); break;
+      case 4:  launch_merge_wave_i<4>(m, x, y, s); break;
+      case 8:  launch_merge_wave_i<8>(m, x, y, s); break;
+      default: launch_merge_wave_i<16>(m, x, y, s); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return CASK_HIP_OK;
+  }
   if (pl.prm.variant == CASK_HIP_VARIANT_VECTOR) {
     switch (pl.prm.lanes_per_row) {
       case 1:  launch_vector_l<1>(m, x, y, s); break;
@@ -443,6 +554,8 @@ int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz, cons
   *out = nullptr;
   if (!d_row_ptr || (nnz > 0 && (!d_col_ind || !d_values))) return fail(CASK_HIP_ERR_INVALID, "NULL array");
   if (n_rows < 0 || n_cols < 0 || nnz < 0) return fail(CASK_HIP_ERR_INVALID, "negative dimension");
+  if ((reinterpret_cast<uintptr_t>(d_values) & 15) || (reinterpret_cast<uintptr_t>(d_col_ind) & 7))
+    return fail(CASK_HIP_ERR_INVALID, "device arrays must be 16-byte (values) / 8-byte (col_ind) aligned");
   int rc = ensure_device();
   if (rc) return rc;
   std::unique_ptr<cask_hip_matrix> m(new cask_hip_matrix);
@@ -631,13 +744,15 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
         for (int il = 0; il < n_lanes; il++)
           for (int iva = 0; iva < n_variants; iva++) {
             const int variant = variants[iva];
+            const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
-            if (variant == CASK_HIP_VARIANT_MERGE && il != 0) continue;
+            if (is_merge && il != 0) continue;
+            if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel
             cask_hip_tune_point pt{};
             pt.params = saved;
             pt.params.variant = variant;
             pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
-            pt.params.items_per_thread = variant == CASK_HIP_VARIANT_MERGE ? items[iv] : 0;
+            pt.params.items_per_thread = is_merge ? items[iv] : 0;
             pt.params.tile_width = tiles[it];
             pt.params.wg_size = wg_sizes[iw];
             int rc = build_plan(*m, pt.params);

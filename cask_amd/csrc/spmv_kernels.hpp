@@ -190,31 +190,75 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
   }
 }
 
-// Phase 1 of the merge kernel: products of the block's nonzeros, in nonzero
-// order, into LDS.  All IPT/2 16-byte value loads and 8-byte index loads of a
-// lane are issued before the first gather; XLDS is a template parameter for
-// the same reason as in row_dot.
-template <int IPT, bool XLDS, bool NT>
-__device__ __forceinline__ void merge_stream(const BlockDesc &d, int base, int lead, int total_even,
-                                             const int *__restrict__ ci, const double *__restrict__ val,
-                                             const double *__restrict__ x, const double *xs, double *prod) {
+// One block of the merge kernel, straight-line so that hipcc can count the
+// outstanding loads exactly.  Issue order is the point (membench2, stage 3 vs
+// 4: 11.0 -> 9.2 us on the cant payload):
+//   1. the block's x window (XU 8-byte loads per lane)      -- oldest
+//   2. its row offsets (2 loads per lane)
+//   3. the value/index stream (IPT/2 16-byte + 8-byte loads) -- youngest
+// vmcnt retires in order, so parking the window and the offsets in LDS waits
+// only for (1) and (2) while the stream is still in flight; when the stream
+// lands the gathers are LDS reads (~100 ns, no TA traffic) instead of a second
+// dependent trip to L2.  XU = 0 gathers from L2 (window wider than the tile).
+template <int IPT, int XU, bool NT>
+__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int max_gpair,
+                                            const int *__restrict__ rp, const int *__restrict__ ci,
+                                            const double *__restrict__ val, const double *__restrict__ x,
+                                            double *__restrict__ y, double *prod, int *roff, double *xs) {
   const int WG = blockDim.x, tid = threadIdx.x;
+  // 16-byte loads need an even element index: start one element early if the
+  // block starts on an odd nonzero (that element belongs to the previous block;
+  // its product lands in prod[0] and no row of this block references it).
+  const int base = d.nnz_start & ~1;
+  const int lead = d.nnz_start - base;
+  const int total = d.nnz_count + lead;
+  // An odd total ends in a pair whose second element is foreign (the next
+  // block's first nonzero, or -- for the very last nonzero of an odd-nnz matrix
+  // -- the 8 bytes after the array: a 16-byte-aligned 16-byte load that holds
+  // one valid element cannot cross a page, so it is memory-safe).
+  const int npairs = (total + 1) >> 1;
+
+  double xw[XU > 0 ? XU : 1];
+  if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, n_cols - 1)];
+  }
+  const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
+  const int ro1 = rp[d.row_start + min(tid + WG, d.n_rows)] - base;
+
   dbl2 v[IPT / 2];
   int2v c[IPT / 2];
-  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val + base);
-  const int2v *ci2 = reinterpret_cast<const int2v *>(ci + base);
-  const int last_pair = (total_even >> 1) - 1;
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  const int first = base >> 1;
+  const int last = min(first + max(npairs - 1, 0), max_gpair);
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
-    const int p = min(u * WG + tid, last_pair);              // clamped: redundant loads hit the same line
+    const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
     v[u] = stream_load<NT>(val2 + p);
     c[u] = stream_load<NT>(ci2 + p);
   }
-  if (lead && tid == 0) c[0].x = d.cmin;                     // foreign element: keep its gather inside the window
+
+  if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
+  }
+  roff[tid] = ro0;
+  roff[tid + WG] = ro1;
+  if (XU > 0) __syncthreads();
+
+  // foreign elements: give them a column this block owns, so their gather stays
+  // inside the x window / inside x (their products land in slots no row uses)
+  if (lead && tid == 0) c[0].x = c[0].y;
+  if (total & 1) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++)
+      if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+  }
   dbl2 xv[IPT / 2];
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
-    if (XLDS) {
+    if (XU > 0) {
       xv[u].x = xs[c[u].x - d.cmin];
       xv[u].y = xs[c[u].y - d.cmin];
     } else {
@@ -222,16 +266,26 @@ __device__ __forceinline__ void merge_stream(const BlockDesc &d, int base, int l
       xv[u].y = x[c[u].y];
     }
   }
+  // every lane stores: lanes past the last pair hold a duplicate of it and land
+  // in slots no row offset points to
   dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
 #pragma unroll
-  for (int u = 0; u < IPT / 2; u++) {
-    const int p = u * WG + tid;
-    if (p <= last_pair) prod2[p] = v[u] * xv[u];
+  for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
+  __syncthreads();
+
+  switch (d.kind_g & 0xff) {
+    case 1:  reduce_rows<1>(d, prod, roff, y); break;
+    case 2:  reduce_rows<2>(d, prod, roff, y); break;
+    case 4:  reduce_rows<4>(d, prod, roff, y); break;
+    case 8:  reduce_rows<8>(d, prod, roff, y); break;
+    case 16: reduce_rows<16>(d, prod, roff, y); break;
+    case 32: reduce_rows<32>(d, prod, roff, y); break;
+    default: reduce_rows<64>(d, prod, roff, y); break;
   }
 }
 
-template <int IPT, bool LDSX, bool NT>
-__global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int tile_width,
+template <int IPT, int XU, bool NT>
+__global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials) {
@@ -239,8 +293,8 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
-  int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // CAP + 2 ints
-  double *xs = reinterpret_cast<double *>(roff + CAP + 2);    // tile_width doubles (LDSX)
+  int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
+  double *xs = reinterpret_cast<double *>(roff + 2 * WG);     // XU*WG doubles
 
   const BlockDesc d = blocks[logical_block(blockIdx.x, n_blocks, remap)];
 
@@ -274,45 +328,214 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
     return;
   }
 
-  // 16-byte loads need an even element index: start one element early if the
-  // block starts on an odd nonzero (that element belongs to the previous block;
-  // its product lands in prod[0] and no row of this block references it).
-  const int base = d.nnz_start & ~1;
-  const int lead = d.nnz_start - base;
-  const int total = d.nnz_count + lead;
-  const int total_even = total & ~1;
+  const int max_gpair = ((nnz + 1) >> 1) - 1;
+  if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
+    merge_block<IPT, XU, NT>(d, n_cols, max_gpair, rp, ci, val, x, y, prod, roff, xs);
+  else
+    merge_block<IPT, 0, NT>(d, n_cols, max_gpair, rp, ci, val, x, y, prod, roff, xs);
+}
 
-  for (int i = tid; i <= d.n_rows; i += WG) roff[i] = rp[d.row_start + i] - base;
+// --------------------------------------------- merge variant, pipelined waves
+// Same merge-path decomposition, but the unit of work is a WAVE and the waves
+// are persistent: each wave walks a strided list of small blocks (at most
+// 64*IPT items, at most 127 rows) and software-pipelines them -- while block b
+// is gathered, multiplied and row-reduced, the 16-byte value/index stream and
+// the row offsets of block b+1 are already in flight, and the descriptor of
+// b+2 is being fetched.  A one-shot workgroup pays the whole dependent chain
+// descriptor -> row_ptr -> stream -> gather -> reduce (~6 us on MI355X) once
+// per ~2 rounds; here it is paid once per wave and hidden afterwards.  No
+// workgroup barrier: a wave only talks to itself through its own LDS slice
+// (DS operations of one wave execute in order).
+struct WaveStream {            // one block's worth of loads held in registers
+  int ro0, ro1;                // row offsets for rows lane, lane+64 (relative to base)
+};
 
-  bool in_lds = false;
-  if (LDSX) {
-    in_lds = d.cwidth > 0 && d.cwidth <= tile_width;        // workgroup-uniform
-    if (in_lds) {
-      for (int i = tid; i < d.cwidth; i += WG) xs[i] = x[d.cmin + i];
-      __syncthreads();
+template <int G>
+__device__ __forceinline__ void wave_reduce_rows(int n_rows, int row_start, const double *prod,
+                                                 const int *roff, double *__restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  constexpr int rows_per_pass = 64 / G;
+  const int j = lane & (G - 1);
+  for (int r0 = 0; r0 < n_rows; r0 += rows_per_pass) {
+    const int r = r0 + lane / G;
+    double acc = 0.0;
+    if (r < n_rows) {
+      const int s = roff[r], e = roff[r + 1];
+#pragma unroll 4
+      for (int k = s + j; k < e; k += G) acc += prod[k];
     }
+    acc = group_sum<G>(acc);
+    if (j == 0 && r < n_rows) y[row_start + r] = acc;
   }
+}
 
-  if (total_even > 0) {
-    if (LDSX && in_lds) merge_stream<IPT, true, NT>(d, base, lead, total_even, ci, val, x, xs, prod);
-    else                merge_stream<IPT, false, NT>(d, base, lead, total_even, ci, val, x, xs, prod);
+template <int IPT, bool NT>
+__device__ __forceinline__ void wave_issue(const BlockDesc &d, int max_gpair, const int *__restrict__ rp,
+                                           const int *__restrict__ ci, const double *__restrict__ val,
+                                           dbl2 (&v)[IPT / 2], int2v (&c)[IPT / 2], int &ro0, int &ro1) {
+  const int lane = threadIdx.x & 63;
+  const int base = d.nnz_start & ~1;
+  const int npairs = (d.nnz_count + d.nnz_start - base + 1) >> 1;   // an odd total ends in a half-foreign pair
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  // Lanes past the block's last pair re-read that pair (same cache line); the
+  // clamp to max_gpair keeps an empty block at the very end of the arrays
+  // inside the allocation.
+  const int first = base >> 1;
+  const int last = min(first + max(npairs - 1, 0), max_gpair);
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int p = min(first + u * 64 + lane, last);
+    v[u] = stream_load<NT>(val2 + p);
+    c[u] = stream_load<NT>(ci2 + p);
   }
-  if ((total & 1) && tid == 0) {                              // odd tail element
-    const int k = total - 1;
-    const int cc = ci[base + k];
-    const double xx = (LDSX && in_lds) ? xs[cc - d.cmin] : x[cc];
-    prod[k] = val[base + k] * xx;
-  }
-  __syncthreads();
+  ro0 = rp[d.row_start + min(lane, d.n_rows)] - base;
+  ro1 = rp[d.row_start + min(lane + 64, d.n_rows)] - base;
+}
 
+template <int IPT, bool NT, bool HAS_NEXT>
+__device__ __forceinline__ void wave_block(const BlockDesc &d, const BlockDesc &dn, int max_gpair,
+                                           const int *__restrict__ rp, const int *__restrict__ ci,
+                                           const double *__restrict__ val, const double *__restrict__ x,
+                                           double *__restrict__ y, double *prod, int *roff,
+                                           dbl2 (&v)[IPT / 2], int2v (&c)[IPT / 2], int &ro0, int &ro1) {
+  const int lane = threadIdx.x & 63;
+  const int base = d.nnz_start & ~1;
+  const int total = d.nnz_count + d.nnz_start - base;
+  // 1. gathers of the current block (their indices arrived while the previous block was reduced);
+  //    the half-foreign tail pair of an odd block gathers a column this block owns
+  if (total & 1) {
+    const int npairs = (total + 1) >> 1;
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++)
+      if (u * 64 + lane >= npairs - 1) c[u].y = c[u].x;
+  }
+  dbl2 xv[IPT / 2];
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    xv[u].x = x[c[u].x];
+    xv[u].y = x[c[u].y];
+  }
+  const int cur_ro0 = ro0, cur_ro1 = ro1;
+  dbl2 pv[IPT / 2];
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) pv[u] = v[u];
+  // 2. next block's stream goes out BEHIND the gathers (vmcnt retires in order:
+  //    waiting for the gathers must not wait for these)
+  if (HAS_NEXT) wave_issue<IPT, NT>(dn, max_gpair, rp, ci, val, v, c, ro0, ro1);
+  // 3. row offsets and products into this wave's LDS slice
+  roff[lane] = cur_ro0;
+  roff[lane + 64] = cur_ro1;
+  // Every lane stores (lanes past the block's last pair hold a duplicate of it
+  // and land in slots no row offset points to): a conditional store would let
+  // hipcc sink the gathers into the branch, behind the prefetch, and the wait
+  // for them would then drain the prefetch too.
+  dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) prod2[u * 64 + lane] = pv[u] * xv[u];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // 4. per-row sums
   switch (d.kind_g & 0xff) {
-    case 1:  reduce_rows<1>(d, prod, roff, y); break;
-    case 2:  reduce_rows<2>(d, prod, roff, y); break;
-    case 4:  reduce_rows<4>(d, prod, roff, y); break;
-    case 8:  reduce_rows<8>(d, prod, roff, y); break;
-    case 16: reduce_rows<16>(d, prod, roff, y); break;
-    case 32: reduce_rows<32>(d, prod, roff, y); break;
-    default: reduce_rows<64>(d, prod, roff, y); break;
+    case 1:  wave_reduce_rows<1>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 2:  wave_reduce_rows<2>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 4:  wave_reduce_rows<4>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 8:  wave_reduce_rows<8>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 16: wave_reduce_rows<16>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 32: wave_reduce_rows<32>(d.n_rows, d.row_start, prod, roff, y); break;
+    default: wave_reduce_rows<64>(d.n_rows, d.row_start, prod, roff, y); break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int IPT, bool NT>
+__global__ void k_spmv_merge_wave(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int nnz,
+                                  const int *__restrict__ rp, const int *__restrict__ ci,
+                                  const double *__restrict__ val, const double *__restrict__ x,
+                                  double *__restrict__ y) {
+  static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int CAP = 64 * IPT;
+  const int wave = threadIdx.x >> 6, waves_per_wg = blockDim.x >> 6;
+  double *prod = reinterpret_cast<double *>(smem) + wave * (CAP + 2);
+  int *roff = reinterpret_cast<int *>(reinterpret_cast<double *>(smem) + waves_per_wg * (CAP + 2)) + wave * 128;
+
+  // Which blocks does this wave walk?  With the XCD remap every XCD owns one
+  // contiguous eighth of the block list and its resident waves sweep it
+  // together (stride = waves on that XCD), so concurrently processed blocks are
+  // neighbours: shared x lines and seam cache lines stay in that XCD's L2.
+  int b, b_end, stride;
+  if (remap) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int gq = gridDim.x >> 3, gr = gridDim.x & 7;
+    const int wgs_here = gq + (xcd < gr ? 1 : 0);
+    const int nq = n_blocks >> 3, nr = n_blocks & 7;
+    const int xb0 = xcd * nq + min(xcd, nr);
+    b_end = xb0 + nq + (xcd < nr ? 1 : 0);
+    stride = wgs_here * waves_per_wg;
+    b = xb0 + idx * waves_per_wg + wave;
+  } else {
+    stride = gridDim.x * waves_per_wg;
+    b = blockIdx.x * waves_per_wg + wave;
+    b_end = n_blocks;
+  }
+  b = __builtin_amdgcn_readfirstlane(b);
+  if (b >= b_end) return;
+
+  dbl2 v[IPT / 2];
+  int2v c[IPT / 2];
+  int ro0, ro1;
+  const int max_gpair = ((nnz + 1) >> 1) - 1;
+  BlockDesc d = blocks[b];
+  wave_issue<IPT, NT>(d, max_gpair, rp, ci, val, v, c, ro0, ro1);
+  int nb = b + stride;
+  BlockDesc dn = blocks[min(nb, b_end - 1)];
+  while (nb < b_end) {
+    const int nnb = nb + stride;
+    const BlockDesc dnn = blocks[min(nnb, b_end - 1)];       // descriptor two blocks ahead
+    wave_block<IPT, NT, true>(d, dn, max_gpair, rp, ci, val, x, y, prod, roff, v, c, ro0, ro1);
+    d = dn;
+    dn = dnn;
+    nb = nnb;
+  }
+  wave_block<IPT, NT, false>(d, d, max_gpair, rp, ci, val, x, y, prod, roff, v, c, ro0, ro1);
+}
+
+// Long-row pieces as their own launch (the pipelined kernel handles only
+// whole-row blocks): one workgroup per piece.
+template <bool NT>
+__global__ void k_spmv_long(const BlockDesc *__restrict__ blocks, int n_blocks,
+                            const int *__restrict__ ci, const double *__restrict__ val,
+                            const double *__restrict__ x, double *__restrict__ y,
+                            double *__restrict__ partials) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x, WG = blockDim.x;
+  const BlockDesc d = blocks[blockIdx.x];
+  const int end = d.nnz_start + d.nnz_count;
+  double acc = 0.0;
+  for (int k = d.nnz_start + tid; k < end; k += 4 * WG) {
+    int c[4];
+    double v[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int kk = min(k + u * WG, end - 1);
+      c[u] = stream_load<NT>(ci + kk);
+      v[u] = stream_load<NT>(val + kk);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k + u * WG < end) acc = fma(v[u], xv[u], acc);
+  }
+  acc = group_sum<64>(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (WG >> 6); w++) s += red[w];
+    if (d.kind_g & KIND_PARTIAL) partials[d.aux] = s; else y[d.row_start] = s;
   }
 }
 

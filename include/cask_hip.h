@@ -36,7 +36,8 @@ extern "C" {
 /* kernel variants */
 #define CASK_HIP_VARIANT_AUTO     0   /* pick from row-length statistics */
 #define CASK_HIP_VARIANT_VECTOR   1   /* lanes_per_row lanes of a wavefront per row (1 = thread per row) */
-#define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, streamed through LDS */
+#define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, products and x tile in LDS */
+#define CASK_HIP_VARIANT_MERGE_WAVE 3 /* merge-based, persistent software-pipelined waves (no workgroup barrier, x from L2) */
 
 typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launch plan */
 
@@ -49,7 +50,7 @@ typedef struct cask_hip_params {
   int32_t lanes_per_row;    /* VECTOR: 1,2,4,...,64                                  */
   int32_t tile_width;       /* doubles of x staged in LDS per workgroup; -1 = no tile */
   int32_t wg_size;          /* threads per workgroup: 64,128,256,512,1024            */
-  int32_t items_per_thread; /* MERGE: merge items per thread: 2,4,8,16               */
+  int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
   int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off                 */
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
   int32_t reserved;

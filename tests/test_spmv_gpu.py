@@ -25,6 +25,11 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096),
     dict(variant="merge", items_per_thread=4, wg_size=128, tile_width=64, xcd_remap=-1),
     dict(variant="merge", items_per_thread=16, wg_size=256, tile_width=-1, nontemporal=-1),
+    dict(variant="merge", items_per_thread=8, wg_size=512, tile_width=1024),
+    dict(variant="merge_wave", items_per_thread=2, wg_size=64),
+    dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
+    dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
+    dict(variant="merge_wave", items_per_thread=16, wg_size=128),
     dict(),   # AUTO / all defaults
 ]
 DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
@@ -76,6 +81,7 @@ def test_baseline_configs_full_size(name):
     want1 = oracle.csr_spmv(rp, ci, va, x1)
     colsum = oracle.csr_spmv_t(n, rp, ci, va, np.ones(n))
     for dp in (dict(variant="merge"), dict(variant="vector"), dict(variant="merge", tile_width=-1),
+               dict(variant="merge_wave"), dict(variant="merge", wg_size=512, items_per_thread=8),
                dict(variant="vector", lanes_per_row=8, tile_width=-1)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         y1, y2 = m.spmv(x1), m.spmv(x2)
@@ -127,6 +133,7 @@ def test_long_rows_split_across_workgroups():
     for dp in (dict(variant="merge", wg_size=64, items_per_thread=2),
                dict(variant="merge", wg_size=64, items_per_thread=2, tile_width=256),
                dict(variant="merge", wg_size=256, items_per_thread=8),
+               dict(variant="merge_wave", items_per_thread=2), dict(variant="merge_wave", items_per_thread=16, wg_size=64),
                dict(variant="vector", lanes_per_row=64), dict(variant="vector", lanes_per_row=1)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         info = m.info
@@ -135,6 +142,8 @@ def test_long_rows_split_across_workgroups():
         oracle.assert_almost_equal(got, want, what=f"long rows {dp}")
         if dp["variant"] == "merge" and dp["wg_size"] == 64:
             assert info.n_long_rows == 3 and info.n_split_rows >= 1
+        if dp["variant"] == "merge_wave":
+            assert info.n_long_rows >= 1
 
 
 def test_device_vector_entry_point_and_streams():
@@ -204,10 +213,11 @@ def test_tune_sweeps_in_reference_order_and_keeps_the_best():
     x = mmio.test_vector(n)
     want = oracle.csr_spmv(rp, ci, va, x)
     m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
-    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[4, 16, 64], tiles=[-1, 2048],
-                       wg_sizes=[256], items=[4, 8], warmup=1, iters=5)
-    # first list (variants) fastest; lanes only swept for VECTOR, items only for MERGE
-    assert len(pts) == 3 * 2 + 2 * 2
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE, capi.VARIANT_MERGE_WAVE], lanes=[4, 16, 64],
+                       tiles=[-1, 2048], wg_sizes=[256], items=[4, 8], warmup=1, iters=5)
+    # first list (variants) fastest; lanes only swept for VECTOR, items only for the merge kernels,
+    # tiles not for MERGE_WAVE
+    assert len(pts) == 3 * 2 + 2 * 2 + 2
     assert pts[0]["params"]["variant"] == "vector" and pts[0]["params"]["lanes_per_row"] == 4
     assert pts[1]["params"]["variant"] == "merge"
     assert all(p["valid"] and p["usec"] > 0 for p in pts)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect rocprofv3 PMC passes for one bench.py design point (run on the GPU box via gpurun).
+# usage: tools/pmc.sh <tag> [bench args...]
+set -u
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+args="--steps 30 --warmup 5 --launch eager --no-cpu-baseline --no-tune $*"
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT" \
+           "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 GRBM_GUI_ACTIVE" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" \
+           "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pass$i -- python3 $root/bench.py $args > $out/pass$i.json 2> $out/pass$i.err || echo "pass $i failed: $(tail -2 $out/pass$i.err)"
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "k_spmv" not in k: continue
+        agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print("==", k)
+    for c, v in sorted(d.items()):
+        v = v[len(v)//3:]          # skip the warm-up launches
+        print(f"  {c:34s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+PY
