@@ -31,10 +31,10 @@ EXPORTED_SYMBOLS = (
 class Params(Structure):
     _fields_ = [("variant", c_int32), ("lanes_per_row", c_int32), ("tile_width", c_int32),
                 ("wg_size", c_int32), ("items_per_thread", c_int32), ("xcd_remap", c_int32),
-                ("nontemporal", c_int32), ("reserved", c_int32)]
+                ("nontemporal", c_int32), ("index16", c_int32)]
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_}
         d["variant"] = VARIANT_NAMES.get(d["variant"], d["variant"])
         return d
 
@@ -127,10 +127,10 @@ def device_props(device: int = 0) -> dict:
 
 
 def make_params(variant=0, lanes_per_row=0, tile_width=0, wg_size=0, items_per_thread=0,
-                xcd_remap=0, nontemporal=0) -> Params:
+                xcd_remap=0, nontemporal=0, index16=0) -> Params:
     if isinstance(variant, str):
         variant = {v: k for k, v in VARIANT_NAMES.items()}[variant]
-    return Params(variant, lanes_per_row, tile_width, wg_size, items_per_thread, xcd_remap, nontemporal, 0)
+    return Params(variant, lanes_per_row, tile_width, wg_size, items_per_thread, xcd_remap, nontemporal, index16)
 
 
 def _np(a, dtype):

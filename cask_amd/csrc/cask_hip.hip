@@ -80,6 +80,7 @@ struct Plan {
   int n_blocks = 0, n_long_blocks = 0;
   DevBuf<SplitRow> split_rows;
   DevBuf<double> partials;
+  DevBuf<unsigned short> ci16;     // MERGE with an x tile: col_ind - cmin per in-tile block (2 B/nnz)
   int n_long_rows = 0, n_split_rows = 0;
   // VECTOR
   DevBuf<int2v> xspan;
@@ -140,6 +141,8 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.tile_width < -1) return fail(CASK_HIP_ERR_INVALID, "tile_width must be -1 (off), 0 (default) or > 0");
   if (out.xcd_remap == 0) out.xcd_remap = 1;
   if (out.nontemporal == 0) out.nontemporal = 1;
+  if (out.index16 == 0) out.index16 = 1;
+  if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
     if (8 * (cap + 2) + 8 * out.wg_size > MAX_LDS_BYTES)
@@ -224,6 +227,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.prm = prm;
   pl.blocks.release();
   pl.long_blocks.release();
+  pl.ci16.release();
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
@@ -303,7 +307,15 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       }
       pl.xu = xu;
       if (xu > 0) pl.prm.tile_width = xu * prm.wg_size;
+      if (xu > 0 && prm.index16 > 0) {
+        HIP_TRY(pl.ci16.alloc((size_t)m.nnz + 8));
+        hipLaunchKernelGGL(k_build_ci16, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid,
+                           xu * prm.wg_size, m.d_ci, pl.ci16.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(m.stream));
+      }
     }
+    if (!pl.ci16.p) pl.prm.index16 = -1;
     pl.ldsx = pl.xu > 0;
     pl.lds_bytes = base_lds + 8 * pl.xu * prm.wg_size;
   } else {
@@ -354,12 +366,14 @@ void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipSt
   const Plan &pl = m.plan;
   const dim3 grid(pl.grid), block(pl.prm.wg_size);
   const int remap = pl.prm.xcd_remap > 0;
-  if (pl.prm.nontemporal > 0)
-    hipLaunchKernelGGL((k_spmv_merge<IPT, XU, true>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, remap,
-                       m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p);
-  else
-    hipLaunchKernelGGL((k_spmv_merge<IPT, XU, false>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, remap,
-                       m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, m.d_val, x, y, pl.partials.p);
+  const unsigned *ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
+#define CASK_LAUNCH_M(NT, C16)                                                                              \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, \
+                     remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, m.d_val, x, y, pl.partials.p)
+  const bool nt = pl.prm.nontemporal > 0;
+  if (XU > 0 && ci16) { if (nt) CASK_LAUNCH_M(true, (XU > 0)); else CASK_LAUNCH_M(false, (XU > 0)); }
+  else                { if (nt) CASK_LAUNCH_M(true, false); else CASK_LAUNCH_M(false, false); }
+#undef CASK_LAUNCH_M
 }
 
 template <int IPT>
@@ -708,16 +722,16 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                   int32_t n_wg_sizes, const int32_t *items, int32_t n_items, int32_t warmup, int32_t iters,
                   cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
-  static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE};
-  static const int32_t def_lanes[] = {2, 4, 8, 16, 32, 64};
-  static const int32_t def_tiles[] = {-1, 4096};
-  static const int32_t def_wg[] = {256};
-  static const int32_t def_items[] = {4, 8, 16};
-  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 2; }
-  if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 6; }
-  if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 2; }
-  if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 1; }
-  if (!items || n_items <= 0) { items = def_items; n_items = 3; }
+  static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE};
+  static const int32_t def_lanes[] = {4, 8, 16, 32};
+  static const int32_t def_tiles[] = {-1, 1024, 4096};
+  static const int32_t def_wg[] = {256, 512};
+  static const int32_t def_items[] = {4, 8};
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 3; }
+  if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 4; }
+  if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 3; }
+  if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 2; }
+  if (!items || n_items <= 0) { items = def_items; n_items = 2; }
   if (warmup < 0) warmup = 0;
   if (iters <= 0) iters = 20;
   HIP_TRY(hipSetDevice(m->device));

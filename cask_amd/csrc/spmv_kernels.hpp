@@ -200,9 +200,15 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
 // only for (1) and (2) while the stream is still in flight; when the stream
 // lands the gathers are LDS reads (~100 ns, no TA traffic) instead of a second
 // dependent trip to L2.  XU = 0 gathers from L2 (window wider than the tile).
-template <int IPT, int XU, bool NT>
+//
+// C16 (only with an x window): the block's column indices are read from the
+// 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
+// per nonzero and already LDS offsets -- the stream shrinks from 12 to 10
+// bytes per nonzero, which on a bandwidth-bound kernel is the whole game.
+template <int IPT, int XU, bool NT, bool C16>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
+                                            const unsigned *__restrict__ ci16,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs) {
   const int WG = blockDim.x, tid = threadIdx.x;
@@ -236,7 +242,13 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   for (int u = 0; u < IPT / 2; u++) {
     const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
     v[u] = stream_load<NT>(val2 + p);
-    c[u] = stream_load<NT>(ci2 + p);
+    if (C16) {
+      const unsigned w = stream_load<NT>(ci16 + p);
+      c[u].x = (int)(w & 0xffffu);
+      c[u].y = (int)(w >> 16);
+    } else {
+      c[u] = stream_load<NT>(ci2 + p);
+    }
   }
 
   if (XU > 0) {
@@ -259,8 +271,8 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
     if (XU > 0) {
-      xv[u].x = xs[c[u].x - d.cmin];
-      xv[u].y = xs[c[u].y - d.cmin];
+      xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
+      xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
     } else {
       xv[u].x = x[c[u].x];
       xv[u].y = x[c[u].y];
@@ -284,9 +296,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   }
 }
 
-template <int IPT, int XU, bool NT>
+template <int IPT, int XU, bool NT, bool C16>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
+                             const unsigned *__restrict__ ci16,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
@@ -330,9 +343,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 
   const int max_gpair = ((nnz + 1) >> 1) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT>(d, n_cols, max_gpair, rp, ci, val, x, y, prod, roff, xs);
+    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
   else
-    merge_block<IPT, 0, NT>(d, n_cols, max_gpair, rp, ci, val, x, y, prod, roff, xs);
+    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
 }
 
 // --------------------------------------------- merge variant, pipelined waves
@@ -575,6 +588,18 @@ __global__ void k_col_span_blocks(BlockDesc *blocks, int n_blocks, const int *__
     blocks[b].cmin = hi < 0 ? 0 : lo;
     blocks[b].cwidth = hi < 0 ? 0 : hi - lo + 1;
   }
+}
+
+// Fills the 16-bit side index (col_ind - cmin) for every block whose x window
+// fits the LDS tile; other blocks keep reading the 32-bit col_ind.
+__global__ void k_build_ci16(const BlockDesc *__restrict__ blocks, int n_blocks, int capacity,
+                             const int *__restrict__ ci, unsigned short *__restrict__ ci16) {
+  const int b = blockIdx.x;
+  if (b >= n_blocks) return;
+  const BlockDesc d = blocks[b];
+  if ((d.kind_g & KIND_LONG) || d.cwidth <= 0 || d.cwidth > capacity) return;
+  const int e = d.nnz_start + d.nnz_count;
+  for (int k = d.nnz_start + threadIdx.x; k < e; k += blockDim.x) ci16[k] = (unsigned short)(ci[k] - d.cmin);
 }
 
 __global__ void k_col_span_rows(int2v *xspan, int n_wg, int rows_per_wg, int n_rows,

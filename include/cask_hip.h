@@ -42,7 +42,7 @@ extern "C" {
 typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launch plan */
 
 /* Architecture parameters of one SpMV "design point"; 0 in any field = default
- * (tile_width, xcd_remap, nontemporal: 0 = default, -1 = off).
+ * (tile_width, xcd_remap, nontemporal, index16: 0 = default, -1 = off).
  * The DSE (cask_hip_tune) sweeps these per matrix exactly as the reference's
  * DSE sweeps num_pipes/input_width/cache_size (src/runtime/Dse.cpp:103-109). */
 typedef struct cask_hip_params {
@@ -53,7 +53,7 @@ typedef struct cask_hip_params {
   int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
   int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off                 */
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
-  int32_t reserved;
+  int32_t index16;          /* MERGE with an x tile: 1 = stream 16-bit (col - tile start) indices, -1 = off */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {

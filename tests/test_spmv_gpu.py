@@ -26,6 +26,7 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=4, wg_size=128, tile_width=64, xcd_remap=-1),
     dict(variant="merge", items_per_thread=16, wg_size=256, tile_width=-1, nontemporal=-1),
     dict(variant="merge", items_per_thread=8, wg_size=512, tile_width=1024),
+    dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, index16=-1),
     dict(variant="merge_wave", items_per_thread=2, wg_size=64),
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),

@@ -68,6 +68,9 @@ def main():
         points.append(dict(variant="vector", lanes_per_row=L, wg_size=wg, tile_width=tile, xcd_remap=xcd, nontemporal=nt))
     for ipt, wg, tile, (xcd, nt) in itertools.product(ipt_l, wg_l, tile_l, flags):
         points.append(dict(variant="merge", items_per_thread=ipt, wg_size=wg, tile_width=tile, xcd_remap=xcd, nontemporal=nt))
+        if tile > 0 and (xcd, nt) == (1, 1):
+            points.append(dict(variant="merge", items_per_thread=ipt, wg_size=wg, tile_width=tile, xcd_remap=xcd,
+                               nontemporal=nt, index16=-1))
     for ipt, wg, (xcd, nt) in itertools.product(ipt_l, [64, 128, 256, 512, 1024], flags):
         points.append(dict(variant="merge_wave", items_per_thread=ipt, wg_size=wg, xcd_remap=xcd, nontemporal=nt))
 
