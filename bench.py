@@ -160,14 +160,19 @@ def main():
     x_full = torch.from_numpy(x_host).to(dev) if world == 1 else torch.zeros(n_global, dtype=torch.float64, device=dev)
     y = torch.zeros(n_local, dtype=torch.float64, device=dev)
 
-    # ---- measured DSE on the first copy, applied to all ---------------------------
+    # ---- measured DSE (cold: on the rotating copies), best point left active --------
     tune_info = None
     if not args.no_tune and args.variant is None:
-        pts, best = mats[0].tune(warmup=3, iters=30)
-        chosen = mats[0].params
-        for m in mats[1:]:
-            m.set_params(chosen)
-        tune_info = {"points": len(pts), "best_usec_warm": round(pts[best]["usec"], 3)}
+        from cask_amd import dse
+        rows, best, took = dse.explore(mats, x_full if world == 1 else torch.from_numpy(x_host).to(dev), y)
+        if world > 1:
+            # every rank must run the same design point: take rank 0's winner
+            obj = [mats[0].params.as_dict()]
+            dist.broadcast_object_list(obj, src=0)
+            prm = capi.make_params(**obj[0])
+            for m in mats:
+                m.set_params(prm)
+        tune_info = {"points": len(rows), "best_usec_cold": best["usec"], "seconds": round(took, 2)}
     design = mats[0].params.as_dict()
     info = mats[0].info
 

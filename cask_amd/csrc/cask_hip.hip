@@ -114,15 +114,16 @@ namespace {
 int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip_params &out) {
   out = in;
   const double mean = m.n_rows ? (double)m.nnz / m.n_rows : 0.0;
-  if (out.wg_size == 0) out.wg_size = 256;
+  if (out.variant == CASK_HIP_VARIANT_AUTO) {
+    // Measured on all four BASELINE families (profiles/r01_dse_out.json): the workgroup-level merge
+    // kernel wins everywhere; the DSE (cask_hip_tune / cask_amd.dse) refines the shape per matrix.
+    out.variant = CASK_HIP_VARIANT_MERGE;
+  }
+  const bool long_rows = mean >= 16.0;
+  if (out.wg_size == 0) out.wg_size = (out.variant == CASK_HIP_VARIANT_MERGE && long_rows) ? 512 : 256;
   if (!(out.wg_size == 64 || out.wg_size == 128 || out.wg_size == 256 || out.wg_size == 512 ||
         out.wg_size == 1024))
     return fail(CASK_HIP_ERR_INVALID, "wg_size must be 64, 128, 256, 512 or 1024");
-  if (out.variant == CASK_HIP_VARIANT_AUTO) {
-    // Regular, moderately long rows: lanes-per-row kernel; short or skewed rows: merge-based.
-    const bool skewed = m.max_row > 8 * std::max(mean, 1.0) + 64;
-    out.variant = (mean >= 12.0 && !skewed) ? CASK_HIP_VARIANT_VECTOR : CASK_HIP_VARIANT_MERGE;
-  }
   if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE &&
       out.variant != CASK_HIP_VARIANT_MERGE_WAVE)
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
@@ -133,7 +134,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   }
   if (!is_pow2(out.lanes_per_row) || out.lanes_per_row > 64)
     return fail(CASK_HIP_ERR_INVALID, "lanes_per_row must be a power of two in 1..64");
-  if (out.items_per_thread == 0) out.items_per_thread = 8;
+  if (out.items_per_thread == 0) out.items_per_thread = (out.variant == CASK_HIP_VARIANT_MERGE && long_rows) ? 4 : 8;
   if (!(out.items_per_thread == 2 || out.items_per_thread == 4 || out.items_per_thread == 8 ||
         out.items_per_thread == 16))
     return fail(CASK_HIP_ERR_INVALID, "items_per_thread must be 2, 4, 8 or 16");

@@ -1,0 +1,147 @@
+"""Measured design-space exploration (DSE) for one matrix on one GPU.
+
+The reference's DSE (src/main.cpp:119-207, src/runtime/Dse.cpp:32-140, driven by
+src/frontend/cask.py:90-122) walks the cross product of architecture parameter
+ranges, scores every point with an FPGA cycle MODEL and writes the winner per
+matrix to ``dse_out.json``.  Here the loop is the same shape but every point is
+MEASURED on the GPU: the point is applied to R rotating device copies of the
+matrix (R copies exceed 2x the 256 MiB Infinity Cache, so every launch reads
+HBM), ``steps`` SpMVs are captured into a HIP graph, and the best replay gives
+microseconds per launch -> GFLOP/s and algorithmic GB/s against the 8 TB/s peak.
+
+Parameter mapping (include/cask_hip.h): input_width -> lanes_per_row,
+cache_size -> tile_width, num_pipes -> workgroup shape (wg_size,
+items_per_thread), plus the kernel variant.  Points are visited with the FIRST
+range fastest (Utils.hpp:158-202) and -- unlike Dse.cpp:40-47 -- including the
+last one.
+"""
+from __future__ import annotations
+
+import json
+import time
+from pathlib import Path
+
+from . import capi
+
+HBM_PEAK_GBS = 8000.0
+INFINITY_CACHE_BYTES = 256 << 20
+
+# default ranges (the analogue of src/frontend/params.json)
+DEFAULT_RANGES = {
+    "variant": ["vector", "merge", "merge_wave"],
+    "lanes_per_row": [4, 8, 16, 32],
+    "tile_width": [-1, 1024, 4096],
+    "wg_size": [256, 512],
+    "items_per_thread": [4, 8],
+}
+
+
+def design_points(ranges=None):
+    """Cross product in reference sweep order (first key fastest); parameters that a variant
+    ignores are not swept for it."""
+    r = dict(DEFAULT_RANGES)
+    if ranges:
+        r.update(ranges)
+    pts, seen = [], set()
+    for ipt in r["items_per_thread"]:
+        for wg in r["wg_size"]:
+            for tile in r["tile_width"]:
+                for lanes in r["lanes_per_row"]:
+                    for var in r["variant"]:
+                        if var == "vector":
+                            dp = dict(variant=var, lanes_per_row=lanes, tile_width=tile, wg_size=wg)
+                        elif var == "merge":
+                            dp = dict(variant=var, items_per_thread=ipt, tile_width=tile, wg_size=wg)
+                        else:
+                            dp = dict(variant=var, items_per_thread=ipt, wg_size=wg)
+                        key = tuple(sorted(dp.items()))
+                        if key not in seen:
+                            seen.add(key)
+                            pts.append(dp)
+    return pts
+
+
+def copies_for_cold(matrix_bytes: int) -> int:
+    return max(2, -(-2 * INFINITY_CACHE_BYTES // max(matrix_bytes, 1)) + 1)
+
+
+def measure(mats, x_t, y_t, steps=60, reps=3):
+    """Best microseconds per launch over `reps` replays of a `steps`-launch HIP graph rotating over mats."""
+    import torch
+    n = len(mats)
+    for i in range(min(4, steps)):
+        mats[i % n].spmv_device(x_t, y_t)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(steps):
+            mats[i % n].spmv_device(x_t, y_t)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / steps)
+    del g
+    return best
+
+
+def explore(mats, x_t, y_t, points=None, steps=60, reps=3):
+    """Measure every design point on the rotating copies `mats`; leave the fastest active on all
+    of them.  Returns (rows, best_row); a row is the design point plus usec/gflops/gbs/pct_peak."""
+    points = points if points is not None else design_points()
+    info0 = mats[0].info
+    nnz, alg = int(info0.nnz), int(info0.algorithmic_bytes)
+    rows, best = [], None
+    t0 = time.perf_counter()
+    for dp in points:
+        try:
+            prm = capi.make_params(**dp)
+            for m in mats:
+                m.set_params(prm)
+        except ValueError as e:
+            rows.append({**dp, "valid": False, "error": str(e)})
+            continue
+        us = measure(mats, x_t, y_t, steps, reps)
+        info = mats[0].info
+        row = {**mats[0].params.as_dict(), "valid": True, "usec": round(us, 3),
+               "gflops": round(2.0 * nnz / us * 1e-3, 2), "gbs_algorithmic": round(alg / us * 1e-3, 1),
+               "pct_hbm_peak": round(100.0 * alg / us * 1e-3 / HBM_PEAK_GBS, 2),
+               "grid": int(info.grid), "lds_bytes": int(info.lds_bytes)}
+        rows.append(row)
+        if best is None or us < best["usec"]:
+            best = row
+    if best is not None:
+        keys = ("variant", "lanes_per_row", "tile_width", "wg_size", "items_per_thread", "xcd_remap",
+                "nontemporal", "index16")
+        prm = capi.make_params(**{k: best[k] for k in keys})
+        for m in mats:
+            m.set_params(prm)
+    took = time.perf_counter() - t0
+    return rows, best, took
+
+
+def write_dse_out(path, entries, took):
+    """dse_out.json in the reference's layout (src/main.cpp:81-117): `best_architectures[]` with
+    name / architecture_params / matrices, `estimated_gflops` replaced by MEASURED numbers."""
+    doc = {"date": time.strftime("%a %b %d %H:%M:%S %Y"), "took": took, "best_architectures": []}
+    for e in entries:
+        b = e["best"]
+        doc["best_architectures"].append({
+            "name": b["variant"],
+            "measured_gflops": b["gflops"],
+            "measured_usec": b["usec"],
+            "measured_gbs_algorithmic": b["gbs_algorithmic"],
+            "pct_hbm_peak": b["pct_hbm_peak"],
+            "architecture_params": {k: b[k] for k in ("variant", "lanes_per_row", "tile_width", "wg_size",
+                                                      "items_per_thread", "xcd_remap", "nontemporal", "index16")},
+            "launch": {"grid": b["grid"], "lds_bytes": b["lds_bytes"]},
+            "matrices": [e["matrix"]],
+            "points_evaluated": e["points"],
+        })
+    Path(path).write_text(json.dumps(doc, indent=2))
+    return doc

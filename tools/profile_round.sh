@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round profile for the headline bench (run on the GPU box via gpurun):
+#   tools/profile_round.sh <tag>     e.g. r01
+# 1. bench.py as the driver runs it              -> gpurun_out/bench_<tag>.json
+# 2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/prof_<tag>/
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, for the SpMV
+#    kernel and for a calibration kernel that streams a known byte count with the
+#    same 16-byte access shape (tools/membench.hip k_oneshot), because gfx950's
+#    FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM).
+set -u
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+python3 bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
+cat $out/bench_$tag.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline > $out/prof_$tag.json 2> $out/prof_$tag.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_spmv_$c -- python3 $root/bench.py --steps 40 --warmup 10 --launch eager --no-cpu-baseline > /dev/null 2> $out/pmc_${tag}_spmv_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
+done
+python3 $root/tools/traffic_summary.py $tag

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn the PMC passes of tools/profile_round.sh into profiles/traffic_cant.json.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  The calibration kernel (tools/membench.hip
+k_oneshot<8,true>) reads exactly 12*nnz bytes with 16-byte-per-lane nontemporal
+loads; the factor known_bytes / (FETCH_SIZE*1024) corrects gfx950's FETCH_SIZE
+for that access shape (the guide measures exactly 2.0) and is applied to the
+SpMV kernel's FETCH_SIZE.  WRITE_SIZE is taken as is.
+"""
+import csv
+import glob
+import json
+import statistics
+import sys
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = Path(__file__).resolve().parent.parent
+out = root / "gpurun_out"
+
+
+def counter(dirpat, kernel_sub, name):
+    vals = []
+    for f in glob.glob(str(out / dirpat / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+    vals = vals[len(vals) // 4:]                      # drop warm-up launches
+    return statistics.median(vals) if vals else None, len(vals)
+
+
+CAL_NNZ = 4010891
+fetch_cal, n1 = counter(f"pmc_{tag}_calib_FETCH_SIZE", "k_oneshot<8, true>", "FETCH_SIZE")
+known = 12.0 * CAL_NNZ
+factor = known / (fetch_cal * 1024.0) if fetch_cal else None
+res = {"tag": tag, "calibration": {"kernel": "k_oneshot<8,true> (tools/membench.hip)", "known_bytes": known,
+                                   "FETCH_SIZE_KiB": fetch_cal, "factor": factor, "samples": n1}}
+for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
+    f, nf = counter(f"pmc_{tag}_spmv_FETCH_SIZE", kern, "FETCH_SIZE")
+    w, nw = counter(f"pmc_{tag}_spmv_WRITE_SIZE", kern, "WRITE_SIZE")
+    if f is None:
+        continue
+    res["kernel"] = kern.rstrip("<")
+    res["FETCH_SIZE_KiB"] = f
+    res["WRITE_SIZE_KiB"] = w
+    res["samples"] = [nf, nw]
+    if factor:
+        res["hbm_bytes_per_launch"] = round(f * 1024.0 * factor + (w or 0) * 1024.0)
+    break
+print(json.dumps(res, indent=1))
+(root / "gpurun_out" / f"traffic_{tag}.json").write_text(json.dumps(res, indent=1))
