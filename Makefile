@@ -5,7 +5,39 @@ ARCH       ?= gfx950
 HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Icask_amd/csrc -Wall -Wno-unused-function
 LIBDIR     := cask_amd/lib
 
-all: $(LIBDIR)/libcask_hip.so
+GENDIR     := $(LIBDIR)/lib-generated
+CXXFLAGS   ?= -std=c++14 -O2 -fPIC -Wall -Iinclude
+HOSTSRC    := cask_amd/csrc/host/CaskHost.cpp
+HOSTHDR    := $(wildcard include/cask/*.hpp) include/cask_hip.h
+RPATHS     := -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/lib-generated' -Wl,-rpath,'$$ORIGIN/../cask_amd/lib' -Wl,-rpath,'$$ORIGIN/../cask_amd/lib/lib-generated'
+
+all: $(LIBDIR)/libcask_hip.so $(LIBDIR)/libCaskHip.so $(GENDIR)/libSpmv_hip.so build/main build/test_host
+
+# C++ host runtime over the C ABI (the SparkCpuLib of this build)
+$(LIBDIR)/libCaskHip.so: $(HOSTSRC) $(HOSTHDR) $(LIBDIR)/libcask_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) -L$(LIBDIR) -lcask_hip $(RPATHS)
+
+# generated implementation library (target hip): loader constructor + design points
+$(GENDIR)/libSpmv_hip.so: tools/gen_impl.py include/cask/GeneratedImplSupport.hpp
+	python3 tools/gen_impl.py --out-dir $(GENDIR) --cpp $(CXX)
+
+# DSE executable: build/main <bench-path> <params.json> -> dse_out.json
+build/main: cask_amd/csrc/host/dse_main.cpp $(LIBDIR)/libCaskHip.so
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lCaskHip -lcask_hip $(RPATHS)
+
+# CPU unit tests of the host surface
+build/test_host: tests/cpp/test_host.cpp $(HOSTHDR)
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $<
+
+# integration client (links the CPU oracle: test infrastructure only)
+build/test_spmv_hip: tests/clients/test_spmv_client.cpp $(LIBDIR)/libCaskHip.so $(GENDIR)/libSpmv_hip.so oracle
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -L$(GENDIR) -Loracle/_build -lCaskHip -lSpmv_hip -lcask_hip -lcask_oracle \
+	  $(RPATHS) -Wl,-rpath,'$$ORIGIN/../oracle/_build'
+
+clients: build/test_spmv_hip
 
 $(LIBDIR)/libcask_hip.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h
 	mkdir -p $(LIBDIR)
@@ -17,4 +49,4 @@ oracle:
 clean:
 	rm -rf $(LIBDIR) build oracle/_build
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean clients

@@ -1,0 +1,88 @@
+"""C++ host surface (include/cask/*.hpp + libCaskHip.so + generated libSpmv_hip.so).
+CPU part: unit tests against the reference's gtest known answers, link seams.
+GPU part: the integration client over every reference fixture and the DSE executable."""
+import json
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO, golden_matrix_files
+
+LIBDIR = REPO / "cask_amd" / "lib"
+
+
+def make(*targets):
+    subprocess.run(["make", "-C", str(REPO), "-s", *targets], check=True, capture_output=True)
+
+
+def test_host_unit_tests(plain_mtx_dir):
+    make("build/test_host")
+    out = subprocess.run([str(REPO / "build" / "test_host"), str(plain_mtx_dir)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert re.search(r"\d+ checks, 0 failures", out.stdout)
+
+
+def test_generated_library_exports_the_loader_constructor():
+    """The seam the reference's clients link against: the loader ctor, both variants."""
+    make("cask_amd/lib/lib-generated/libSpmv_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", str(LIBDIR / "lib-generated" / "libSpmv_hip.so")],
+                         check=True, capture_output=True, text=True).stdout
+    assert "_ZN4cask7runtime24SpmvImplementationLoaderC1Ev" in out
+    assert "_ZN4cask7runtime24SpmvImplementationLoaderC2Ev" in out
+    assert "cask_hip_generated_design_point" in out
+
+
+def test_host_library_exports_the_spmv_methods():
+    make("cask_amd/lib/libCaskHip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", str(LIBDIR / "libCaskHip.so")], check=True,
+                         capture_output=True, text=True).stdout
+    # the symbols a client compiled against the reference headers would reference
+    assert "_ZN4cask4spmv4Spmv10preprocessERKNS_9CsrMatrixE" in out
+    assert "_ZN4cask4spmv4Spmv4spmvERKNS_6VectorE" in out
+
+
+def test_gen_impl_from_dse_out(tmp_path):
+    dse = {"best_architectures": [
+        {"architecture_params": {"variant": "merge", "lanes_per_row": 16, "tile_width": 1024, "wg_size": 512,
+                                 "items_per_thread": 4, "xcd_remap": 1, "nontemporal": 1, "index16": 1},
+         "matrices": ["cant.mtx"]},
+        {"architecture_params": {"variant": 2, "lanes_per_row": 1, "tile_width": -1, "wg_size": 256,
+                                 "items_per_thread": 8, "xcd_remap": 1, "nontemporal": 1, "index16": -1},
+         "matrices": ["G3_circuit.mtx"]}]}
+    (tmp_path / "dse_out.json").write_text(json.dumps(dse))
+    subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dse", str(tmp_path / "dse_out.json"),
+                    "--out-dir", str(tmp_path)], check=True, capture_output=True)
+    src = (tmp_path / "GeneratedImplementations.cpp").read_text()
+    assert src.count("new GeneratedSpmvImplementation(") == 2
+    assert "{2, 16, 1024, 512, 4, 1, 1, 1}" in src and "{2, 1, -1, 256, 8, 1, 1, -1}" in src
+    assert (tmp_path / "libSpmv_hip.so").exists()
+
+
+@pytest.mark.gpu
+def test_integration_client_over_reference_fixtures(plain_mtx_dir):
+    """ctest -R hw of the reference (CMakeLists.txt:135-139): test_spmv_<target> <matrix> for every fixture."""
+    make("clients")
+    exe = REPO / "build" / "test_spmv_hip"
+    for key, _ in golden_matrix_files():
+        path = plain_mtx_dir / (key + ".mtx")
+        out = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
+        assert out.returncode == 0 and "Test passed!" in out.stdout, (key, out.stdout[-600:], out.stderr[-300:])
+        assert "Result  Gflops (actual)=" in out.stdout
+
+
+@pytest.mark.gpu
+def test_dse_executable_writes_dse_out(plain_mtx_dir, tmp_path):
+    make("build/main")
+    out = subprocess.run([str(REPO / "build" / "main"), str(plain_mtx_dir / "benchmark"),
+                          str(REPO / "cask_amd" / "csrc" / "host" / "params.json")], cwd=tmp_path,
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-500:]
+    doc = json.loads((tmp_path / "dse_out.json").read_text())
+    assert len(doc["best_architectures"]) == 3
+    for arch in doc["best_architectures"]:
+        assert arch["measured_gflops"] > 0 and arch["points_evaluated"] > 10
+        assert arch["architecture_params"]["variant"] in (1, 2, 3)
+    # and the generator accepts what the DSE wrote
+    subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dse", str(tmp_path / "dse_out.json"),
+                    "--out-dir", str(tmp_path)], check=True, capture_output=True)
