@@ -39,9 +39,9 @@ build/test_spmv_hip: tests/clients/test_spmv_client.cpp $(LIBDIR)/libCaskHip.so 
 
 clients: build/test_spmv_hip
 
-$(LIBDIR)/libcask_hip.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h
+$(LIBDIR)/libcask_hip.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h include/cask_hip_dfe.h
 	mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ cask_amd/csrc/cask_hip.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip
 
 oracle:
 	$(MAKE) -C oracle _build/libcask_oracle.so
@@ -50,3 +50,8 @@ clean:
 	rm -rf $(LIBDIR) build oracle/_build
 
 .PHONY: all oracle clean clients
+
+# diagnostic build with in-kernel phase stamps (tools/stamps.py); never used by tests or bench
+build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -shared -o $@ cask_amd/csrc/cask_hip.hip

@@ -506,6 +506,14 @@ struct SolverScratch {
 // ======================================================================= C ABI
 extern "C" {
 
+#ifdef CASK_STAMPS
+// diagnostic build only: point the kernels' stamp buffer at device memory (8 x u64 per workgroup)
+int cask_hip_debug_set_stamps(unsigned long long *d_buf) {
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_buf, sizeof(d_buf)));
+  return CASK_HIP_OK;
+}
+#endif
+
 const char *cask_hip_last_error(void) { return g_err.c_str(); }
 int cask_hip_abi_version(void) { return CASK_HIP_ABI_VERSION; }
 

@@ -15,6 +15,18 @@
 
 namespace caskhip {
 
+// Diagnostic build only (-DCASK_STAMPS, tools/stamps.py): wave 0 of every merge workgroup records
+// s_memrealtime (100 MHz) at phase boundaries into a side buffer no other code reads.
+#ifdef CASK_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#define CASK_STAMP(i)                                                                     \
+  do {                                                                                    \
+    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CASK_STAMP(i) do {} while (0)
+#endif
+
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int    int2v __attribute__((ext_vector_type(2)));
 
@@ -251,6 +263,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
     }
   }
 
+  CASK_STAMP(1);
   if (XU > 0) {
 #pragma unroll
     for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
@@ -258,6 +271,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   roff[tid] = ro0;
   roff[tid + WG] = ro1;
   if (XU > 0) __syncthreads();
+  CASK_STAMP(2);
 
   // foreign elements: give them a column this block owns, so their gather stays
   // inside the x window / inside x (their products land in slots no row uses)
@@ -281,9 +295,14 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // every lane stores: lanes past the last pair hold a duplicate of it and land
   // in slots no row offset points to
   dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
+#ifdef CASK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CASK_STAMP(3);
+#endif
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
   __syncthreads();
+  CASK_STAMP(4);
 
   switch (d.kind_g & 0xff) {
     case 1:  reduce_rows<1>(d, prod, roff, y); break;
@@ -309,6 +328,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
   double *xs = reinterpret_cast<double *>(roff + 2 * WG);     // XU*WG doubles
 
+  CASK_STAMP(0);
   const BlockDesc d = blocks[logical_block(blockIdx.x, n_blocks, remap)];
 
   if (d.kind_g & KIND_LONG) {
@@ -346,6 +366,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
     merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
   else
     merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
+  CASK_STAMP(5);
 }
 
 // --------------------------------------------- merge variant, pipelined waves

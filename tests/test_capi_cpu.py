@@ -37,6 +37,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.cask_hip_abi_version() == 1
 
 
+def test_dfe_compat_triple_is_exported():
+    """include/cask_hip_dfe.h: the reference's device function triple (GeneratedImplSupport.hpp:31-49)."""
+    text = re.sub(r"/\*.*?\*/", "", (REPO / "include" / "cask_hip_dfe.h").read_text(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cask_hip_dfe_[a-z_]+)\s*\(", text)))
+    assert declared == ["cask_hip_dfe_dram_read", "cask_hip_dfe_dram_write", "cask_hip_dfe_reset", "cask_hip_dfe_run"]
+    out = subprocess.run(["nm", "-D", "--defined-only", str(capi.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), name
+
+
 def test_code_object_is_gfx950_only():
     blob = capi.LIB_PATH.read_bytes()
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))

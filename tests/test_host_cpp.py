@@ -59,6 +59,16 @@ def test_gen_impl_from_dse_out(tmp_path):
     assert (tmp_path / "libSpmv_hip.so").exists()
 
 
+def test_gen_impl_dfe_compat_binds_the_reference_triple(tmp_path):
+    """--dfe-compat: the loader registers Spmv_<id>/_dramWrite/_dramRead wrappers (cask.py:259-283 shape)."""
+    subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dfe-compat", "--out-dir", str(tmp_path)],
+                   check=True, capture_output=True)
+    src = (tmp_path / "GeneratedImplementations.cpp").read_text()
+    assert "new GeneratedSpmvImplementation(0, Spmv_0, Spmv_0_dramWrite, Spmv_0_dramRead, 2147483647, 2, 1024, 16, false, 2)" in src
+    out = subprocess.run(["nm", "-D", str(tmp_path / "libSpmv_hip_dfe.so")], check=True, capture_output=True, text=True).stdout
+    assert "_ZN4cask7runtime24SpmvImplementationLoaderC1Ev" in out and "U cask_hip_dfe_run" in out
+
+
 @pytest.mark.gpu
 def test_integration_client_over_reference_fixtures(plain_mtx_dir):
     """ctest -R hw of the reference (CMakeLists.txt:135-139): test_spmv_<target> <matrix> for every fixture."""

@@ -211,3 +211,25 @@ def test_sweep_order_known_answers(known_answers):
     assert as_pairs[15] == ka["after_15_from_start"]
     assert as_pairs[16:18] == ka["then"]
     assert len(pts) == 18                              # every point, last included
+
+
+# ---- DFE stream format restatement (oracle/dfe_format.py vs the C decoder) -----------------
+
+@pytest.mark.parametrize("arch", [(3, 32, 5), (2, 1024, 16), (6, 256, 3)])
+def test_dfe_format_restatement_decodes_to_the_product(arch, expected_y):
+    from oracle import dfe_format
+    pipes, cache, width = arch
+    files = dict(golden_matrix_files())
+    for key in ("matrices/test_cage6", "matrices/test_tiny", "matrices/test_long_row", "matrices/test_wa",
+                "matrices/test_non_multiple", "matrices/test_large_empty", "matrices/bfwb62"):
+        m = mmio.read_matrix(files[key])
+        x = mmio.test_vector(m.m)
+        parts = dfe_format.preprocess(m.n, m.m, m.row_ptr, m.col_ind, m.values, pipes, cache, width)
+        assert len(parts) == pipes
+        xp = np.concatenate([x, np.zeros((-x.size) % cache)])
+        ys = [oracle.partition_decode_spmv(p["n"], p["n_blocks"], cache, width, False, p["colptr"],
+                                           np.frombuffer(p["records"].tobytes(), dtype=np.uint8), xp) for p in parts]
+        y = ys[0] if m.n < pipes else np.concatenate(ys)
+        oracle.assert_almost_equal(y, expected_y[key], what=f"{key} {arch}")
+        for p in parts:                                   # Spmv.cpp:76-77: records padded per block to input_width
+            assert p["records"].size % width == 0 and p["colptr"].size == p["n"] * p["n_blocks"]

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 and 5 on one GPU: CG on the G3_circuit-like SPD system and BiCG on the
+atmosmodd-like nonsymmetric system (b = A*1), reporting iterations, final residual, device
+microseconds per iteration and the algorithmic bytes/iteration of SURVEY.md 8(d):
+CG  B_it = B_spmv + 96 n ;  BiCG B_it = 2 B_spmv + 32 n + 120 n."""
+import json, sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from cask_amd import capi, synth
+
+def run(name, solver, maxiters):
+    n, rp, ci, va, src = synth.load_or_make(name)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    ones = np.ones(n)
+    b = m.spmv(ones)
+    t0 = time.perf_counter()
+    x, it, conv, us = (m.cg if solver == "cg" else m.bicg)(b, maxiters=maxiters)
+    wall = time.perf_counter() - t0
+    res = float(np.linalg.norm(b - m.spmv(x)))
+    b_spmv = synth.algorithmic_bytes(n, n, ci.size)
+    b_it = b_spmv + 96 * n if solver == "cg" else 2 * b_spmv + 152 * n
+    f_it = 2 * ci.size + 12 * n if solver == "cg" else 4 * ci.size + 20 * n
+    out = {"matrix": name, "solver": solver, "n": n, "nnz": int(ci.size), "iterations": it, "converged": conv,
+           "residual_2norm": res, "usec_per_iteration": round(us, 2), "wall_s": round(wall, 3),
+           "algorithmic_bytes_per_iteration": b_it, "gbs_algorithmic": round(b_it / us * 1e-3, 1),
+           "pct_hbm_peak": round(100 * b_it / us * 1e-3 / 8000, 1), "gflops": round(f_it / us * 1e-3, 1),
+           "design_point": m.params.as_dict(), "err_vs_ones": float(np.abs(x - ones).max())}
+    print(json.dumps(out))
+    m.close()
+
+if __name__ == "__main__":
+    run("G3_circuit", "cg", 2000)
+    run("atmosmodd", "bicg", 2000)
+    run("cant", "cg", 2000)
