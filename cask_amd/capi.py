@@ -69,9 +69,19 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    import os
+    global LIB_PATH
+    if os.environ.get("CASK_HIP_DIAGNOSTIC_LIB"):          # development only: tools/stamps.py, ablation builds
+        LIB_PATH = Path(os.environ["CASK_HIP_DIAGNOSTIC_LIB"])
     if not LIB_PATH.exists():
         raise CaskHipError(f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
                            "the engine has no CPU fallback")
+    # torch wheels bundle their own libamdhip64; whichever HIP runtime is loaded first serves the whole
+    # process.  Load torch's first, otherwise a later `import torch` finds "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(str(LIB_PATH))
     vp, i32, i64, dbl = c_void_p, c_int32, c_int64, c_double
     L.cask_hip_last_error.restype = ctypes.c_char_p

@@ -119,8 +119,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     // kernel wins everywhere; the DSE (cask_hip_tune / cask_amd.dse) refines the shape per matrix.
     out.variant = CASK_HIP_VARIANT_MERGE;
   }
-  const bool long_rows = mean >= 16.0;
-  if (out.wg_size == 0) out.wg_size = (out.variant == CASK_HIP_VARIANT_MERGE && long_rows) ? 512 : 256;
+  if (out.wg_size == 0) out.wg_size = 256;
   if (!(out.wg_size == 64 || out.wg_size == 128 || out.wg_size == 256 || out.wg_size == 512 ||
         out.wg_size == 1024))
     return fail(CASK_HIP_ERR_INVALID, "wg_size must be 64, 128, 256, 512 or 1024");
@@ -134,7 +133,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   }
   if (!is_pow2(out.lanes_per_row) || out.lanes_per_row > 64)
     return fail(CASK_HIP_ERR_INVALID, "lanes_per_row must be a power of two in 1..64");
-  if (out.items_per_thread == 0) out.items_per_thread = (out.variant == CASK_HIP_VARIANT_MERGE && long_rows) ? 4 : 8;
+  if (out.items_per_thread == 0) out.items_per_thread = 8;
   if (!(out.items_per_thread == 2 || out.items_per_thread == 4 || out.items_per_thread == 8 ||
         out.items_per_thread == 16))
     return fail(CASK_HIP_ERR_INVALID, "items_per_thread must be 2, 4, 8 or 16");
@@ -156,7 +155,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
 // most `cap` items (and at most `max_rows` rows), snapped to row boundaries;
 // rows longer than cap/2 become long-row pieces of at most `piece` nonzeros.
 // Long pieces go to `longs` when it is given (pipelined plan), else inline.
-void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long piece,
+void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long piece, int threads,
                         std::vector<BlockDesc> &blocks, std::vector<BlockDesc> *longs,
                         std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots) {
   const int *rp = m.h_rp.data();
@@ -171,8 +170,13 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
     d.n_rows = cur_rows;
     d.nnz_start = rp[cur_start];
     d.nnz_count = cur_nnz;
-    const int mean = cur_nnz / cur_rows;
-    d.kind_g = std::min(64, std::max(1, pow2_floor(std::max(1, mean / 4))));
+    // lanes per row in the reduce phase: as many as keep the phase to ONE pass over the block's rows
+    // (threads / rows), but no more than the mean row length can feed
+    const int mean = std::max(1, cur_nnz / cur_rows);
+    const int by_rows = pow2_floor(std::max(1, threads / cur_rows));
+    int by_len = 1;
+    while (by_len < mean && by_len < 64) by_len *= 2;
+    d.kind_g = std::min(64, std::max(1, std::min(by_rows, by_len)));
     blocks.push_back(d);
     cur_rows = 0;
     cur_nnz = 0;
@@ -247,7 +251,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     std::vector<BlockDesc> blocks, longs;
     std::vector<SplitRow> splits;
     int n_long = 0, n_slots = 0;
-    build_merge_blocks(m, cap, 127, 32768, blocks, &longs, splits, n_long, n_slots);
+    build_merge_blocks(m, cap, 127, 32768, 64, blocks, &longs, splits, n_long, n_slots);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
     pl.n_blocks = (int)blocks.size();
@@ -275,8 +279,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     std::vector<BlockDesc> blocks;
     std::vector<SplitRow> splits;
     int n_long = 0, n_slots = 0;
-    build_merge_blocks(m, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, blocks, nullptr, splits, n_long,
-                       n_slots);
+    build_merge_blocks(m, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, prm.wg_size, blocks, nullptr, splits,
+                       n_long, n_slots);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
     pl.grid = (int)blocks.size();
