@@ -894,6 +894,7 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   const int check_every = 16;
   int h_flags[2] = {0, 0};
   int launched = 0;
+  double clean_us = 0.0;
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
     rc = launch_spmv(*m, p.p, Ap.p, s);                                                 // :206
@@ -906,9 +907,14 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
     hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, rsnew, rsold, r.p, p.p, (const int *)done);  // :229
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipEventRecord(e1, s));
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       if (h_flags[0]) break;
+      // a checkpoint reached without convergence: every pass so far did real work
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / launched;
     }
   }
   HIP_TRY(hipEventRecord(e1, s));
@@ -920,7 +926,9 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0];
-  if (usec_per_iteration) *usec_per_iteration = launched ? ms * 1e3 / launched : 0.0;
+  // passes launched after the converged one are no-ops: prefer the rate measured up to the last
+  // checkpoint that had not converged yet
+  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
   return CASK_HIP_OK;
 }
 
@@ -964,6 +972,7 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   const int check_every = 16;
   int h_flags[2] = {0, 0};
   int launched = 0;
+  double clean_us = 0.0;
   for (int i = 0; i < maxiters; i++) {
     double *rho_old = rho[i & 1], *rho_new = rho[(i + 1) & 1];
     rc = launch_spmv(*m, p.p, q.p, s);
@@ -981,9 +990,14 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
     hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, rho_new, rho_old, r.p, rt.p, p.p, pt.p, (const int *)done);
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipEventRecord(e1, s));
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       if (h_flags[0]) break;
+      // a checkpoint reached without convergence: every pass so far did real work
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / launched;
     }
   }
   HIP_TRY(hipEventRecord(e1, s));
@@ -995,7 +1009,9 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0];
-  if (usec_per_iteration) *usec_per_iteration = launched ? ms * 1e3 / launched : 0.0;
+  // passes launched after the converged one are no-ops: prefer the rate measured up to the last
+  // checkpoint that had not converged yet
+  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
   return CASK_HIP_OK;
 }
 
