@@ -27,6 +27,21 @@ __device__ __forceinline__ double wg_sum(double v, double *red) {
   return s;   // valid in thread 0
 }
 
+// Sum of a (<= 1024-entry, L2-resident) partials array, computed redundantly by every workgroup in the
+// same order => every workgroup sees the bit-identical value.  This replaces a separate single-workgroup
+// "final" kernel (4.3 us + a launch boundary per dot in the first version).  Result in all threads.
+__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int n, double *red) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+  acc = group_sum<64>(acc);
+  __syncthreads();                                  // red may still be read by a previous use
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+  return s;
+}
+
 __global__ void k_dot_partial(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                               double *__restrict__ partials, const int *done) {
   __shared__ double red[16];
@@ -103,15 +118,16 @@ __global__ void k_axpby(int64_t n, double alpha, const double *__restrict__ x, d
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = alpha * x[n - 1] + b * y[n - 1];
 }
 
-// CG: alpha = rsold / pAp ; x += alpha p ; r -= alpha Ap ; partials of r.r
-// (SparseLinearSolvers.hpp:208-218 in one pass over the vectors).
-__global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *pAp,
+// CG: alpha = rsold / (p.Ap) ; x += alpha p ; r -= alpha Ap ; partials of r.r
+// (SparseLinearSolvers.hpp:208-218 in one pass over the vectors).  p.Ap arrives as the partials of
+// k_dot_partial; the r.r partials go to a second array.
+__global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *__restrict__ part_pAp, int n_part,
                                const double *__restrict__ p, const double *__restrict__ Ap,
                                double *__restrict__ x, double *__restrict__ r,
-                               double *__restrict__ partials, const int *done) {
+                               double *__restrict__ part_rr, const int *done) {
   __shared__ double red[16];
   if (done && *done) return;
-  const double alpha = *rsold / *pAp;
+  const double alpha = *rsold / sum_partials(part_pAp, n_part, red);
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     x[i] = fma(alpha, p[i], x[i]);
@@ -119,29 +135,40 @@ __global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *pAp
     r[i] = rn;
     acc = fma(rn, rn, acc);
   }
+  __syncthreads();
   const double s = wg_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = s;
 }
 
-// CG: p = r + (rsnew/rsold) p   (SparseLinearSolvers.hpp:229)
-__global__ void k_cg_update_p(int64_t n, const double *rsnew, const double *rsold,
-                              const double *__restrict__ r, double *__restrict__ p, const int *done) {
-  if (done && *done) return;
-  const double beta = *rsnew / *rsold;
+// CG: rsnew = r.r (from its partials); converged if rsnew <= tol^2 (then nothing else happens:
+// SparseLinearSolvers.hpp:220-226), else iterations = iter and p = r + (rsnew/rsold) p (:229-231).
+// Every workgroup takes the same decision from the same sum; workgroup 0 records it.
+__global__ void k_cg_update_p(int64_t n, const double *__restrict__ part_rr, int n_part, const double *rsold,
+                              double *rsnew_out, double tol2, int iter, const double *__restrict__ r,
+                              double *__restrict__ p, int *done, int *iters) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double rsnew = sum_partials(part_rr, n_part, red);
+  if (rsnew <= tol2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *done = 1; }
+    return;
+  }
+  const double beta = rsnew / *rsold;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     p[i] = fma(beta, p[i], r[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *iters = iter; }
 }
 
 // BiCG: alpha = rho / (pt.q); x += alpha p; r -= alpha q; rt -= alpha qt;
-// partials of r.r (-> part_rr) and rt.r (-> part_rho).
-__global__ void k_bicg_update(int64_t n, const double *rho, const double *ptq,
+// partials of r.r (-> part_rr) and rt.r (-> part_rho).  pt.q arrives as partials.
+__global__ void k_bicg_update(int64_t n, const double *rho, const double *__restrict__ part_ptq, int n_part,
                               const double *__restrict__ p, const double *__restrict__ q,
                               const double *__restrict__ qt, double *__restrict__ x,
                               double *__restrict__ r, double *__restrict__ rt,
                               double *__restrict__ part_rr, double *__restrict__ part_rho, const int *done) {
   __shared__ double red[16];
   if (done && *done) return;
-  const double alpha = *rho / *ptq;
+  const double alpha = *rho / sum_partials(part_ptq, n_part, red);
   double a_rr = 0.0, a_rho = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     x[i] = fma(alpha, p[i], x[i]);
@@ -152,22 +179,32 @@ __global__ void k_bicg_update(int64_t n, const double *rho, const double *ptq,
     a_rr = fma(rn, rn, a_rr);
     a_rho = fma(rtn, rn, a_rho);
   }
+  __syncthreads();
   const double s1 = wg_sum(a_rr, red);
   __syncthreads();
   const double s2 = wg_sum(a_rho, red);
   if (threadIdx.x == 0) { part_rr[blockIdx.x] = s1; part_rho[blockIdx.x] = s2; }
 }
 
-// BiCG: beta = rho_new/rho; p = r + beta p; pt = rt + beta pt
-__global__ void k_bicg_update_p(int64_t n, const double *rho_new, const double *rho,
+// BiCG: converged if r.r <= tol^2; else beta = rho_new/rho; p = r + beta p; pt = rt + beta pt
+__global__ void k_bicg_update_p(int64_t n, const double *__restrict__ part_rr, const double *__restrict__ part_rho,
+                                int n_part, const double *rho, double *rho_out, double tol2, int iter,
                                 const double *__restrict__ r, const double *__restrict__ rt,
-                                double *__restrict__ p, double *__restrict__ pt, const int *done) {
-  if (done && *done) return;
-  const double beta = *rho_new / *rho;
+                                double *__restrict__ p, double *__restrict__ pt, int *done, int *iters) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double rr = sum_partials(part_rr, n_part, red);
+  if (rr <= tol2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *done = 1;
+    return;
+  }
+  const double rho_new = sum_partials(part_rho, n_part, red);
+  const double beta = rho_new / *rho;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     p[i] = fma(beta, p[i], r[i]);
     pt[i] = fma(beta, pt[i], rt[i]);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *rho_out = rho_new; *iters = iter; }
 }
 
 }  // namespace caskhip

@@ -867,14 +867,14 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   HIP_TRY(hipSetDevice(m->device));
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;
-  DevBuf<double> dx, db, r, p, Ap, partials, scal;
+  DevBuf<double> dx, db, r, p, Ap, partials, partials_rr, scal;
   DevBuf<int> flags;
   HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
   HIP_TRY(r.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
-  HIP_TRY(partials.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(partials.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(partials_rr.alloc(BLAS_MAX_PARTIALS));
+  HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   double *rs[2] = {scal.p, scal.p + 1};
-  double *pAp = scal.p + 2;
   int *done = flags.p, *iters = flags.p + 1;
   const int g = blas_grid(n);
   const dim3 bg(g), bw(BLAS_WG);
@@ -900,11 +900,10 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
     rc = launch_spmv(*m, p.p, Ap.p, s);                                                 // :206
     if (rc) return rc;
     hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
-    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, pAp, 0, 0.0, done, (int *)nullptr, 0);
-    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp, p.p, Ap.p, dx.p, r.p, partials.p,
+    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, partials.p, g, p.p, Ap.p, dx.p, r.p, partials_rr.p,
                        (const int *)done);                                              // :208-218
-    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rsnew, 1, tol * tol, done, iters, i);  // :220-231
-    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, rsnew, rsold, r.p, p.p, (const int *)done);  // :229
+    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rr.p, g, rsold, rsnew, tol * tol, i, r.p, p.p, done,
+                       iters);                                                          // :220-231
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
@@ -942,16 +941,16 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   cask_hip_matrix &mt = *m->transpose;
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;
-  DevBuf<double> dx, db, r, rt, p, pt, q, qt, part_a, part_b, scal;
+  DevBuf<double> dx, db, r, rt, p, pt, q, qt, part_a, part_b, part_c, scal;
   DevBuf<int> flags;
   HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
   HIP_TRY(r.alloc(n)); HIP_TRY(rt.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(pt.alloc(n));
   HIP_TRY(q.alloc(n)); HIP_TRY(qt.alloc(n));
   HIP_TRY(part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_b.alloc(BLAS_MAX_PARTIALS));
+  HIP_TRY(part_c.alloc(BLAS_MAX_PARTIALS));
   HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   double *rho[2] = {scal.p, scal.p + 1};
-  double *ptq = scal.p + 2, *rr = scal.p + 3;
   int *done = flags.p, *iters = flags.p + 1;
   const int g = blas_grid(n);
   const dim3 bg(g), bw(BLAS_WG);
@@ -979,15 +978,11 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
     if (rc) return rc;
     rc = launch_spmv(mt, pt.p, qt.p, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_a.p, (const int *)done);
-    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, ptq, 0, 0.0, done, (int *)nullptr, 0);
-    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, ptq, p.p, q.p, qt.p, dx.p, r.p, rt.p, part_a.p,
-                       part_b.p, (const int *)done);
-    // rho_new first (no test), then r.r with the convergence test, so that a
-    // converged pass leaves rho_new written but p/pt untouched.
-    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_b.p, rho_new, 0, 0.0, done, (int *)nullptr, 0);
-    hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, rr, 1, tol * tol, done, iters, i);
-    hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, rho_new, rho_old, r.p, rt.p, p.p, pt.p, (const int *)done);
+    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_c.p, (const int *)done);
+    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, part_c.p, g, p.p, q.p, qt.p, dx.p, r.p, rt.p,
+                       part_a.p, part_b.p, (const int *)done);
+    hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, part_a.p, part_b.p, g, rho_old, rho_new, tol * tol, i, r.p,
+                       rt.p, p.p, pt.p, done, iters);
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
