@@ -226,3 +226,45 @@ def test_tune_sweeps_in_reference_order_and_keeps_the_best():
     assert m.params.as_dict() == pts[best]["params"]
     oracle.assert_almost_equal(m.spmv(x), want, what="after tune")
     m.close()
+
+
+def _random_csr(rng, n_rows, n_cols, profile):
+    """Seeded random CSR with a chosen row-length profile (sorted, duplicate-free rows)."""
+    if profile == "uniform":
+        lens = rng.integers(0, 12, n_rows)
+    elif profile == "powerlaw":
+        lens = np.minimum(rng.zipf(1.8, n_rows), n_cols)
+    elif profile == "banded":
+        lens = np.full(n_rows, min(24, n_cols))
+    elif profile == "mostly_empty":
+        lens = np.where(rng.random(n_rows) < 0.05, rng.integers(1, 40, n_rows), 0)
+    else:   # "dense_rows"
+        lens = np.full(n_rows, min(n_cols, 200))
+    lens = np.minimum(lens, n_cols).astype(np.int64)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = []
+    for r, l in enumerate(lens):
+        if profile == "banded":
+            lo = max(0, min(n_cols - l, r * n_cols // max(n_rows, 1) - l // 2))
+            cols.append(np.arange(lo, lo + l))
+        else:
+            cols.append(np.sort(rng.choice(n_cols, size=l, replace=False)))
+    ci = (np.concatenate(cols) if cols else np.zeros(0)).astype(np.int32)
+    va = rng.standard_normal(ci.size)
+    return rp, ci, va
+
+
+@pytest.mark.parametrize("profile", ["uniform", "powerlaw", "banded", "mostly_empty", "dense_rows"])
+def test_random_matrices_all_design_points(profile):
+    """Property test: for seeded random shapes and row-length profiles every design point agrees with the
+    oracle under the reference tolerance, and odd/even nnz, odd block starts and ragged tails are hit."""
+    rng = np.random.default_rng({"uniform": 1, "powerlaw": 2, "banded": 3, "mostly_empty": 4, "dense_rows": 5}[profile])
+    for trial in range(6):
+        n_rows = int(rng.integers(1, 3000))
+        n_cols = int(rng.integers(1, 3000))
+        rp, ci, va = _random_csr(rng, n_rows, n_cols, profile)
+        x = rng.uniform(-2, 2, n_cols)
+        want = oracle.csr_spmv(rp, ci, va, x)
+        for dp in DESIGN_POINTS:
+            got = run_host(n_rows, n_cols, rp, ci, va, x, dp)
+            oracle.assert_almost_equal(got, want, what=f"{profile} trial {trial} {n_rows}x{n_cols} nnz={ci.size} {dp}")
