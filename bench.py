@@ -120,6 +120,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # CASK_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all_gather, all_reduce) with a single
+    # rank: a dry run of the N>1 plumbing on a 1-GPU box.
+    use_dist = world > 1 or bool(os.environ.get("CASK_BENCH_FORCE_DIST"))
     os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
     os.environ.setdefault("OMP_PROC_BIND", "true")
 
@@ -131,7 +134,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload -----------------------------------------------------------
@@ -139,7 +142,7 @@ def main():
         n_local, n_global, rp, ci, va = synth.cant_like_shard(rank, world)
         source = "synthetic"
     else:
-        if world > 1:
+        if use_dist:
             raise SystemExit("multi-GPU bench is defined for the cant workload")
         n_local, rp, ci, va, source = synth.load_or_make(args.workload)
         n_global = n_local
@@ -157,15 +160,15 @@ def main():
         mats.append(capi.CsrMatrix.from_device(n_local, n_global, rp_t, ci_t, va_t, forced))
     x_host = np.arange(n_global, dtype=np.float64) * 0.25 / n_global        # test_spmv.cpp operand, scaled
     x_local = torch.from_numpy(x_host[rank * n_local:(rank + 1) * n_local].copy()).to(dev)
-    x_full = torch.from_numpy(x_host).to(dev) if world == 1 else torch.zeros(n_global, dtype=torch.float64, device=dev)
+    x_full = torch.from_numpy(x_host).to(dev) if not use_dist else torch.zeros(n_global, dtype=torch.float64, device=dev)
     y = torch.zeros(n_local, dtype=torch.float64, device=dev)
 
     # ---- measured DSE (cold: on the rotating copies), best point left active --------
     tune_info = None
     if not args.no_tune and args.variant is None:
         from cask_amd import dse
-        rows, best, took = dse.explore(mats, x_full if world == 1 else torch.from_numpy(x_host).to(dev), y)
-        if world > 1:
+        rows, best, took = dse.explore(mats, x_full if not use_dist else torch.from_numpy(x_host).to(dev), y)
+        if use_dist:
             # every rank must run the same design point: take rank 0's winner
             obj = [mats[0].params.as_dict()]
             dist.broadcast_object_list(obj, src=0)
@@ -177,7 +180,7 @@ def main():
     info = mats[0].info
 
     def step(i):
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(x_full, x_local)
         mats[i % copies].spmv_device(x_full, y)
 
@@ -186,7 +189,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
-    launch_mode = args.launch if world == 1 else "eager"
+    launch_mode = args.launch if not use_dist else "eager"
     graph = None
     if launch_mode == "graph":
         try:
@@ -209,7 +212,7 @@ def main():
 
     # ---- timed region: exactly K steps -------------------------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -221,11 +224,11 @@ def main():
             step(i)
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -259,7 +262,7 @@ def main():
             "config": {"workload": f"{args.workload}-like CSR SpMV, {n_local} rows x {n_global} cols per GPU, "
                                    f"{nnz_local} nnz per GPU, x_i = 0.25 i / n",
                        "rows": n_local * world, "nnz": int(nnz_total), "parallelism": f"row-blocks x{world}",
-                       "exchange": "none" if world == 1 else "RCCL all_gather(x) per step",
+                       "exchange": "none" if not use_dist else "RCCL all_gather(x) per step",
                        "matrix_copies_rotated": copies, "launch": launch_mode, "design_point": design,
                        "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info},
             "hbm_gbs_algorithmic": round(achieved * world, 1),
@@ -278,7 +281,7 @@ def main():
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
