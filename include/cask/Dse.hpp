@@ -21,24 +21,31 @@
 namespace cask {
 namespace dse {
 
+// The matrices a DSE run covers: an ordered list of MatrixMarket paths.
 class Benchmark {
-  std::vector<std::string> paths;
-
  public:
+  void add_matrix_path(std::string path) { files_.push_back(std::move(path)); }
+  int get_benchmark_size() const { return static_cast<int>(files_.size()); }
+  bool empty() const { return files_.empty(); }
+
   std::string get_matrix_path(int id) const {
-    if (id >= 0 && id < static_cast<int>(paths.size())) return paths[id];
-    std::stringstream ss;
-    ss << "Benchmark::Index out of range " << id;
-    throw std::invalid_argument(ss.str());
+    if (id < 0 || id >= get_benchmark_size())
+      throw std::invalid_argument("Benchmark::Index out of range " + std::to_string(id));
+    return files_[static_cast<std::size_t>(id)];
   }
-  void add_matrix_path(std::string path) { paths.push_back(path); }
-  int get_benchmark_size() const { return static_cast<int>(paths.size()); }
+
+  void describe(std::ostream &out) const {
+    out << "Benchmark(" << std::endl;
+    for (const std::string &f : files_) out << "  " << f << std::endl;
+    out << ")" << std::endl;
+  }
+
+ private:
+  std::vector<std::string> files_;
 };
 
 inline std::ostream &operator<<(std::ostream &s, Benchmark &b) {
-  s << "Benchmark(" << std::endl;
-  for (int i = 0; i < b.get_benchmark_size(); i++) s << "  " << b.get_matrix_path(i) << std::endl;
-  s << ")" << std::endl;
+  b.describe(s);
   return s;
 }
 

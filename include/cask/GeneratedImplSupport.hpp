@@ -17,7 +17,9 @@
 
 #include <climits>
 #include <cstdint>
+#include <cstddef>
 #include <functional>
+#include <string>
 #include <vector>
 
 namespace cask {
@@ -51,11 +53,25 @@ class GeneratedSpmvImplementation {
         dram_reduction_enabled(_dram_reduction_enabled), num_controllers(_num_controllers), Spmv(_run),
         write(_write), read(_read) {}
 
+  // two implementations are the same architecture when every parameter but the id agrees
   bool operator==(const GeneratedSpmvImplementation &o) const {
-    return max_rows == o.max_rows && num_pipes == o.num_pipes && cache_size == o.cache_size &&
-           input_width == o.input_width && dram_reduction_enabled == o.dram_reduction_enabled &&
-           num_controllers == o.num_controllers;
+    const int mine[] = {max_rows, num_pipes, cache_size, input_width, dram_reduction_enabled, num_controllers};
+    const int theirs[] = {o.max_rows, o.num_pipes, o.cache_size, o.input_width, o.dram_reduction_enabled,
+                          o.num_controllers};
+    for (int k = 0; k < 6; k++)
+      if (mine[k] != theirs[k]) return false;
+    return true;
   }
+
+  // "id=0 max_rows=... pipes=... cache=... width=... controllers=..." for logs
+  std::string describe() const {
+    return "id=" + std::to_string(id) + " max_rows=" + std::to_string(max_rows) + " pipes=" + std::to_string(num_pipes) +
+           " cache=" + std::to_string(cache_size) + " width=" + std::to_string(input_width) +
+           " controllers=" + std::to_string(num_controllers);
+  }
+
+  // whether a matrix with `rows` rows fits (the only capability test the reference applies, Spmv.cpp:201-207)
+  bool supportsRows(int rows) const { return max_rows >= rows; }
 };
 
 class SpmvImplementationLoader {
@@ -64,15 +80,22 @@ class SpmvImplementationLoader {
  public:
   SpmvImplementationLoader();   // defined in the generated library
 
-  // smallest registered max_rows that still holds `maxRows` rows; nullptr if none
+  // The registered implementation with the smallest max_rows that still holds `maxRows` rows;
+  // nullptr when none does (a generated library should always register a catch-all).
   GeneratedSpmvImplementation *architectureWithParams(int maxRows) {
-    GeneratedSpmvImplementation *best = nullptr;
-    for (GeneratedSpmvImplementation *a : impls)
-      if (a->max_rows >= maxRows && (!best || a->max_rows < best->max_rows)) best = a;
-    return best;
+    GeneratedSpmvImplementation *tightest = nullptr;
+    for (std::size_t k = 0; k < impls.size(); k++) {
+      GeneratedSpmvImplementation *candidate = impls[k];
+      if (!candidate->supportsRows(maxRows)) continue;
+      if (tightest == nullptr || candidate->max_rows < tightest->max_rows) tightest = candidate;
+    }
+    return tightest;
   }
 
-  GeneratedSpmvImplementation *architectureWithId(int id) { return impls.at(id); }
+  GeneratedSpmvImplementation *architectureWithId(int id) { return impls.at(static_cast<std::size_t>(id)); }
+
+  // number of registered implementations (new; the reference exposes none)
+  int size() const { return static_cast<int>(impls.size()); }
 };
 
 }  // namespace runtime

@@ -1,165 +1,214 @@
-// Host utilities of the CASK surface: Timer, alignment helpers, the "Result  k=v,"
-// log lines and the design-parameter sweep (Parameter / ChainedParameterRange).
-// Same names and behaviour as the reference's src/runtime/Utils.hpp (:15-202);
-// the sweep order -- first parameter fastest -- is pinned by the reference's
-// test/TestUtils.cpp:12-49 and by tests/cpp/test_host.cpp here.  No Boost.
+// Host utilities of the CASK surface.  API-compatible with the reference's
+// src/runtime/Utils.hpp (Timer :15-50, align/size_bytes/ceilDivide :62-86,
+// logResult :88-112, Parameter :114-155, ChainedParameterRange :158-202), new
+// implementation, no Boost.  The behaviours clients and log scrapers depend on:
+//   * logResult prints "Result  <key>=" (two spaces) then every value followed by
+//     a comma -- for the variadic form in REVERSE argument order, because the
+//     reference's recursion prints the tail before the head;
+//   * ChainedParameterRange is an odometer whose FIRST parameter turns fastest
+//     (pinned by the reference's test/TestUtils.cpp:12-49 and tests/cpp/test_host.cpp).
 #ifndef CASK_UTILS_HPP
 #define CASK_UTILS_HPP
 
 #include <chrono>
+#include <cstddef>
 #include <iostream>
-#include <map>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 namespace cask {
 namespace utils {
 
-// Named stopwatches: tic(name) ... toc(name) records one duration per name.
+// ---------------------------------------------------------------- stopwatches
+// tic(name) starts (or restarts) a named stopwatch, toc(name) stops it and returns
+// the elapsed seconds; get(name) returns the last completed measurement.
 class Timer {
-  using clock_type = std::chrono::high_resolution_clock;
-  using duration_type = std::chrono::duration<double>;
-  std::map<std::string, clock_type::time_point> running;
-  std::map<std::string, duration_type> finished;
-
  public:
-  void tic(std::string name) { running[name] = clock_type::now(); }
+  using seconds = std::chrono::duration<double>;
 
-  duration_type toc(std::string name) {
-    auto it = running.find(name);
-    if (it == running.end()) throw std::invalid_argument("No previous tic() with " + name);
-    finished[name] = clock_type::now() - it->second;
-    running.erase(it);
-    return finished[name];
+  void tic(std::string name) { started_[name] = now(); }
+
+  seconds toc(std::string name) {
+    const auto hit = started_.find(name);
+    if (hit == started_.end()) throw std::invalid_argument("No previous tic() with " + name);
+    const seconds elapsed = now() - hit->second;
+    started_.erase(hit);
+    done_[name] = elapsed;
+    return elapsed;
   }
 
-  duration_type get(std::string name) {
-    auto it = finished.find(name);
-    if (it == finished.end()) throw std::invalid_argument("No previous tic()/toc() with " + name);
-    return it->second;
+  seconds get(std::string name) {
+    const auto hit = done_.find(name);
+    if (hit == done_.end()) throw std::invalid_argument("No previous tic()/toc() with " + name);
+    return hit->second;
   }
+
+ private:
+  using clock = std::chrono::steady_clock;
+  static clock::time_point now() { return clock::now(); }
+  std::unordered_map<std::string, clock::time_point> started_;
+  std::unordered_map<std::string, seconds> done_;
 };
 
-template <typename T>
-void print(T v, std::string message = "") {
-  std::cout << message;
-  for (const auto &e : v) std::cout << e << " ";
-  std::cout << std::endl;
+// ---------------------------------------------------------------- small helpers
+template <typename Container>
+void print(Container c, std::string message = "") {
+  std::ostringstream line;
+  line << message;
+  for (const auto &item : c) line << item << " ";
+  std::cout << line.str() << std::endl;
 }
 
-// Pad v with T{} until its byte size is a multiple of widthInBytes (at most one width of padding).
+// Grow v with default-constructed elements until its size in bytes is a multiple of
+// widthInBytes; never adds more than one width's worth of elements.
 template <typename T>
 void align(std::vector<T> &v, int widthInBytes) {
-  const size_t per = static_cast<size_t>(widthInBytes) / sizeof(T);
-  if (per == 0) return;
-  const size_t rem = (v.size() * sizeof(T)) % static_cast<size_t>(widthInBytes);
-  if (rem == 0) return;
-  size_t add = (static_cast<size_t>(widthInBytes) - rem + sizeof(T) - 1) / sizeof(T);
-  if (add > per) add = per;
-  v.resize(v.size() + add, T{});
+  const std::size_t width = static_cast<std::size_t>(widthInBytes);
+  const std::size_t most = width / sizeof(T);
+  std::size_t added = 0;
+  while (added < most && (v.size() * sizeof(T)) % width != 0) {
+    v.emplace_back();
+    ++added;
+  }
 }
 
-inline int align(int bytes, int to) { return bytes % to == 0 ? bytes : (bytes / to + 1) * to; }
+// smallest multiple of `to` that is >= bytes
+inline int align(int bytes, int to) {
+  const int over = bytes % to;
+  return over ? bytes + (to - over) : bytes;
+}
 
 template <typename T>
 long size_bytes(const std::vector<T> &v) {
-  return static_cast<long>(sizeof(T) * v.size());
+  return static_cast<long>(v.size() * sizeof(T));
 }
 
 inline int ceilDivide(int a, int b) {
   if (a < 0 || b < 0) throw std::invalid_argument("ceilDivide: arguments must be positive");
-  return a / b + (a % b != 0);
+  return (a + b - 1) / b;
 }
 
-// "Result  <key>=<v>,<v>,..." -- two spaces after "Result", a comma after every value, and for the
-// variadic form the values in REVERSE argument order followed by the first (the reference's
-// recursion, Utils.hpp:88-112, prints the tail before the head).
-inline void logResultR(std::string key) { std::cout << "Result " << " " << key << "="; }
+// ---------------------------------------------------------------- "Result  k=v," lines
+namespace detail {
+inline void emitResult(const std::string &key, const std::vector<std::string> &values, bool newline) {
+  std::ostringstream line;
+  line << "Result " << " " << key << "=";
+  for (const std::string &v : values) line << v << ",";
+  std::cout << line.str();
+  if (newline) std::cout << std::endl;
+}
 
-template <typename Arg, typename... Args>
-void logResultR(std::string key, Arg a, Args... rest) {
-  logResultR(key, rest...);
-  std::cout << a << ",";
+template <typename V>
+std::string shown(const V &v) {
+  std::ostringstream s;
+  s << v;
+  return s.str();
+}
+
+inline void collectReversed(std::vector<std::string> &) {}
+template <typename Head, typename... Tail>
+void collectReversed(std::vector<std::string> &out, const Head &h, const Tail &... t) {
+  collectReversed(out, t...);      // tail first: the reference prints its arguments back to front
+  out.push_back(shown(h));
+}
+}  // namespace detail
+
+// header plus values, no line end (the building block the reference exposes as logResultR)
+template <typename... Args>
+void logResultR(std::string key, Args... values) {
+  std::vector<std::string> shownValues;
+  detail::collectReversed(shownValues, values...);
+  detail::emitResult(key, shownValues, false);
 }
 
 template <typename U>
-void logResult(std::string key, std::vector<U> vals) {
-  logResultR(key);
-  for (const auto &v : vals) std::cout << v << ",";
-  std::cout << std::endl;
+void logResult(std::string key, std::vector<U> values) {
+  std::vector<std::string> shownValues;
+  for (const U &v : values) shownValues.push_back(detail::shown(v));
+  detail::emitResult(key, shownValues, true);
 }
 
-template <typename Arg, typename... Args>
-void logResult(std::string key, Arg a, Args... rest) {
-  logResultR(key, rest...);
-  std::cout << a << ",";
-  std::cout << std::endl;
+template <typename First, typename... Rest>
+void logResult(std::string key, First first, Rest... rest) {
+  std::vector<std::string> shownValues;
+  detail::collectReversed(shownValues, first, rest...);
+  detail::emitResult(key, shownValues, true);
 }
 
-// One design parameter: a value inside [start, end] stepping by `step`.
+// ---------------------------------------------------------------- design-parameter sweep
+// One integer-like design parameter: `value` walks start, start+step, ... , end.
 template <typename T = int>
 class Parameter {
-  Parameter(std::string n, T s, T e, T st, T v) : start(s), end(e), step(st), value(v), name(n) {}
-
  public:
   T start, end, step;
   T value;
   std::string name;
 
-  Parameter(std::string n, T s, T e, T st) : Parameter(n, s, e, st, s) {}
-  Parameter(std::string n, T single) : Parameter(n, single, single, 1, single) {}
+  Parameter(std::string name_, T start_, T end_, T step_) : start(start_), end(end_), step(step_), value(start_), name(name_) {}
+  Parameter(std::string name_, T only) : start(only), end(only), step(1), value(only), name(name_) {}
 
-  Parameter first() { return Parameter(name, start, end, step, start); }
-  Parameter last() { return Parameter(name, start, end, step, end); }
+  Parameter first() { return at(start); }
+  Parameter last() { return at(end); }
+  bool hasNext() { return !(value == end); }
   Parameter next() {
     if (value + step > end) throw std::invalid_argument("Invalid call to next() - no more elements");
-    return Parameter(name, start, end, step, value + step);
+    return at(value + step);
   }
-  bool hasNext() { return value != end; }
+
+ private:
+  Parameter at(T v) const {
+    Parameter copy(*this);
+    copy.value = v;
+    return copy;
+  }
 };
 
 template <typename T>
 inline std::ostream &operator<<(std::ostream &s, const Parameter<T> &p) {
-  s << "Parameter{" << p.start << "," << p.end << "," << p.step << "}";
-  return s;
+  return s << "Parameter{" << p.start << "," << p.end << "," << p.step << "}";
 }
 
-// Odometer over several parameters; the FIRST one turns fastest.
+// Cross product of several parameters visited like an odometer: the first parameter is the
+// least significant digit.
 template <typename T = int>
 class ChainedParameterRange {
-  std::vector<Parameter<T>> range;
-
  public:
-  ChainedParameterRange(std::vector<Parameter<T>> r) : range(r) {}
-  ChainedParameterRange(std::initializer_list<Parameter<T>> r) : range(r) {}
+  ChainedParameterRange(std::vector<Parameter<T>> params) : digits_(std::move(params)) {}
+  ChainedParameterRange(std::initializer_list<Parameter<T>> params) : digits_(params) {}
 
   void start() {
-    for (auto &p : range) p = p.first();
+    for (Parameter<T> &d : digits_) d = d.first();
   }
 
   bool hasNext() {
-    for (auto &p : range)
-      if (p.hasNext()) return true;
+    for (Parameter<T> &d : digits_)
+      if (d.hasNext()) return true;
     return false;
   }
 
   void next() {
-    size_t i = 0;
-    while (i < range.size() && !range[i].hasNext()) {
-      range[i] = range[i].first();
-      i++;
+    for (Parameter<T> &d : digits_) {
+      if (d.hasNext()) {
+        d = d.next();
+        return;
+      }
+      d = d.first();                 // this digit wraps, carry into the next one
     }
-    if (i == range.size()) throw std::invalid_argument("No next element available");
-    range[i] = range[i].next();
+    throw std::invalid_argument("No next element available");
   }
 
   Parameter<T> getParam(std::string name) {
-    for (auto &p : range)
-      if (p.name == name) return p;
+    for (Parameter<T> &d : digits_)
+      if (d.name == name) return d;
     throw std::invalid_argument("Param not found " + name);
   }
+
+ private:
+  std::vector<Parameter<T>> digits_;
 };
 
 }  // namespace utils
