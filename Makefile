@@ -2,7 +2,7 @@
 HIPCC      ?= /opt/rocm/bin/hipcc
 CXX        ?= g++
 ARCH       ?= gfx950
-HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Icask_amd/csrc -Wall -Wno-unused-function
+HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -pthread -Iinclude -Icask_amd/csrc -Wall -Wno-unused-function
 LIBDIR     := cask_amd/lib
 
 GENDIR     := $(LIBDIR)/lib-generated

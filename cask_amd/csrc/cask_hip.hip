@@ -10,6 +10,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "blas1_kernels.hpp"
@@ -80,7 +81,9 @@ struct Plan {
   int n_blocks = 0, n_long_blocks = 0;
   DevBuf<SplitRow> split_rows;
   DevBuf<double> partials;
-  DevBuf<unsigned short> ci16;     // MERGE with an x tile: col_ind - cmin per in-tile block (2 B/nnz)
+  DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz)
+  DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
+  int maxch = 0;
   int n_long_rows = 0, n_split_rows = 0;
   // VECTOR
   DevBuf<int2v> xspan;
@@ -97,6 +100,7 @@ struct cask_hip_matrix {
   DevBuf<int> own_rp, own_ci;
   DevBuf<double> own_val;
   std::vector<int> h_rp;           // row_ptr kept on the host for (re)planning
+  std::vector<int> h_ci;           // col_ind on the host (filled on first use) for the x-tile planner
   int max_row = 0, empty_rows = 0;
   cask_hip_params requested{};
   Plan plan;
@@ -210,6 +214,73 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
   close(m.n_rows);
 }
 
+// x tile as a set of column ranges: for every block collect the distinct columns it references, join
+// columns closer than GAP into ranges, cut the ranges into 64-column chunks.  A block whose chunks
+// fit `max_chunks` is "tiled": its nonzeros get 16-bit LDS slot indices (chunk*64 + offset) and its
+// chunk start columns go to chunk_starts.  d.cwidth = slots used (0 = not tiled).
+int ensure_host_col_ind(cask_hip_matrix &m) {
+  if (m.h_ci.size() == (size_t)m.nnz) return CASK_HIP_OK;
+  m.h_ci.resize((size_t)m.nnz);
+  if (m.nnz) HIP_TRY(hipMemcpy(m.h_ci.data(), m.d_ci, (size_t)m.nnz * sizeof(int), hipMemcpyDeviceToHost));
+  return CASK_HIP_OK;
+}
+
+void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks, int max_chunks,
+                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16) {
+  constexpr int GAP = 32;
+  const int *ci = m.h_ci.data();
+  ci16.assign((size_t)m.nnz + 8, 0);
+  chunk_starts.assign(blocks.size(), {});
+  auto work = [&](size_t b0, size_t b1) {
+    std::vector<int> uniq, starts;
+    for (size_t b = b0; b < b1; b++) {
+      BlockDesc &d = blocks[b];
+      d.cwidth = 0;
+      if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
+      const int k0 = d.nnz_start, k1 = d.nnz_start + d.nnz_count;
+      uniq.assign(ci + k0, ci + k1);
+      std::sort(uniq.begin(), uniq.end());
+      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+      starts.clear();
+      bool fits = true;
+      size_t i = 0;
+      while (i < uniq.size() && fits) {
+        size_t j = i;
+        while (j + 1 < uniq.size() && uniq[j + 1] - uniq[j] <= GAP) j++;
+        for (int c = uniq[i]; c <= uniq[j]; c += 64) {
+          if ((int)starts.size() == max_chunks) { fits = false; break; }
+          starts.push_back(c);
+        }
+        i = j + 1;
+      }
+      if (!fits) continue;
+      d.cmin = uniq.front();
+      d.cwidth = (int)starts.size() * 64;
+      bool contiguous = true;
+      for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
+      if (contiguous) d.kind_g |= KIND_CONTIG;
+      for (int k = k0; k < k1; k++) {
+        const int c = ci[k];
+        const int idx = (int)(std::upper_bound(starts.begin(), starts.end(), c) - starts.begin()) - 1;
+        ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
+      }
+      chunk_starts[b] = starts;
+    }
+  };
+  // blocks are independent (disjoint nonzero ranges): plan them on a few host threads
+  const size_t nb = blocks.size();
+  size_t n_threads = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+  if (m.nnz < 200000) n_threads = 1;
+  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
+  if (n_threads <= 1) {
+    work(0, nb);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
+    for (auto &th : pool) th.join();
+  }
+}
+
 template <int IPT>
 const void *merge_wave_fn(bool nt) {
   return nt ? reinterpret_cast<const void *>(&k_spmv_merge_wave<IPT, true>)
@@ -233,6 +304,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.blocks.release();
   pl.long_blocks.release();
   pl.ci16.release();
+  pl.xchunk.release();
+  pl.maxch = 0;
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
@@ -293,14 +366,38 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     const int base_lds = 8 * (cap + 2) + 8 * prm.wg_size;
     pl.xu = 0;
     pl.prm.tile_width = -1;
-    if (tile > 0 && m.nnz > 0) {
+    if (tile > 0 && m.nnz > 0 && prm.index16 > 0) {
+      // tile = set of column ranges in 64-column chunks, 16-bit slot indices (host planner)
+      int rc2 = ensure_host_col_ind(m);
+      if (rc2) return rc2;
+      int xu_cap = 8;
+      while (xu_cap > 0 && base_lds + 8 * xu_cap * prm.wg_size > MAX_LDS_BYTES) xu_cap /= 2;
+      const int max_slots = std::min(tile, xu_cap * prm.wg_size);
+      std::vector<std::vector<int>> chunk_starts;
+      std::vector<unsigned short> ci16;
+      build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16);
+      int max_chunks = 0;
+      for (const auto &c : chunk_starts) max_chunks = std::max(max_chunks, (int)c.size());
+      if (max_chunks > 0) {
+        int xu = 1;
+        while (xu * prm.wg_size < max_chunks * 64) xu *= 2;
+        pl.xu = xu;
+        pl.maxch = xu * prm.wg_size / 64;
+        pl.prm.tile_width = xu * prm.wg_size;
+        std::vector<int> xchunk((size_t)pl.grid * pl.maxch, 0);
+        for (size_t b = 0; b < chunk_starts.size(); b++)
+          std::copy(chunk_starts[b].begin(), chunk_starts[b].end(), xchunk.begin() + b * pl.maxch);
+        HIP_TRY(pl.xchunk.upload(xchunk));
+        HIP_TRY(pl.ci16.upload(ci16));
+        HIP_TRY(pl.blocks.upload(blocks));             // cwidth now holds the slots each block uses
+      }
+    } else if (tile > 0 && m.nnz > 0) {
+      // 32-bit indices: one contiguous window per block
       hipLaunchKernelGGL(k_col_span_blocks, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid, m.d_ci);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(blocks.data(), pl.blocks.p, blocks.size() * sizeof(BlockDesc),
                              hipMemcpyDeviceToHost, m.stream));
       HIP_TRY(hipStreamSynchronize(m.stream));
-      // window capacity is xu*wg_size doubles, xu in {1,2,4,8}: the smallest that holds the widest
-      // block window not exceeding the requested tile (wider blocks gather from L2)
       int max_width = 0;
       for (const BlockDesc &d : blocks)
         if (!(d.kind_g & KIND_LONG) && d.cwidth <= tile) max_width = std::max(max_width, d.cwidth);
@@ -312,13 +409,6 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       }
       pl.xu = xu;
       if (xu > 0) pl.prm.tile_width = xu * prm.wg_size;
-      if (xu > 0 && prm.index16 > 0) {
-        HIP_TRY(pl.ci16.alloc((size_t)m.nnz + 8));
-        hipLaunchKernelGGL(k_build_ci16, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid,
-                           xu * prm.wg_size, m.d_ci, pl.ci16.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(m.stream));
-      }
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
     pl.ldsx = pl.xu > 0;
@@ -374,7 +464,8 @@ void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipSt
   const unsigned *ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
 #define CASK_LAUNCH_M(NT, C16)                                                                              \
   hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, \
-                     remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, m.d_val, x, y, pl.partials.p)
+                     remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, pl.xchunk.p, pl.maxch, m.d_val, x, y,     \
+                     pl.partials.p)
   const bool nt = pl.prm.nontemporal > 0;
   if (XU > 0 && ci16) { if (nt) CASK_LAUNCH_M(true, (XU > 0)); else CASK_LAUNCH_M(false, (XU > 0)); }
   else                { if (nt) CASK_LAUNCH_M(true, false); else CASK_LAUNCH_M(false, false); }
@@ -565,6 +656,7 @@ int cask_hip_csr_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32
   m->n_cols = n_cols;
   m->nnz = nnz;
   m->h_rp.assign(row_ptr, row_ptr + n_rows + 1);
+  if (nnz) m->h_ci.assign(col_ind, col_ind + nnz);
   HIP_TRY(m->own_rp.upload(row_ptr, (size_t)n_rows + 1));
   HIP_TRY(m->own_ci.upload(col_ind, (size_t)nnz));
   HIP_TRY(m->own_val.upload(values, (size_t)nnz));

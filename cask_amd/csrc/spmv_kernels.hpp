@@ -44,6 +44,7 @@ struct BlockDesc {
 };
 constexpr int KIND_LONG = 0x100;
 constexpr int KIND_PARTIAL = 0x200;
+constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutive: chunk c starts at cmin + 64c
 
 struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
   int32_t row, first_slot, n_slots, pad;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
 template <int IPT, int XU, bool NT, bool C16>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
-                                            const unsigned *__restrict__ ci16,
+                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs) {
   const int WG = blockDim.x, tid = threadIdx.x;
@@ -236,10 +237,21 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // one valid element cannot cross a page, so it is memory-safe).
   const int npairs = (total + 1) >> 1;
 
+  // x tile.  With 16-bit indices the tile is a SET of column ranges cut into 64-column chunks
+  // (xchunk[c] = first column of chunk c; built on the host): chunk c = u*(WG/64) + wave lands in
+  // LDS slots [64c, 64c+64), and a nonzero's 16-bit index is its slot.  One contiguous window is
+  // the special case of consecutive chunks; stencil-like matrices (a few narrow bands far apart)
+  // fit the same way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
   double xw[XU > 0 ? XU : 1];
   if (XU > 0) {
+    if (C16 && !(d.kind_g & KIND_CONTIG)) {                   // workgroup-uniform
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
 #pragma unroll
-    for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, n_cols - 1)];
+      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, n_cols - 1)];
+    } else {                                                  // one window: no chunk table on the critical path
+#pragma unroll
+      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, n_cols - 1)];
+    }
   }
   const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
   const int ro1 = rp[d.row_start + min(tid + WG, d.n_rows)] - base;
@@ -318,7 +330,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 template <int IPT, int XU, bool NT, bool C16>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
-                             const unsigned *__restrict__ ci16,
+                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
@@ -329,7 +341,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   double *xs = reinterpret_cast<double *>(roff + 2 * WG);     // XU*WG doubles
 
   CASK_STAMP(0);
-  const BlockDesc d = blocks[logical_block(blockIdx.x, n_blocks, remap)];
+  const int lb = logical_block(blockIdx.x, n_blocks, remap);
+  const BlockDesc d = blocks[lb];
+  const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
 
   if (d.kind_g & KIND_LONG) {
     // One piece of one long row: the whole workgroup strides over it.
@@ -363,9 +377,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 
   const int max_gpair = ((nnz + 1) >> 1) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
+    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs);
   else
-    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, val, x, y, prod, roff, xs);
+    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs);
   CASK_STAMP(5);
 }
 
@@ -609,18 +623,6 @@ __global__ void k_col_span_blocks(BlockDesc *blocks, int n_blocks, const int *__
     blocks[b].cmin = hi < 0 ? 0 : lo;
     blocks[b].cwidth = hi < 0 ? 0 : hi - lo + 1;
   }
-}
-
-// Fills the 16-bit side index (col_ind - cmin) for every block whose x window
-// fits the LDS tile; other blocks keep reading the 32-bit col_ind.
-__global__ void k_build_ci16(const BlockDesc *__restrict__ blocks, int n_blocks, int capacity,
-                             const int *__restrict__ ci, unsigned short *__restrict__ ci16) {
-  const int b = blockIdx.x;
-  if (b >= n_blocks) return;
-  const BlockDesc d = blocks[b];
-  if ((d.kind_g & KIND_LONG) || d.cwidth <= 0 || d.cwidth > capacity) return;
-  const int e = d.nnz_start + d.nnz_count;
-  for (int k = d.nnz_start + threadIdx.x; k < e; k += blockDim.x) ci16[k] = (unsigned short)(ci[k] - d.cmin);
 }
 
 __global__ void k_col_span_rows(int2v *xspan, int n_wg, int rows_per_wg, int n_rows,
