@@ -166,7 +166,7 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
   const int long_t = cap / 2;
   n_long = 0;
   n_partial_slots = 0;
-  int cur_start = 0, cur_rows = 0, cur_nnz = 0;
+  int cur_start = 0, cur_rows = 0, cur_nnz = 0, cur_max = 0;
   auto close = [&](int next_row) {
     if (cur_rows == 0) return;
     BlockDesc d{};
@@ -181,9 +181,11 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
     int by_len = 1;
     while (by_len < mean && by_len < 64) by_len *= 2;
     d.kind_g = std::min(64, std::max(1, std::min(by_rows, by_len)));
+    if (cur_max > SKEW_FACTOR * (d.kind_g & 0xff)) d.kind_g |= KIND_SKEW;   // long rows get a wave each
     blocks.push_back(d);
     cur_rows = 0;
     cur_nnz = 0;
+    cur_max = 0;
     cur_start = next_row;
   };
   for (int r = 0; r < m.n_rows; r++) {
@@ -210,6 +212,7 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
     if (cur_rows == 0) cur_start = r;
     cur_rows++;
     cur_nnz += len;
+    cur_max = std::max(cur_max, len);
   }
   close(m.n_rows);
 }

@@ -44,6 +44,7 @@ struct BlockDesc {
 };
 constexpr int KIND_LONG = 0x100;
 constexpr int KIND_PARTIAL = 0x200;
+constexpr int KIND_SKEW = 0x800;      // block holds rows much longer than its lanes-per-row suits: second, wave-per-row pass
 constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutive: chunk c starts at cmin + 64c
 
 struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
@@ -184,9 +185,15 @@ __global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width,
 // elements in flight per lane, independent of row structure) and parks the
 // products in LDS; phase 2 sums each row's run of products with G lanes per
 // row (G chosen per block from its mean row length) and a DPP butterfly.
+// Rows longer than SKEW_FACTOR*G products are left to a second pass in which a whole wave sums one row
+// (power-law blocks: a 500-nonzero row among 3-nonzero rows would otherwise keep one lane busy for
+// microseconds while 255 idle).  The host flags such blocks (KIND_SKEW); others pay one compare.
+constexpr int SKEW_FACTOR = 32;
+constexpr int SKEW_LIST = 64;         // queue capacity; entry [SKEW_LIST] is the counter
+
 template <int G>
-__device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
-                                            double *__restrict__ y) {
+__device__ __forceinline__ void reduce_rows_plain(const BlockDesc &d, const double *prod, const int *roff,
+                                                  double *__restrict__ y) {
   const int tid = threadIdx.x;
   const int rows_per_pass = blockDim.x / G;
   const int j = tid & (G - 1);
@@ -200,6 +207,65 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
     }
     acc = group_sum<G>(acc);
     if (j == 0 && r < d.n_rows) y[d.row_start + r] = acc;
+  }
+}
+
+template <int G>
+__device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
+                                            double *__restrict__ y, int *skew_list) {
+  const bool skew = d.kind_g & KIND_SKEW;                     // workgroup-uniform
+  if (!skew) {                                                // the common case keeps the lean loop
+    reduce_rows_plain<G>(d, prod, roff, y);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int rows_per_pass = blockDim.x / G;
+  const int j = tid & (G - 1);
+  for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
+    const int r = r0 + tid / G;
+    double acc = 0.0;
+    bool mine = r < d.n_rows;
+    if (mine) {
+      const int s = roff[r], e = roff[r + 1];
+      bool deferred = false;
+      if (skew && e - s > SKEW_FACTOR * G) {
+        // long row: lane 0 of the group queues it for the wave-per-row pass (the queue holds 64 rows;
+        // when it is full the row is summed here after all)
+        int slot = SKEW_LIST;
+        if (j == 0) slot = atomicAdd(&skew_list[SKEW_LIST], 1);
+        if (G > 1) slot = __shfl(slot, (tid & 63) & ~(G - 1));
+        if (slot < SKEW_LIST) {
+          if (j == 0) skew_list[slot] = r;
+          deferred = true;
+        }
+      }
+      if (deferred) {
+        mine = false;
+      } else {
+#pragma unroll 4
+        for (int k = s + j; k < e; k += G) acc += prod[k];
+      }
+    }
+    acc = group_sum<G>(acc);
+    if (j == 0 && mine) y[d.row_start + r] = acc;
+  }
+  if (skew) {
+    __syncthreads();                                          // queue complete
+    const int queued = min(skew_list[SKEW_LIST], SKEW_LIST);
+    const int lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    for (int q = wave; q < queued; q += n_waves) {            // wave-uniform
+      const int r = skew_list[q];
+      const int s = roff[r], e = roff[r + 1];
+      double a0 = 0.0, a1 = 0.0;
+      int k = s + lane;
+      for (; k + 64 < e; k += 128) {
+        a0 += prod[k];
+        a1 += prod[k + 64];
+      }
+      if (k < e) a0 += prod[k];
+      const double acc = group_sum<64>(a0 + a1);
+      if (lane == 0) y[d.row_start + r] = acc;
+    }
   }
 }
 
@@ -223,8 +289,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
-                                            double *__restrict__ y, double *prod, int *roff, double *xs) {
+                                            double *__restrict__ y, double *prod, int *roff, double *xs,
+                                            int *skew_list) {
   const int WG = blockDim.x, tid = threadIdx.x;
+  if ((d.kind_g & KIND_SKEW) && tid == 0) skew_list[SKEW_LIST] = 0;   // read only after the products barrier
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -317,13 +385,13 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   CASK_STAMP(4);
 
   switch (d.kind_g & 0xff) {
-    case 1:  reduce_rows<1>(d, prod, roff, y); break;
-    case 2:  reduce_rows<2>(d, prod, roff, y); break;
-    case 4:  reduce_rows<4>(d, prod, roff, y); break;
-    case 8:  reduce_rows<8>(d, prod, roff, y); break;
-    case 16: reduce_rows<16>(d, prod, roff, y); break;
-    case 32: reduce_rows<32>(d, prod, roff, y); break;
-    default: reduce_rows<64>(d, prod, roff, y); break;
+    case 1:  reduce_rows<1>(d, prod, roff, y, skew_list); break;
+    case 2:  reduce_rows<2>(d, prod, roff, y, skew_list); break;
+    case 4:  reduce_rows<4>(d, prod, roff, y, skew_list); break;
+    case 8:  reduce_rows<8>(d, prod, roff, y, skew_list); break;
+    case 16: reduce_rows<16>(d, prod, roff, y, skew_list); break;
+    case 32: reduce_rows<32>(d, prod, roff, y, skew_list); break;
+    default: reduce_rows<64>(d, prod, roff, y, skew_list); break;
   }
 }
 
@@ -335,6 +403,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              double *__restrict__ y, double *__restrict__ partials) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int skew_list[SKEW_LIST + 1];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
@@ -377,9 +446,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 
   const int max_gpair = ((nnz + 1) >> 1) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs);
+    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
   else
-    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs);
+    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
   CASK_STAMP(5);
 }
 
@@ -399,7 +468,7 @@ struct WaveStream {            // one block's worth of loads held in registers
 };
 
 template <int G>
-__device__ __forceinline__ void wave_reduce_rows(int n_rows, int row_start, const double *prod,
+__device__ __forceinline__ void wave_reduce_rows(int n_rows, int row_start, bool skew, const double *prod,
                                                  const int *roff, double *__restrict__ y) {
   const int lane = threadIdx.x & 63;
   constexpr int rows_per_pass = 64 / G;
@@ -407,13 +476,28 @@ __device__ __forceinline__ void wave_reduce_rows(int n_rows, int row_start, cons
   for (int r0 = 0; r0 < n_rows; r0 += rows_per_pass) {
     const int r = r0 + lane / G;
     double acc = 0.0;
-    if (r < n_rows) {
+    bool mine = r < n_rows;
+    if (mine) {
       const int s = roff[r], e = roff[r + 1];
+      if (skew && e - s > SKEW_FACTOR * G) {
+        mine = false;
+      } else {
 #pragma unroll 4
-      for (int k = s + j; k < e; k += G) acc += prod[k];
+        for (int k = s + j; k < e; k += G) acc += prod[k];
+      }
     }
     acc = group_sum<G>(acc);
-    if (j == 0 && r < n_rows) y[row_start + r] = acc;
+    if (j == 0 && mine) y[row_start + r] = acc;
+  }
+  if (skew) {
+    for (int r = 0; r < n_rows; r++) {                        // wave-uniform
+      const int s = roff[r], e = roff[r + 1];
+      if (e - s <= SKEW_FACTOR * G) continue;
+      double a = 0.0;
+      for (int k = s + lane; k < e; k += 64) a += prod[k];
+      a = group_sum<64>(a);
+      if (lane == 0) y[row_start + r] = a;
+    }
   }
 }
 
@@ -485,13 +569,13 @@ __device__ __forceinline__ void wave_block(const BlockDesc &d, const BlockDesc &
   __builtin_amdgcn_wave_barrier();
   // 4. per-row sums
   switch (d.kind_g & 0xff) {
-    case 1:  wave_reduce_rows<1>(d.n_rows, d.row_start, prod, roff, y); break;
-    case 2:  wave_reduce_rows<2>(d.n_rows, d.row_start, prod, roff, y); break;
-    case 4:  wave_reduce_rows<4>(d.n_rows, d.row_start, prod, roff, y); break;
-    case 8:  wave_reduce_rows<8>(d.n_rows, d.row_start, prod, roff, y); break;
-    case 16: wave_reduce_rows<16>(d.n_rows, d.row_start, prod, roff, y); break;
-    case 32: wave_reduce_rows<32>(d.n_rows, d.row_start, prod, roff, y); break;
-    default: wave_reduce_rows<64>(d.n_rows, d.row_start, prod, roff, y); break;
+    case 1:  wave_reduce_rows<1>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    case 2:  wave_reduce_rows<2>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    case 4:  wave_reduce_rows<4>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    case 8:  wave_reduce_rows<8>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    case 16: wave_reduce_rows<16>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    case 32: wave_reduce_rows<32>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
+    default: wave_reduce_rows<64>(d.n_rows, d.row_start, d.kind_g & KIND_SKEW, prod, roff, y); break;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   __builtin_amdgcn_wave_barrier();

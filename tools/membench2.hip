@@ -128,6 +128,59 @@ __global__ void k_stage4(const double *__restrict__ val, const int *__restrict__
   if (j == 0) y[(long)blockIdx.x * (WG / G) + r] = a;
 }
 
+// STAGE 5: like 4 (x window requested first, gathered from LDS), but every WAVE owns a contiguous run of
+// 64*IPT nonzeros (= IPT whole rows) and reduces its own rows without a second workgroup barrier.
+template <int IPT, int XU>
+__global__ void k_stage5(const double *__restrict__ val, const int *__restrict__ ci, const double *__restrict__ x,
+                         double *__restrict__ y, long nnz, int n, double *out) {
+  extern __shared__ double smem[];
+  const int WG = blockDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double *prod = smem + wave * (64 * IPT);   // per wave
+  double *xs = smem + WG * IPT;              // XU*WG*2 shared
+  const dbl2 *v2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *c2 = reinterpret_cast<const int2v *>(ci);
+  const long pairs = nnz / 2;
+  const long base = (long)blockIdx.x * WG * (IPT / 2) + (long)wave * 64 * (IPT / 2);
+  const int rows = WG * IPT / 64;
+  const int r0 = blockIdx.x * rows;
+  const int w0 = max(0, r0 - 400) & ~1;
+  const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x + w0);
+  const int maxp = (n - w0) / 2 - 1;
+  dbl2 xw[XU];
+#pragma unroll
+  for (int u = 0; u < XU; u++) xw[u] = x2[min(u * WG + tid, maxp)];
+  dbl2 v[IPT / 2]; int2v c[IPT / 2];
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    long p = base + u * 64 + lane;
+    if (p >= pairs) p = pairs - 1;
+    v[u] = __builtin_nontemporal_load(v2 + p);
+    c[u] = __builtin_nontemporal_load(c2 + p);
+  }
+  dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
+#pragma unroll
+  for (int u = 0; u < XU; u++) xs2[u * WG + tid] = xw[u];
+  __syncthreads();
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(prod);
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    dbl2 xv; xv.x = xs[c[u].x - w0]; xv.y = xs[c[u].y - w0];
+    p2[u * 64 + lane] = v[u] * xv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int G = 64 / IPT;                // lanes per row: the wave's IPT rows in one pass
+  const int r = lane / G, j = lane % G;
+  double a = 0;
+#pragma unroll
+  for (int k = 0; k < 64 / G; k++) a += prod[r * 64 + j + k * G];
+  if (G >= 2) a += dpp<0xB1>(a);
+  if (G >= 4) a += dpp<0x4E>(a);
+  if (G >= 8) a += dpp<0x141>(a);
+  if (G >= 16) a += dpp<0x140>(a);
+  if (j == 0) y[(long)blockIdx.x * rows + wave * IPT + r] = a;
+}
+
 __global__ void k_empty() {}
 
 int main() {
@@ -175,6 +228,10 @@ int main() {
 #define RUN4(IPT, WG, XU) { char nm[96]; snprintf(nm, 96, "stage 4 (LDS x) IPT=%d WG=%d XU=%d", IPT, WG, XU); \
     long tile = (long)WG * (IPT / 2); int grid = (int)((nnz / 2 + tile - 1) / tile); \
     timeit(nm, [&](int c) { hipLaunchKernelGGL((k_stage4<IPT, XU>), dim3(grid), dim3(WG), (WG * IPT + XU * WG * 2) * 8, 0, vals[c], cis[c], x, y, nnz, (int)n, out); }); }
+#define RUN5(IPT, WG, XU) { char nm[96]; snprintf(nm, 96, "stage 5 (wave rows) IPT=%d WG=%d XU=%d", IPT, WG, XU); \
+    long tile = (long)WG * (IPT / 2); int grid = (int)((nnz / 2 + tile - 1) / tile); \
+    timeit(nm, [&](int c) { hipLaunchKernelGGL((k_stage5<IPT, XU>), dim3(grid), dim3(WG), (WG * IPT + XU * WG * 2) * 8, 0, vals[c], cis[c], x, y, nnz, (int)n, out); }); }
+  RUN5(8, 256, 2) RUN5(4, 256, 2) RUN5(4, 512, 1) RUN5(8, 512, 1) RUN5(16, 256, 2)
   RUN4(8, 256, 2) RUN4(4, 256, 2) RUN4(4, 512, 1) RUN4(8, 512, 1) RUN4(16, 256, 2) RUN4(16, 512, 1) RUN4(8, 1024, 1) RUN4(4, 1024, 1)
   return 0;
 }
