@@ -39,9 +39,10 @@ build/test_spmv_hip: tests/clients/test_spmv_client.cpp $(LIBDIR)/libCaskHip.so 
 
 clients: build/test_spmv_hip
 
-$(LIBDIR)/libcask_hip.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h include/cask_hip_dfe.h
+ENGINESRC  := cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip
+$(LIBDIR)/libcask_hip.so: $(ENGINESRC) cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp cask_amd/csrc/internal.hpp include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h
 	mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINESRC)
 
 oracle:
 	$(MAKE) -C oracle _build/libcask_oracle.so

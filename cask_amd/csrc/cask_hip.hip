@@ -17,6 +17,8 @@
 #include "cask_hip.h"
 #include "spmv_kernels.hpp"
 
+#include "internal.hpp"
+
 using namespace caskhip;
 
 namespace {
@@ -27,6 +29,11 @@ int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+}  // namespace
+
+int caskhip::report_failure(int code, const std::string &msg) { return fail(code, msg); }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \

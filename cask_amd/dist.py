@@ -12,6 +12,10 @@ the matching slice of every vector, and one exchange per product:
     y_local = A_g @ x_full                (local HIP kernel)
 
 Dot products are a local two-stage reduction plus a one-element all_reduce.
+
+``exchange="p2p"`` replaces the all-gather by the peer-to-peer halo pull of
+``cask_amd/p2p.py`` (remote loads over xGMI from shared x slices, only the
+entries the block references): no collective on the data path.
 """
 from __future__ import annotations
 
@@ -55,9 +59,10 @@ class ShardedSpmv:
     ``from_global``), in the gloo CPU tests the test injects a checker.
     """
 
-    def __init__(self, bounds, rank: int, world: int, local_product, device, group=None):
+    def __init__(self, bounds, rank: int, world: int, local_product, device, group=None, exchange=None):
         import torch
         self.torch = torch
+        self.exchange = exchange              # p2p.PeerExchange or None (= all-gather)
         self.bounds = list(bounds)
         self.rank, self.world = rank, world
         self.local_product = local_product
@@ -74,18 +79,46 @@ class ShardedSpmv:
             self._pad_out = torch.zeros(self.max_local * world, dtype=torch.float64, device=device)
 
     @classmethod
-    def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None):
-        """Build this rank's block of a globally known CSR matrix on the current GPU."""
+    def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None,
+                    exchange="all_gather", fence=None):
+        """Build this rank's block of a globally known CSR matrix on the current GPU.
+
+        exchange="all_gather": block with global columns, x all-gathered per product.
+        exchange="p2p": block with extended columns [own | halo], halo pulled from the peers' shared
+        slices per product (collective construction; raises on every rank if any rank cannot map a peer).
+        ``fence`` orders device work across ranks for the p2p path (default: a 1-element all-reduce)."""
         import torch
         from . import capi
         n = len(row_ptr) - 1
         bounds = partition_rows_by_nnz(row_ptr, world) if balance == "nnz" else partition_rows_even(n, world)
         if n != n_cols:
-            raise ValueError("row sharding with an all-gathered x needs a square matrix")
+            raise ValueError("row sharding of x needs a square matrix")
         rp, ci, va = slice_rows(row_ptr, col_ind, values, bounds[rank], bounds[rank + 1])
-        mat = capi.CsrMatrix.from_host(bounds[rank + 1] - bounds[rank], n_cols, rp, ci, va, params)
         dev = torch.device("cuda", torch.cuda.current_device())
-        obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
+        n_local = bounds[rank + 1] - bounds[rank]
+        if exchange == "p2p":
+            import torch.distributed as dist
+            from . import p2p
+            ci_ext, halo_cols, halo_owner, halo_index = p2p.plan_halo(ci, bounds, rank)
+
+            def gather_objects(obj):
+                out = [None] * world
+                dist.all_gather_object(out, obj, group=group)
+                return out
+
+            if fence is None:
+                token = torch.zeros(1, device=dev)
+
+                def fence():
+                    dist.all_reduce(token, group=group)
+            ex = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects, fence)
+            mat = capi.CsrMatrix.from_host(n_local, n_local + ex.n_halo, rp, ci_ext, va, params)
+            obj = cls(bounds, rank, world, lambda xe, yl: mat.spmv_device(xe, yl), dev, group, exchange=ex)
+        elif exchange == "all_gather":
+            mat = capi.CsrMatrix.from_host(n_local, n_cols, rp, ci, va, params)
+            obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
+        else:
+            raise ValueError(f"unknown exchange {exchange!r}")
         obj.matrix = mat
         return obj
 
@@ -109,9 +142,29 @@ class ShardedSpmv:
     def spmv(self, x_local, y_local=None):
         if y_local is None:
             y_local = self.torch.empty(self.n_local, dtype=self.torch.float64, device=self.device)
+        ex = self.exchange
+        if ex is not None:
+            if x_local.data_ptr() != ex.x_local.data_ptr():
+                ex.x_local.copy_(x_local)
+            ex.fence()              # every slice is final ...
+            ex.pull()
+            ex.fence()              # ... and nobody overwrites its slice while a peer still pulls from it
+            self.local_product(ex.x_ext, y_local)
+            return y_local
         xf = self.gather_x(x_local)
         self.local_product(xf, y_local)
         return y_local
+
+    def close(self):
+        """Collective: unmap the peers' slices, then free the own one."""
+        ex, self.exchange = self.exchange, None
+        if ex is not None:
+            for g, p in list(ex.peers.items()):
+                from . import p2p
+                p2p.close_peer(p)
+            ex.peers = {}
+            ex.fence()
+            ex.close()
 
     def dot(self, a_local, b_local):
         """Global dot product as a 1-element tensor on the device (no host sync)."""

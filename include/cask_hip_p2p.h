@@ -1,0 +1,53 @@
+/*
+ * cask_hip_p2p.h -- multi-GPU exchange step of the sharded SpMV without a collective:
+ * peer-to-peer loads over xGMI from vectors shared between the per-GPU processes.
+ *
+ * The reference has no multi-device code; its only precedent is the per-pipe contiguous row
+ * split of Spmv::preprocess (src/runtime/Spmv.cpp:334-364) and the num_controllers memory
+ * banks of GeneratedSpmvImplementation (src/runtime/GeneratedImplSupport.hpp:56).  Here one
+ * process drives one GPU and owns a contiguous row block plus the matching slice of x.  The
+ * slice lives in a SHARED allocation: its owner exports a 64-byte handle, every peer opens
+ * it and gets a device pointer it can load from directly (xGMI is point-to-point, a remote
+ * load is one hop).  Per product a rank pulls the x entries its block references from the
+ * owners' slices (cask_hip_halo_pull_device: one small kernel, no host involvement, legal
+ * inside a HIP graph) into the tail of its own extended x, then runs the ordinary local kernel.
+ *
+ * Plain C, same conventions as cask_hip.h (status codes, cask_hip_last_error()).
+ */
+#ifndef CASK_HIP_P2P_H
+#define CASK_HIP_P2P_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASK_HIP_SHARED_HANDLE_BYTES 64
+
+/* Allocate `bytes` of zeroed device memory on the current device and export it.
+ * handle_out receives CASK_HIP_SHARED_HANDLE_BYTES bytes to pass to the peer processes
+ * (any byte transport: torch.distributed object collectives, a file, a socket). */
+int cask_hip_shared_alloc(int64_t bytes, void **d_ptr_out, unsigned char *handle_out);
+/* Release an allocation made by cask_hip_shared_alloc (after every peer has closed it). */
+int cask_hip_shared_free(void *d_ptr);
+/* Map a peer's allocation into this process; the pointer is loadable from kernels on the
+ * current device.  Never call it on a handle exported by this same process. */
+int cask_hip_shared_open(const unsigned char *handle, void **d_ptr_out);
+int cask_hip_shared_close(void *d_ptr);
+
+/* Plain copies for callers without a device-array library (and the mapping self-test:
+ * reading a few bytes of a freshly opened peer allocation through the runtime fails with a
+ * status code where a kernel would fault). */
+int cask_hip_copy_to_device(void *d_dst, const void *h_src, int64_t bytes);
+int cask_hip_copy_to_host(void *h_dst, const void *d_src, int64_t bytes);
+
+/* dst[j] = *(const double *)src_addr[j]  for j < n_halo.  src_addr is a DEVICE array of
+ * absolute device addresses (own or peer allocations, 8-byte aligned), built once per
+ * matrix from the opened base pointers.  Asynchronous on `stream`. */
+int cask_hip_halo_pull_device(int64_t n_halo, const uint64_t *d_src_addr, double *d_dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASK_HIP_P2P_H */
