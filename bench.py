@@ -4,9 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path: y = A x over the whole matrix resident in
-HBM (for N > 1: all-gather of the x slices over RCCL, then the local row-block
-product; weak scaling -- every rank owns one cant-sized row block of a block-
-banded global matrix).  To make the number an HBM number and not an Infinity-
+HBM.  For N > 1 (weak scaling: every rank owns one cant-sized row block of a
+block-banded global matrix, and the slice of x that goes with it) a step is the
+exchange of the x entries the block references, then the local row-block
+product.  The exchange is peer-to-peer: a small kernel pulls the halo entries
+over xGMI straight from the neighbours' shared x slices (cask_amd/p2p.py) -- no
+collective on the data path; if the slices cannot be mapped the step falls back
+to an RCCL all-gather of x.  To make the number an HBM number and not an Infinity-
 Cache number the steps rotate through enough device copies of the matrix to
 exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one copy is
 reported next to it.  The K timed steps are captured once into a HIP graph
@@ -132,10 +136,27 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    backend = os.environ.get("CASK_BENCH_BACKEND", "nccl")
+    if os.environ.get("CASK_BENCH_SHARE_DEVICE"):              # dry run of N ranks on a 1-GPU box (with the gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    ctl_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    def all_reduce_scalar(v, op):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(t, op=op)
+        return float(t[0])
+
+    def host_barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
 
     # ---- workload -----------------------------------------------------------
     if args.workload == "cant":
@@ -147,29 +168,74 @@ def main():
         n_local, rp, ci, va, source = synth.load_or_make(args.workload)
         n_global = n_local
     nnz_local = int(ci.size)
-    alg_bytes = synth.algorithmic_bytes(n_local, n_global, nnz_local)
+    x_host = np.arange(n_global, dtype=np.float64) * 0.25 / n_global        # test_spmv.cpp operand, scaled
+    x_slice = x_host[rank * n_local:(rank + 1) * n_local].copy()
+
+    # ---- exchange (N > 1): peer-to-peer halo pull, else RCCL all-gather ------------
+    exchange, peer, p2p_error = "none", None, None
+    ci_dev, n_cols_dev = ci, n_global
+    if use_dist:
+        exchange = "all_gather"
+        if not os.environ.get("CASK_BENCH_NO_P2P"):
+            from cask_amd import p2p
+            bounds = [g * n_local for g in range(world + 1)]
+            ci_ext, halo_cols, halo_owner, halo_index = p2p.plan_halo(ci, bounds, rank)
+
+            def gather_objects(obj):
+                out = [None] * world
+                dist.all_gather_object(out, obj)
+                return out
+
+            try:
+                peer = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects)
+                peer.x_local.copy_(torch.from_numpy(x_slice).to(dev))
+                host_barrier()                                   # every slice is in place before anyone pulls
+                peer.pull()
+                torch.cuda.synchronize()
+                # self-check against a halo computed from the formula for x (no collective involved)
+                want = torch.from_numpy(x_host[halo_cols]).to(dev)
+                ok = bool(torch.equal(peer.x_ext[n_local:], want))
+            except Exception as e:  # noqa: BLE001 - setup is collective: it fails on every rank or none
+                ok, p2p_error = False, repr(e)
+            ok = all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            if ok:
+                exchange, ci_dev, n_cols_dev = "p2p", ci_ext, n_local + peer.n_halo
+            else:
+                if rank == 0:
+                    print(f"[bench] peer-to-peer exchange unavailable ({p2p_error or 'halo mismatch'}); "
+                          "using the RCCL all-gather", file=sys.stderr)
+                if peer is not None:
+                    peer.close()
+                    peer = None
+    # bytes the local kernel must move: x entries = the columns this block can reference
+    alg_bytes = synth.algorithmic_bytes(n_local, n_cols_dev, nnz_local)
     matrix_bytes = 12 * nnz_local + 4 * (n_local + 1)
     copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // matrix_bytes) + 1)
 
     forced = capi.make_params(variant=args.variant or 0, lanes_per_row=args.lanes, tile_width=args.tile,
                               items_per_thread=args.items, wg_size=args.wg)
-    mats, keep = [], []
+    mats = []
     rp_t = torch.from_numpy(rp).to(dev)
     for _ in range(copies):
-        ci_t, va_t = torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev)
-        mats.append(capi.CsrMatrix.from_device(n_local, n_global, rp_t, ci_t, va_t, forced))
-    x_host = np.arange(n_global, dtype=np.float64) * 0.25 / n_global        # test_spmv.cpp operand, scaled
-    x_local = torch.from_numpy(x_host[rank * n_local:(rank + 1) * n_local].copy()).to(dev)
-    x_full = torch.from_numpy(x_host).to(dev) if not use_dist else torch.zeros(n_global, dtype=torch.float64, device=dev)
+        ci_t, va_t = torch.from_numpy(ci_dev).to(dev), torch.from_numpy(va).to(dev)
+        mats.append(capi.CsrMatrix.from_device(n_local, n_cols_dev, rp_t, ci_t, va_t, forced))
+    if exchange == "p2p":
+        x_in = peer.x_ext                                        # [own slice | halo]
+    elif exchange == "all_gather":
+        x_local = torch.from_numpy(x_slice).to(dev)
+        x_in = torch.zeros(n_global, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(x_in, x_local)
+    else:
+        x_in = torch.from_numpy(x_host).to(dev)
     y = torch.zeros(n_local, dtype=torch.float64, device=dev)
 
     # ---- measured DSE (cold: on the rotating copies), best point left active --------
     tune_info = None
     if not args.no_tune and args.variant is None:
         from cask_amd import dse
-        rows, best, took = dse.explore(mats, x_full if not use_dist else torch.from_numpy(x_host).to(dev), y)
+        rows, best, took = dse.explore(mats, x_in, y)
         if use_dist:
-            # every rank must run the same design point: take rank 0's winner
+            # every rank runs the same design point: rank 0's winner
             obj = [mats[0].params.as_dict()]
             dist.broadcast_object_list(obj, src=0)
             prm = capi.make_params(**obj[0])
@@ -180,16 +246,18 @@ def main():
     info = mats[0].info
 
     def step(i):
-        if use_dist:
-            dist.all_gather_into_tensor(x_full, x_local)
-        mats[i % copies].spmv_device(x_full, y)
+        if exchange == "p2p":
+            peer.pull()                                          # remote loads over xGMI, on the launch stream
+        elif exchange == "all_gather":
+            dist.all_gather_into_tensor(x_in, x_local)
+        mats[i % copies].spmv_device(x_in, y)
 
     # ---- warm-up (eager) -------------------------------------------------------
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
 
-    launch_mode = args.launch if not use_dist else "eager"
+    launch_mode = args.launch if exchange != "all_gather" else "eager"
     graph = None
     if launch_mode == "graph":
         try:
@@ -209,11 +277,16 @@ def main():
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph, launch_mode = None, "eager"
+    if use_dist:
+        # ranks must agree on the launch mode only for reporting; the timed region has no collective in p2p mode
+        launch_mode = "graph" if all_reduce_scalar(1.0 if graph is not None else 0.0, dist.ReduceOp.MIN) > 0.5 \
+            else "eager"
+        if launch_mode == "eager":
+            graph = None
 
     # ---- timed region: exactly K steps -------------------------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if use_dist:
-        dist.barrier()
+    host_barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
@@ -223,24 +296,23 @@ def main():
         for i in range(args.steps):
             step(i)
     e1.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    host_barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
+    y_gpu = y.cpu().numpy()
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        z = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
-        dist.all_reduce(z, op=dist.ReduceOp.SUM)
-        nnz_total = float(z[0])
+        elapsed = all_reduce_scalar(elapsed, dist.ReduceOp.MAX)
+        nnz_total = all_reduce_scalar(nnz_local, dist.ReduceOp.SUM)
+        # every rank checks its whole block against the CPU oracle (the global x is a formula, nothing to gather)
+        import oracle
+        bad, _ = oracle.mismatches(y_gpu, oracle.csr_spmv(rp, ci, va, x_host))
+        rows_wrong = int(all_reduce_scalar(bad, dist.ReduceOp.SUM))
     else:
         nnz_total = float(nnz_local)
-    y_gpu = y.cpu().numpy()
+        rows_wrong = None
 
     # ---- cache-warm rate of ONE copy (what a CG iteration on this matrix sees) ------
-    warm_med, warm_min = mats[0].time(x_full, y, warmup=10, iters=200)
+    warm_med, warm_min = mats[0].time(x_in, y, warmup=10, iters=200)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -262,7 +334,11 @@ def main():
             "config": {"workload": f"{args.workload}-like CSR SpMV, {n_local} rows x {n_global} cols per GPU, "
                                    f"{nnz_local} nnz per GPU, x_i = 0.25 i / n",
                        "rows": n_local * world, "nnz": int(nnz_total), "parallelism": f"row-blocks x{world}",
-                       "exchange": "none" if not use_dist else "RCCL all_gather(x) per step",
+                       "exchange": {"none": "none",
+                                    "p2p": f"per step: pull of {peer.n_halo if peer else 0} halo entries over xGMI from the "
+                                           "neighbours' shared x slices (one kernel, no collective)",
+                                    "all_gather": "per step: RCCL all_gather(x)"}[exchange],
+                       "rows_wrong_vs_oracle_all_ranks": rows_wrong,
                        "matrix_copies_rotated": copies, "launch": launch_mode, "design_point": design,
                        "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info},
             "hbm_gbs_algorithmic": round(achieved * world, 1),
@@ -282,7 +358,13 @@ def main():
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)
     if use_dist:
-        dist.barrier()
+        host_barrier()
+        if peer is not None:
+            for ptr in peer.peers.values():
+                p2p.close_peer(ptr)
+            peer.peers = {}
+            host_barrier()                                       # owners free only after every peer has unmapped
+            peer.close()
         dist.destroy_process_group()
 
 
