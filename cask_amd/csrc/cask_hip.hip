@@ -91,6 +91,7 @@ struct Plan {
   DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz)
   DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
   int maxch = 0;
+  bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
   // VECTOR
   DevBuf<int2v> xspan;
@@ -316,6 +317,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.ci16.release();
   pl.xchunk.release();
   pl.maxch = 0;
+  pl.any_skew = false;
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
@@ -364,6 +366,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     int n_long = 0, n_slots = 0;
     build_merge_blocks(m, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, prm.wg_size, blocks, nullptr, splits,
                        n_long, n_slots);
+    for (const BlockDesc &b : blocks) pl.any_skew = pl.any_skew || (b.kind_g & KIND_SKEW);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
     pl.grid = (int)blocks.size();
@@ -472,13 +475,21 @@ void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipSt
   const dim3 grid(pl.grid), block(pl.prm.wg_size);
   const int remap = pl.prm.xcd_remap > 0;
   const unsigned *ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
-#define CASK_LAUNCH_M(NT, C16)                                                                              \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16>), grid, block, pl.lds_bytes, s, pl.blocks.p, pl.grid, \
-                     remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, pl.xchunk.p, pl.maxch, m.d_val, x, y,     \
-                     pl.partials.p)
-  const bool nt = pl.prm.nontemporal > 0;
-  if (XU > 0 && ci16) { if (nt) CASK_LAUNCH_M(true, (XU > 0)); else CASK_LAUNCH_M(false, (XU > 0)); }
-  else                { if (nt) CASK_LAUNCH_M(true, false); else CASK_LAUNCH_M(false, false); }
+#define CASK_LAUNCH_M(NT, C16, SKEW)                                                                        \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, SKEW>), grid, block, pl.lds_bytes, s, pl.blocks.p,     \
+                     pl.grid, remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, pl.xchunk.p, pl.maxch, m.d_val,  \
+                     x, y, pl.partials.p)
+  // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
+  const bool nt = pl.prm.nontemporal > 0 || pl.any_skew;
+  if (XU > 0 && ci16) {
+    if (pl.any_skew) CASK_LAUNCH_M(true, (XU > 0), true);
+    else if (nt)     CASK_LAUNCH_M(true, (XU > 0), false);
+    else             CASK_LAUNCH_M(false, (XU > 0), false);
+  } else {
+    if (pl.any_skew) CASK_LAUNCH_M(true, false, true);
+    else if (nt)     CASK_LAUNCH_M(true, false, false);
+    else             CASK_LAUNCH_M(false, false, false);
+  }
 #undef CASK_LAUNCH_M
 }
 

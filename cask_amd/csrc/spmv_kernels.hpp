@@ -210,10 +210,10 @@ __device__ __forceinline__ void reduce_rows_plain(const BlockDesc &d, const doub
   }
 }
 
-template <int G>
+template <int G, bool SKEW>
 __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
                                             double *__restrict__ y, int *skew_list) {
-  const bool skew = d.kind_g & KIND_SKEW;                     // workgroup-uniform
+  const bool skew = SKEW && (d.kind_g & KIND_SKEW);           // workgroup-uniform
   if (!skew) {                                                // the common case keeps the lean loop
     reduce_rows_plain<G>(d, prod, roff, y);
     return;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
 // 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
 // per nonzero and already LDS offsets -- the stream shrinks from 12 to 10
 // bytes per nonzero, which on a bandwidth-bound kernel is the whole game.
-template <int IPT, int XU, bool NT, bool C16>
+template <int IPT, int XU, bool NT, bool C16, bool SKEW>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
@@ -292,7 +292,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
                                             double *__restrict__ y, double *prod, int *roff, double *xs,
                                             int *skew_list) {
   const int WG = blockDim.x, tid = threadIdx.x;
-  if ((d.kind_g & KIND_SKEW) && tid == 0) skew_list[SKEW_LIST] = 0;   // read only after the products barrier
+  if (SKEW && (d.kind_g & KIND_SKEW) && tid == 0) skew_list[SKEW_LIST] = 0;   // read only after the products barrier
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -385,17 +385,19 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   CASK_STAMP(4);
 
   switch (d.kind_g & 0xff) {
-    case 1:  reduce_rows<1>(d, prod, roff, y, skew_list); break;
-    case 2:  reduce_rows<2>(d, prod, roff, y, skew_list); break;
-    case 4:  reduce_rows<4>(d, prod, roff, y, skew_list); break;
-    case 8:  reduce_rows<8>(d, prod, roff, y, skew_list); break;
-    case 16: reduce_rows<16>(d, prod, roff, y, skew_list); break;
-    case 32: reduce_rows<32>(d, prod, roff, y, skew_list); break;
-    default: reduce_rows<64>(d, prod, roff, y, skew_list); break;
+    case 1:  reduce_rows<1, SKEW>(d, prod, roff, y, skew_list); break;
+    case 2:  reduce_rows<2, SKEW>(d, prod, roff, y, skew_list); break;
+    case 4:  reduce_rows<4, SKEW>(d, prod, roff, y, skew_list); break;
+    case 8:  reduce_rows<8, SKEW>(d, prod, roff, y, skew_list); break;
+    case 16: reduce_rows<16, SKEW>(d, prod, roff, y, skew_list); break;
+    case 32: reduce_rows<32, SKEW>(d, prod, roff, y, skew_list); break;
+    default: reduce_rows<64, SKEW>(d, prod, roff, y, skew_list); break;
   }
 }
 
-template <int IPT, int XU, bool NT, bool C16>
+// SKEW: the plan holds blocks flagged KIND_SKEW (matrices without any run the instantiation that
+// carries no second-pass code at all: 0.13 us per launch on cant).
+template <int IPT, int XU, bool NT, bool C16, bool SKEW>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
@@ -403,7 +405,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              double *__restrict__ y, double *__restrict__ partials) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int skew_list[SKEW_LIST + 1];
+  __shared__ int skew_list[SKEW ? SKEW_LIST + 1 : 1];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
@@ -446,9 +448,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 
   const int max_gpair = ((nnz + 1) >> 1) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
+    merge_block<IPT, XU, NT, C16, SKEW>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
   else
-    merge_block<IPT, 0, NT, false>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
+    merge_block<IPT, 0, NT, false, SKEW>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
   CASK_STAMP(5);
 }
 
