@@ -221,6 +221,33 @@ def main():
         mats.append(capi.CsrMatrix.from_device(n_local, n_cols_dev, rp_t, ci_t, va_t, forced))
     if exchange == "p2p":
         x_in = peer.x_ext                                        # [own slice | halo]
+        if not os.environ.get("CASK_BENCH_NO_FUSED_HALO") and peer.n_halo:
+            # Fold the exchange into the product kernel: the workgroups at a seam read the halo from the
+            # peers' slices themselves (cask_hip_csr_set_halo_sources), a step is ONE launch.  Checked
+            # against the pull path first; any rank that disagrees sends every rank back to the pull.
+            y_ref = torch.zeros(n_local, dtype=torch.float64, device=dev)
+            peer.pull()
+            mats[0].spmv_device(x_in, y_ref)
+            torch.cuda.synchronize()
+            try:
+                for m in mats:
+                    peer.attach(m)
+                y_try = torch.zeros(n_local, dtype=torch.float64, device=dev)
+                peer.x_ext[n_local:].fill_(float("nan"))         # the kernel must not read the local halo copy
+                mats[0].spmv_device(x_in, y_try)
+                torch.cuda.synchronize()
+                fused_ok = bool(torch.equal(y_try, y_ref))
+            except Exception as e:  # noqa: BLE001
+                fused_ok, p2p_error = False, repr(e)
+            fused_ok = all_reduce_scalar(1.0 if fused_ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            if fused_ok:
+                exchange = "p2p_fused"
+            else:
+                if rank == 0:
+                    print(f"[bench] in-kernel halo disagrees with the pull path ({p2p_error}); pulling", file=sys.stderr)
+                for m in mats:
+                    m.set_halo_sources(n_local, None)
+                peer.pull()
     elif exchange == "all_gather":
         x_local = torch.from_numpy(x_slice).to(dev)
         x_in = torch.zeros(n_global, dtype=torch.float64, device=dev)
@@ -348,6 +375,9 @@ def main():
                                    f"{nnz_local} nnz per GPU, x_i = 0.25 i / n",
                        "rows": n_local * world, "nnz": int(nnz_total), "parallelism": f"row-blocks x{world}",
                        "exchange": {"none": "none",
+                                    "p2p_fused": f"inside the product kernel: its seam workgroups load {peer.n_halo if peer else 0} "
+                                                 "halo entries over xGMI from the neighbours' shared x slices "
+                                                 "(one launch per step, no collective)",
                                     "p2p": f"per step: pull of {peer.n_halo if peer else 0} halo entries over xGMI from the "
                                            "neighbours' shared x slices (one kernel, no collective)",
                                     "all_gather": "per step: RCCL all_gather(x)"}[exchange],

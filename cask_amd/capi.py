@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "cask_hip_last_error", "cask_hip_abi_version", "cask_hip_device_count", "cask_hip_device_props_get",
     "cask_hip_csr_create", "cask_hip_csr_create_device", "cask_hip_csr_destroy", "cask_hip_csr_set_params",
     "cask_hip_csr_get_params", "cask_hip_csr_get_info", "cask_hip_spmv", "cask_hip_spmv_device",
-    "cask_hip_spmv_transpose_device", "cask_hip_spmv_time", "cask_hip_tune", "cask_hip_ddot_device",
+    "cask_hip_spmv_dot_device", "cask_hip_spmv_transpose_device", "cask_hip_spmv_time", "cask_hip_tune", "cask_hip_ddot_device",
     "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
 )
 
@@ -96,6 +96,8 @@ def load() -> ctypes.CDLL:
     L.cask_hip_csr_get_info.argtypes = [vp, POINTER(CsrInfo)]
     L.cask_hip_spmv.argtypes = [vp, vp, vp]
     L.cask_hip_spmv_device.argtypes = [vp, vp, vp, vp]
+    if hasattr(L, "cask_hip_spmv_dot_device") or not os.environ.get("CASK_HIP_DIAGNOSTIC_LIB"):
+        L.cask_hip_spmv_dot_device.argtypes = [vp, vp, vp, vp, vp, vp]
     L.cask_hip_spmv_transpose_device.argtypes = [vp, vp, vp, vp]
     L.cask_hip_spmv_time.argtypes = [vp, vp, vp, i32, i32, POINTER(dbl), POINTER(dbl)]
     L.cask_hip_tune.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32,
@@ -106,6 +108,8 @@ def load() -> ctypes.CDLL:
     for name in ("cask_hip_cg", "cask_hip_bicg"):
         getattr(L, name).argtypes = [vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
     for name in EXPORTED_SYMBOLS:
+        if os.environ.get("CASK_HIP_DIAGNOSTIC_LIB") and not hasattr(L, name):
+            continue                                            # an older build loaded for an A/B timing
         f = getattr(L, name)
         if name not in ("cask_hip_last_error",):
             f.restype = ctypes.c_int
@@ -233,6 +237,22 @@ class CsrMatrix:
         """torch CUDA tensors; launches on ``stream`` (default: torch's current stream)."""
         _check(load().cask_hip_spmv_device(self._h, c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
                                            c_void_p(_stream_ptr(stream))))
+
+    def spmv_dot_device(self, x_t, y_t, w_t, out_t, stream=None):
+        """y = A x and out[0] = w . y in one pass (MERGE plans: fused epilogue)."""
+        _check(load().cask_hip_spmv_dot_device(self._h, c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                               c_void_p(w_t.data_ptr()), c_void_p(out_t.data_ptr()),
+                                               c_void_p(_stream_ptr(stream))))
+
+    def set_halo_sources(self, n_own, addr_t):
+        """Columns >= n_own are read from the device addresses in ``addr_t`` (int64 CUDA tensor) by the
+        product kernel itself (include/cask_hip_p2p.h); ``addr_t=None`` restores the plain layout."""
+        L = load()
+        L.cask_hip_csr_set_halo_sources.argtypes = [c_void_p, c_int32, c_void_p]
+        L.cask_hip_csr_set_halo_sources.restype = ctypes.c_int
+        _check(L.cask_hip_csr_set_halo_sources(self._h, int(n_own),
+                                               c_void_p(addr_t.data_ptr()) if addr_t is not None else None))
+        self._halo_keep = addr_t
 
     def spmv_transpose_device(self, x_t, y_t, stream=None):
         _check(load().cask_hip_spmv_transpose_device(self._h, c_void_p(x_t.data_ptr()),

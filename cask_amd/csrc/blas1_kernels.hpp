@@ -27,12 +27,25 @@ __device__ __forceinline__ double wg_sum(double v, double *red) {
   return s;   // valid in thread 0
 }
 
-// Sum of a (<= 1024-entry, L2-resident) partials array, computed redundantly by every workgroup in the
-// same order => every workgroup sees the bit-identical value.  This replaces a separate single-workgroup
-// "final" kernel (4.3 us + a launch boundary per dot in the first version).  Result in all threads.
+// Sum of an L2-resident partials array (the <= 1024 shares of a BLAS-1 reduction, or the per-block
+// shares the product kernel's dot epilogue leaves: a few thousand), computed redundantly by every
+// workgroup in the same order => every workgroup sees the bit-identical value.  This replaces a
+// separate single-workgroup "final" kernel (4.3 us + a launch boundary per dot in the first version).
+// The loads go out eight 16-byte pairs per lane at a time: one L2 round trip for up to 4096 shares with
+// 256 threads, not one per share.  Result in all threads.
 __device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int n, double *red) {
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(partials);
+  const int n2 = n >> 1, tid = threadIdx.x, wg = blockDim.x;
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+  for (int i0 = 0; i0 < n2; i0 += 8 * wg) {
+    dbl2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p2[min(i0 + u * wg + tid, n2 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u * wg + tid < n2) acc += v[u].x + v[u].y;
+  }
+  if ((n & 1) && tid == 0) acc += partials[n - 1];
   acc = group_sum<64>(acc);
   __syncthreads();                                  // red may still be read by a previous use
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -118,9 +131,21 @@ __global__ void k_axpby(int64_t n, double alpha, const double *__restrict__ x, d
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = alpha * x[n - 1] + b * y[n - 1];
 }
 
+// The update kernels walk the vectors in 16-byte pairs (vectors are the solver's own 256-byte
+// aligned allocations); element n-1 of an odd n is handled by the workgroup/lane that owns the
+// slot after the last pair, so the summation order is a function of n and the grid only.
+#define CASK_PAIR_LOOP(n2)                                                                     \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n2);                    \
+       i += (int64_t)gridDim.x * blockDim.x)
+__device__ __forceinline__ bool owns_tail(int64_t n) {
+  const int64_t slot = n >> 1;
+  return (n & 1) && (int64_t)blockIdx.x == (slot / blockDim.x) % gridDim.x && (int64_t)threadIdx.x == slot % blockDim.x;
+}
+
 // CG: alpha = rsold / (p.Ap) ; x += alpha p ; r -= alpha Ap ; partials of r.r
-// (SparseLinearSolvers.hpp:208-218 in one pass over the vectors).  p.Ap arrives as the partials of
-// k_dot_partial; the r.r partials go to a second array.
+// (SparseLinearSolvers.hpp:208-218 in one pass over the vectors).  p.Ap arrives as partials: of
+// k_dot_partial, or of the product kernel's fused epilogue (DotEpilogue); the r.r partials go to a
+// second array.
 __global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *__restrict__ part_pAp, int n_part,
                                const double *__restrict__ p, const double *__restrict__ Ap,
                                double *__restrict__ x, double *__restrict__ r,
@@ -128,15 +153,29 @@ __global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *__r
   __shared__ double red[16];
   if (done && *done) return;
   const double alpha = *rsold / sum_partials(part_pAp, n_part, red);
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    x[i] = fma(alpha, p[i], x[i]);
-    const double rn = fma(-alpha, Ap[i], r[i]);
-    r[i] = rn;
-    acc = fma(rn, rn, acc);
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p), *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
+  dbl2 *x2 = reinterpret_cast<dbl2 *>(x), *r2 = reinterpret_cast<dbl2 *>(r);
+  double acc0 = 0.0, acc1 = 0.0;
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 pv = p2[i], av = Ap2[i];
+    dbl2 xv = x2[i], rv = r2[i];
+    xv.x = fma(alpha, pv.x, xv.x);
+    xv.y = fma(alpha, pv.y, xv.y);
+    rv.x = fma(-alpha, av.x, rv.x);
+    rv.y = fma(-alpha, av.y, rv.y);
+    x2[i] = xv;
+    r2[i] = rv;
+    acc0 = fma(rv.x, rv.x, acc0);
+    acc1 = fma(rv.y, rv.y, acc1);
+  }
+  if (owns_tail(n)) {
+    x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
+    const double rn = fma(-alpha, Ap[n - 1], r[n - 1]);
+    r[n - 1] = rn;
+    acc0 = fma(rn, rn, acc0);
   }
   __syncthreads();
-  const double s = wg_sum(acc, red);
+  const double s = wg_sum(acc0 + acc1, red);
   if (threadIdx.x == 0) part_rr[blockIdx.x] = s;
 }
 
@@ -154,8 +193,16 @@ __global__ void k_cg_update_p(int64_t n, const double *__restrict__ part_rr, int
     return;
   }
   const double beta = rsnew / *rsold;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = fma(beta, p[i], r[i]);
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p);
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 rv = r2[i];
+    dbl2 pv = p2[i];
+    pv.x = fma(beta, pv.x, rv.x);
+    pv.y = fma(beta, pv.y, rv.y);
+    p2[i] = pv;
+  }
+  if (owns_tail(n)) p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
   if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *iters = iter; }
 }
 
@@ -169,20 +216,40 @@ __global__ void k_bicg_update(int64_t n, const double *rho, const double *__rest
   __shared__ double red[16];
   if (done && *done) return;
   const double alpha = *rho / sum_partials(part_ptq, n_part, red);
-  double a_rr = 0.0, a_rho = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    x[i] = fma(alpha, p[i], x[i]);
-    const double rn = fma(-alpha, q[i], r[i]);
-    const double rtn = fma(-alpha, qt[i], rt[i]);
-    r[i] = rn;
-    rt[i] = rtn;
-    a_rr = fma(rn, rn, a_rr);
-    a_rho = fma(rtn, rn, a_rho);
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p), *q2 = reinterpret_cast<const dbl2 *>(q),
+             *qt2 = reinterpret_cast<const dbl2 *>(qt);
+  dbl2 *x2 = reinterpret_cast<dbl2 *>(x), *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
+  double a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 pv = p2[i], qv = q2[i], qtv = qt2[i];
+    dbl2 xv = x2[i], rv = r2[i], rtv = rt2[i];
+    xv.x = fma(alpha, pv.x, xv.x);
+    xv.y = fma(alpha, pv.y, xv.y);
+    rv.x = fma(-alpha, qv.x, rv.x);
+    rv.y = fma(-alpha, qv.y, rv.y);
+    rtv.x = fma(-alpha, qtv.x, rtv.x);
+    rtv.y = fma(-alpha, qtv.y, rtv.y);
+    x2[i] = xv;
+    r2[i] = rv;
+    rt2[i] = rtv;
+    a_rr0 = fma(rv.x, rv.x, a_rr0);
+    a_rr1 = fma(rv.y, rv.y, a_rr1);
+    a_rho0 = fma(rtv.x, rv.x, a_rho0);
+    a_rho1 = fma(rtv.y, rv.y, a_rho1);
+  }
+  if (owns_tail(n)) {
+    x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
+    const double rn = fma(-alpha, q[n - 1], r[n - 1]);
+    const double rtn = fma(-alpha, qt[n - 1], rt[n - 1]);
+    r[n - 1] = rn;
+    rt[n - 1] = rtn;
+    a_rr0 = fma(rn, rn, a_rr0);
+    a_rho0 = fma(rtn, rn, a_rho0);
   }
   __syncthreads();
-  const double s1 = wg_sum(a_rr, red);
+  const double s1 = wg_sum(a_rr0 + a_rr1, red);
   __syncthreads();
-  const double s2 = wg_sum(a_rho, red);
+  const double s2 = wg_sum(a_rho0 + a_rho1, red);
   if (threadIdx.x == 0) { part_rr[blockIdx.x] = s1; part_rho[blockIdx.x] = s2; }
 }
 
@@ -200,11 +267,24 @@ __global__ void k_bicg_update_p(int64_t n, const double *__restrict__ part_rr, c
   }
   const double rho_new = sum_partials(part_rho, n_part, red);
   const double beta = rho_new / *rho;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    p[i] = fma(beta, p[i], r[i]);
-    pt[i] = fma(beta, pt[i], rt[i]);
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt);
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 rv = r2[i], rtv = rt2[i];
+    dbl2 pv = p2[i], ptv = pt2[i];
+    pv.x = fma(beta, pv.x, rv.x);
+    pv.y = fma(beta, pv.y, rv.y);
+    ptv.x = fma(beta, ptv.x, rtv.x);
+    ptv.y = fma(beta, ptv.y, rtv.y);
+    p2[i] = pv;
+    pt2[i] = ptv;
+  }
+  if (owns_tail(n)) {
+    p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
+    pt[n - 1] = fma(beta, pt[n - 1], rt[n - 1]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { *rho_out = rho_new; *iters = iter; }
 }
+#undef CASK_PAIR_LOOP
 
 }  // namespace caskhip

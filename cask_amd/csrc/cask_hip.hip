@@ -93,6 +93,7 @@ struct Plan {
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
+  DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y (allocated on first use)
   // VECTOR
   DevBuf<int2v> xspan;
 };
@@ -112,6 +113,9 @@ struct cask_hip_matrix {
   int max_row = 0, empty_rows = 0;
   cask_hip_params requested{};
   Plan plan;
+  // row-sharded product (cask_hip_p2p.h): columns >= halo_n_own are read from the addresses in halo_addr
+  int halo_n_own = std::numeric_limits<int>::max();
+  const uint64_t *halo_addr = nullptr;
   hipStream_t stream = nullptr;    // for the host-vector entry points and timing
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
   std::unique_ptr<cask_hip_matrix> transpose;
@@ -138,7 +142,9 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE &&
       out.variant != CASK_HIP_VARIANT_MERGE_WAVE)
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
-  if (m.nnz < 2) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
+  if (m.halo_addr && out.variant != CASK_HIP_VARIANT_MERGE)
+    return fail(CASK_HIP_ERR_INVALID, "a matrix with halo sources runs the MERGE variant only");
+  if (m.nnz < 2 && !m.halo_addr) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
   if (out.lanes_per_row == 0) {
     int l = pow2_floor(std::max(1, (int)std::lround(mean / 4.0)));
     out.lanes_per_row = std::min(64, std::max(out.variant == CASK_HIP_VARIANT_VECTOR ? 2 : 1, l));
@@ -292,6 +298,50 @@ void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks,
   }
 }
 
+// Host twin of logical_block() (spmv_kernels.hpp).
+int logical_block_host(int hw, int n, bool remap) {
+  if (!remap) return hw;
+  const int xcd = hw & 7, idx = hw >> 3, q = n >> 3, rem = n & 7;
+  return xcd * q + std::min(xcd, rem) + idx;
+}
+
+// Sharded product: record every block's largest column in aux (the kernel's seam test) and move the
+// seam blocks -- the ones that read halo columns, i.e. wait for a round trip over xGMI -- to the slots
+// that are dispatched first, so that their longer life overlaps the rest of the launch instead of
+// extending its tail.  chunk_starts (may be empty) is permuted alongside.
+void place_seam_blocks(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks,
+                       std::vector<std::vector<int>> &chunk_starts, bool remap) {
+  const int nb = (int)blocks.size();
+  const int *ci = m.h_ci.data();
+  std::vector<int> seam;
+  for (int b = 0; b < nb; b++) {
+    BlockDesc &d = blocks[b];
+    if (d.kind_g & KIND_LONG) continue;                       // long-row pieces test every column themselves
+    int cmax = -1;
+    for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++) cmax = std::max(cmax, ci[k]);
+    d.aux = cmax;
+    if (cmax >= m.halo_n_own) seam.push_back(b);
+  }
+  if (seam.empty() || (int)seam.size() > nb / 4) return;      // halo everywhere: no order helps
+  std::vector<char> is_seam(nb, 0), is_target(nb, 0);
+  for (int b : seam) is_seam[b] = 1;
+  std::vector<int> targets;
+  for (int hw = 0; hw < (int)seam.size(); hw++) {
+    const int lb = logical_block_host(hw, nb, remap);
+    targets.push_back(lb);
+    is_target[lb] = 1;
+  }
+  size_t ti = 0;
+  for (int b : seam) {
+    if (is_target[b]) continue;                               // already in an early slot
+    while (ti < targets.size() && is_seam[targets[ti]]) ti++; // that slot holds a seam block: leave it
+    if (ti == targets.size()) break;
+    const int t = targets[ti++];
+    std::swap(blocks[b], blocks[t]);
+    if (!chunk_starts.empty()) std::swap(chunk_starts[b], chunk_starts[t]);
+  }
+}
+
 template <int IPT>
 const void *merge_wave_fn(bool nt) {
   return nt ? reinterpret_cast<const void *>(&k_spmv_merge_wave<IPT, true>)
@@ -321,6 +371,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
+  pl.dot_part.release();
   pl.xspan.release();
   pl.n_long_rows = pl.n_split_rows = 0;
   pl.grid = 0;
@@ -389,6 +440,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       std::vector<std::vector<int>> chunk_starts;
       std::vector<unsigned short> ci16;
       build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16);
+      if (m.halo_addr) place_seam_blocks(m, blocks, chunk_starts, prm.xcd_remap > 0);
       int max_chunks = 0;
       for (const auto &c : chunk_starts) max_chunks = std::max(max_chunks, (int)c.size());
       if (max_chunks > 0) {
@@ -402,8 +454,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
           std::copy(chunk_starts[b].begin(), chunk_starts[b].end(), xchunk.begin() + b * pl.maxch);
         HIP_TRY(pl.xchunk.upload(xchunk));
         HIP_TRY(pl.ci16.upload(ci16));
-        HIP_TRY(pl.blocks.upload(blocks));             // cwidth now holds the slots each block uses
       }
+      HIP_TRY(pl.blocks.upload(blocks));               // cwidth now holds the slots each block uses
     } else if (tile > 0 && m.nnz > 0) {
       // 32-bit indices: one contiguous window per block
       hipLaunchKernelGGL(k_col_span_blocks, dim3(pl.grid), dim3(256), 0, m.stream, pl.blocks.p, pl.grid, m.d_ci);
@@ -422,6 +474,19 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       }
       pl.xu = xu;
       if (xu > 0) pl.prm.tile_width = xu * prm.wg_size;
+      if (m.halo_addr) {
+        int rc2 = ensure_host_col_ind(m);
+        if (rc2) return rc2;
+        std::vector<std::vector<int>> none;
+        place_seam_blocks(m, blocks, none, prm.xcd_remap > 0);
+        HIP_TRY(pl.blocks.upload(blocks));
+      }
+    } else if (m.halo_addr && m.nnz > 0) {
+      int rc2 = ensure_host_col_ind(m);
+      if (rc2) return rc2;
+      std::vector<std::vector<int>> none;
+      place_seam_blocks(m, blocks, none, prm.xcd_remap > 0);
+      HIP_TRY(pl.blocks.upload(blocks));
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
     pl.ldsx = pl.xu > 0;
@@ -470,15 +535,16 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
 }
 
 template <int IPT, int XU>
-void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot) {
   const Plan &pl = m.plan;
   const dim3 grid(pl.grid), block(pl.prm.wg_size);
   const int remap = pl.prm.xcd_remap > 0;
   const unsigned *ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
+  const XHalo halo{m.halo_n_own, m.halo_addr};
 #define CASK_LAUNCH_M(NT, C16, SKEW)                                                                        \
   hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, SKEW>), grid, block, pl.lds_bytes, s, pl.blocks.p,     \
                      pl.grid, remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, pl.xchunk.p, pl.maxch, m.d_val,  \
-                     x, y, pl.partials.p)
+                     x, y, pl.partials.p, halo, dot)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = pl.prm.nontemporal > 0 || pl.any_skew;
   if (XU > 0 && ci16) {
@@ -494,18 +560,20 @@ void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipSt
 }
 
 template <int IPT>
-int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
+int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot) {
   const Plan &pl = m.plan;
   switch (pl.xu) {
-    case 0:  launch_merge_ix<IPT, 0>(m, x, y, s); break;
-    case 1:  launch_merge_ix<IPT, 1>(m, x, y, s); break;
-    case 2:  launch_merge_ix<IPT, 2>(m, x, y, s); break;
-    case 4:  launch_merge_ix<IPT, 4>(m, x, y, s); break;
-    default: launch_merge_ix<IPT, 8>(m, x, y, s); break;
+    case 0:  launch_merge_ix<IPT, 0>(m, x, y, s, dot); break;
+    case 1:  launch_merge_ix<IPT, 1>(m, x, y, s, dot); break;
+    case 2:  launch_merge_ix<IPT, 2>(m, x, y, s, dot); break;
+    case 4:  launch_merge_ix<IPT, 4>(m, x, y, s, dot); break;
+    default: launch_merge_ix<IPT, 8>(m, x, y, s, dot); break;
   }
-  if (pl.n_split_rows > 0)
+  if (pl.n_split_rows > 0) {
+    const DotEpilogue fix{dot.w, dot.w ? dot.dot_part + pl.grid : nullptr};
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
-                       pl.n_split_rows, pl.partials.p, y);
+                       pl.n_split_rows, pl.partials.p, y, fix);
+  }
   return CASK_HIP_OK;
 }
 
@@ -532,12 +600,22 @@ int launch_merge_wave_i(const cask_hip_matrix &m, const double *x, double *y, hi
   }
   if (pl.n_split_rows > 0)
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
-                       pl.n_split_rows, pl.partials.p, y);
+                       pl.n_split_rows, pl.partials.p, y, DotEpilogue{nullptr, nullptr});
   return CASK_HIP_OK;
 }
 
-int launch_spmv(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
-  const Plan &pl = m.plan;
+// The merge kernel can leave the shares of w.y behind (one per block + one per split row).
+bool plan_fuses_dot(const Plan &pl) { return pl.prm.variant == CASK_HIP_VARIANT_MERGE && pl.grid > 0; }
+int dot_part_count(const Plan &pl) { return pl.grid + pl.n_split_rows; }
+
+// y = A x; with w != NULL (MERGE plans only) also plan.dot_part[0 .. dot_part_count) = shares of w.y
+int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const double *w = nullptr) {
+  Plan &pl = m.plan;
+  if (w) {
+    if (!plan_fuses_dot(pl)) return fail(CASK_HIP_ERR_INVALID, "this design point has no fused dot epilogue");
+    if (!pl.dot_part.p) HIP_TRY(pl.dot_part.alloc((size_t)dot_part_count(pl)));
+  }
+  const DotEpilogue dot{w, w ? pl.dot_part.p : nullptr};
   if (m.n_rows == 0 || (pl.grid == 0 && pl.n_long_blocks == 0)) return CASK_HIP_OK;
   if (pl.prm.variant == CASK_HIP_VARIANT_MERGE_WAVE) {
     switch (pl.prm.items_per_thread) {
@@ -561,10 +639,10 @@ int launch_spmv(const cask_hip_matrix &m, const double *x, double *y, hipStream_
     }
   } else {
     switch (pl.prm.items_per_thread) {
-      case 2:  launch_merge_i<2>(m, x, y, s); break;
-      case 4:  launch_merge_i<4>(m, x, y, s); break;
-      case 8:  launch_merge_i<8>(m, x, y, s); break;
-      default: launch_merge_i<16>(m, x, y, s); break;
+      case 2:  launch_merge_i<2>(m, x, y, s, dot); break;
+      case 4:  launch_merge_i<4>(m, x, y, s, dot); break;
+      case 8:  launch_merge_i<8>(m, x, y, s, dot); break;
+      default: launch_merge_i<16>(m, x, y, s, dot); break;
     }
   }
   HIP_TRY(hipGetLastError());
@@ -759,6 +837,47 @@ int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, voi
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   if ((m->n_cols > 0 && !d_x) || (m->n_rows > 0 && !d_y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
   return launch_spmv(*m, d_x, d_y, static_cast<hipStream_t>(stream));
+}
+
+int cask_hip_spmv_dot_device(cask_hip_matrix *m, const double *d_x, double *d_y, const double *d_w, double *d_result,
+                             void *stream) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  if ((m->n_cols > 0 && !d_x) || (m->n_rows > 0 && (!d_y || !d_w)) || !d_result)
+    return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan_fuses_dot(m->plan)) {
+    int rc = launch_spmv(*m, d_x, d_y, s, d_w);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(BLAS_WG), 0, s, dot_part_count(m->plan), m->plan.dot_part.p, d_result,
+                       0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    return CASK_HIP_OK;
+  }
+  int rc = launch_spmv(*m, d_x, d_y, s);
+  if (rc) return rc;
+  return cask_hip_ddot_device(m->n_rows, d_w, d_y, d_result, stream);
+}
+
+int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint64_t *d_src_addr) {
+  if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+  if (!d_src_addr) {                                          // back to the plain layout
+    m->halo_n_own = std::numeric_limits<int>::max();
+    m->halo_addr = nullptr;
+    return CASK_HIP_OK;
+  }
+  if (n_own < 1 || n_own > m->n_cols) return fail(CASK_HIP_ERR_INVALID, "n_own must lie in [1, n_cols]");
+  if (m->plan.prm.variant != CASK_HIP_VARIANT_MERGE || m->nnz < 2)
+    return fail(CASK_HIP_ERR_INVALID, "halo sources need the MERGE variant (and at least 2 nonzeros)");
+  m->halo_n_own = n_own;
+  m->halo_addr = d_src_addr;
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = build_plan(*m, m->requested);                      // seam blocks get flagged and dispatched first
+  if (rc) {
+    m->halo_n_own = std::numeric_limits<int>::max();
+    m->halo_addr = nullptr;
+    (void)build_plan(*m, m->requested);
+  }
+  return rc;
 }
 
 int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
@@ -1008,12 +1127,22 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   int h_flags[2] = {0, 0};
   int launched = 0;
   double clean_us = 0.0;
+  const bool fused = plan_fuses_dot(m->plan);
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
-    rc = launch_spmv(*m, p.p, Ap.p, s);                                                 // :206
+    // Ap = A p (:206); with a MERGE plan the shares of p.Ap fall out of the same launch
+    const double *pAp_part = partials.p;
+    int n_pAp = g;
+    if (fused) {
+      rc = launch_spmv(*m, p.p, Ap.p, s, p.p);
+      pAp_part = m->plan.dot_part.p;
+      n_pAp = dot_part_count(m->plan);
+    } else {
+      rc = launch_spmv(*m, p.p, Ap.p, s);
+      hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
+    }
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
-    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, partials.p, g, p.p, Ap.p, dx.p, r.p, partials_rr.p,
+    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rr.p,
                        (const int *)done);                                              // :208-218
     hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rr.p, g, rsold, rsnew, tol * tol, i, r.p, p.p, done,
                        iters);                                                          // :220-231
@@ -1085,14 +1214,24 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   int h_flags[2] = {0, 0};
   int launched = 0;
   double clean_us = 0.0;
+  const bool fused = plan_fuses_dot(m->plan);
   for (int i = 0; i < maxiters; i++) {
     double *rho_old = rho[i & 1], *rho_new = rho[(i + 1) & 1];
-    rc = launch_spmv(*m, p.p, q.p, s);
+    // q = A p with the shares of pt.q from the same launch (MERGE plans); qt = A^T pt
+    const double *ptq_part = part_c.p;
+    int n_ptq = g;
+    if (fused) {
+      rc = launch_spmv(*m, p.p, q.p, s, pt.p);
+      ptq_part = m->plan.dot_part.p;
+      n_ptq = dot_part_count(m->plan);
+    } else {
+      rc = launch_spmv(*m, p.p, q.p, s);
+    }
     if (rc) return rc;
     rc = launch_spmv(mt, pt.p, qt.p, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_c.p, (const int *)done);
-    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, part_c.p, g, p.p, q.p, qt.p, dx.p, r.p, rt.p,
+    if (!fused) hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_c.p, (const int *)done);
+    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, ptq_part, n_ptq, p.p, q.p, qt.p, dx.p, r.p, rt.p,
                        part_a.p, part_b.p, (const int *)done);
     hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, part_a.p, part_b.p, g, rho_old, rho_new, tol * tol, i, r.p,
                        rt.p, p.p, pt.p, done, iters);

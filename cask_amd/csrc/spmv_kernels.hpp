@@ -40,7 +40,7 @@ struct BlockDesc {
   int32_t cmin;        // smallest column referenced (x window start)
   int32_t cwidth;      // window width in doubles (0 when the block has no nonzeros)
   int32_t kind_g;      // bits 0-7: lanes per row in the reduce phase; bit 8: long-row piece; bit 9: piece writes a partial
-  int32_t aux;         // long-row piece: slot in the partials buffer
+  int32_t aux;         // long-row piece: slot in the partials buffer; other blocks: largest column referenced
 };
 constexpr int KIND_LONG = 0x100;
 constexpr int KIND_PARTIAL = 0x200;
@@ -49,6 +49,30 @@ constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutiv
 
 struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
   int32_t row, first_slot, n_slots, pad;
+};
+
+// Where a launch reads x from.  Without a halo every column comes from x[] (n_own = INT_MAX,
+// haddr = NULL).  With one (row-sharded product, include/cask_hip_p2p.h) columns >= n_own are
+// halo columns: column n_own + j is read from the absolute device address haddr[j], which may
+// lie in a peer GPU's shared slice -- the remote load over xGMI happens inside the product
+// kernel, so the sharded product is one launch with no exchange step in front of it.
+struct XHalo {
+  int n_own;
+  const uint64_t *haddr;
+};
+// Two steps so that a lane's loads stay batched: first the table entries of all its columns (entry 0
+// for own columns: harmless, one cached line), then the values from wherever they live.
+__device__ __forceinline__ uint64_t halo_entry(int col, const XHalo &h) { return h.haddr[max(col - h.n_own, 0)]; }
+__device__ __forceinline__ uint64_t halo_source(const double *x, int col, uint64_t entry, const XHalo &h) {
+  return col < h.n_own ? reinterpret_cast<uint64_t>(x + col) : entry;
+}
+
+// Optional epilogue of the merge kernel: dot_part[block] = sum over the block's rows of
+// w[row] * y[row] (fixed order => reproducible), so that the p.Ap of a CG iteration costs no
+// extra pass over the vectors.  w = NULL switches it off.
+struct DotEpilogue {
+  const double *w;
+  double *dot_part;
 };
 
 // ---------------------------------------------------------------- cross-lane
@@ -189,14 +213,14 @@ __global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width,
 // (power-law blocks: a 500-nonzero row among 3-nonzero rows would otherwise keep one lane busy for
 // microseconds while 255 idle).  The host flags such blocks (KIND_SKEW); others pay one compare.
 constexpr int SKEW_FACTOR = 32;
-constexpr int SKEW_LIST = 64;         // queue capacity; entry [SKEW_LIST] is the counter
 
 template <int G>
-__device__ __forceinline__ void reduce_rows_plain(const BlockDesc &d, const double *prod, const int *roff,
-                                                  double *__restrict__ y) {
+__device__ __forceinline__ double reduce_rows_plain(const BlockDesc &d, const double *prod, const int *roff,
+                                                    double *__restrict__ y, const double *__restrict__ w) {
   const int tid = threadIdx.x;
   const int rows_per_pass = blockDim.x / G;
   const int j = tid & (G - 1);
+  double dsum = 0.0;
   for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
     const int r = r0 + tid / G;
     double acc = 0.0;
@@ -206,40 +230,32 @@ __device__ __forceinline__ void reduce_rows_plain(const BlockDesc &d, const doub
       for (int k = s + j; k < e; k += G) acc += prod[k];
     }
     acc = group_sum<G>(acc);
-    if (j == 0 && r < d.n_rows) y[d.row_start + r] = acc;
+    if (j == 0 && r < d.n_rows) {
+      y[d.row_start + r] = acc;
+      if (w) dsum = fma(w[d.row_start + r], acc, dsum);       // workgroup-uniform test
+    }
   }
+  return dsum;
 }
 
 template <int G, bool SKEW>
-__device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
-                                            double *__restrict__ y, int *skew_list) {
+__device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
+                                              double *__restrict__ y, const double *__restrict__ w) {
   const bool skew = SKEW && (d.kind_g & KIND_SKEW);           // workgroup-uniform
-  if (!skew) {                                                // the common case keeps the lean loop
-    reduce_rows_plain<G>(d, prod, roff, y);
-    return;
-  }
+  if (!skew)                                                  // the common case keeps the lean loop
+    return reduce_rows_plain<G>(d, prod, roff, y, w);
   const int tid = threadIdx.x;
   const int rows_per_pass = blockDim.x / G;
   const int j = tid & (G - 1);
+  double dsum = 0.0;
+  // pass 1: rows of ordinary length, G lanes each; long rows are left to pass 2
   for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
     const int r = r0 + tid / G;
     double acc = 0.0;
     bool mine = r < d.n_rows;
     if (mine) {
       const int s = roff[r], e = roff[r + 1];
-      bool deferred = false;
-      if (skew && e - s > SKEW_FACTOR * G) {
-        // long row: lane 0 of the group queues it for the wave-per-row pass (the queue holds 64 rows;
-        // when it is full the row is summed here after all)
-        int slot = SKEW_LIST;
-        if (j == 0) slot = atomicAdd(&skew_list[SKEW_LIST], 1);
-        if (G > 1) slot = __shfl(slot, (tid & 63) & ~(G - 1));
-        if (slot < SKEW_LIST) {
-          if (j == 0) skew_list[slot] = r;
-          deferred = true;
-        }
-      }
-      if (deferred) {
+      if (e - s > SKEW_FACTOR * G) {
         mine = false;
       } else {
 #pragma unroll 4
@@ -247,15 +263,26 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
       }
     }
     acc = group_sum<G>(acc);
-    if (j == 0 && mine) y[d.row_start + r] = acc;
+    if (j == 0 && mine) {
+      y[d.row_start + r] = acc;
+      if (w) dsum = fma(w[d.row_start + r], acc, dsum);
+    }
   }
-  if (skew) {
-    __syncthreads();                                          // queue complete
-    const int queued = min(skew_list[SKEW_LIST], SKEW_LIST);
-    const int lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    for (int q = wave; q < queued; q += n_waves) {            // wave-uniform
-      const int r = skew_list[q];
-      const int s = roff[r], e = roff[r + 1];
+  // pass 2: a whole wave per long row.  Every wave scans the row lengths 64 at a time (one ballot per
+  // chunk) and takes the long rows round-robin IN ROW ORDER, so which wave sums which row -- and with it
+  // the order of every floating-point addition -- is a function of the matrix alone (no queue, no atomics).
+  const int lane = tid & 63, wave = tid >> 6, wave_mask = (blockDim.x >> 6) - 1;
+  int seen = 0;
+  for (int c0 = 0; c0 < d.n_rows; c0 += 64) {                 // workgroup-uniform
+    const int r = c0 + lane;
+    const bool is_long = r < d.n_rows && roff[r + 1] - roff[r] > SKEW_FACTOR * G;
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {                                            // wave-uniform
+      const int b = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      if (((seen++) & wave_mask) != wave) continue;
+      const int row = c0 + b;
+      const int s = roff[row], e = roff[row + 1];
       double a0 = 0.0, a1 = 0.0;
       int k = s + lane;
       for (; k + 64 < e; k += 128) {
@@ -264,9 +291,13 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
       }
       if (k < e) a0 += prod[k];
       const double acc = group_sum<64>(a0 + a1);
-      if (lane == 0) y[d.row_start + r] = acc;
+      if (lane == 0) {
+        y[d.row_start + row] = acc;
+        if (w) dsum = fma(w[d.row_start + row], acc, dsum);
+      }
     }
   }
+  return dsum;
 }
 
 // One block of the merge kernel, straight-line so that hipcc can count the
@@ -284,15 +315,21 @@ __device__ __forceinline__ void reduce_rows(const BlockDesc &d, const double *pr
 // 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
 // per nonzero and already LDS offsets -- the stream shrinks from 12 to 10
 // bytes per nonzero, which on a bandwidth-bound kernel is the whole game.
-template <int IPT, int XU, bool NT, bool C16, bool SKEW>
-__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int max_gpair,
-                                            const int *__restrict__ rp, const int *__restrict__ ci,
-                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
-                                            const double *__restrict__ val, const double *__restrict__ x,
-                                            double *__restrict__ y, double *prod, int *roff, double *xs,
-                                            int *skew_list) {
+//
+// Sharded product (SEAM = true, only for blocks that read halo columns; cask_hip_p2p.h): the block
+// fetches the address-table entries of its window first, issues its stream like any block, then the
+// window loads themselves -- some of them remote: one local and one xGMI round trip, overlapped with
+// the stream.  A separate instantiation, so the code of every other block is exactly the one above.
+typedef __attribute__((address_space(1))) const double gdouble;
+__device__ __forceinline__ double load_at(uint64_t addr) { return *reinterpret_cast<gdouble *>(addr); }
+
+template <int IPT, int XU, bool NT, bool C16, bool SEAM>
+__device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+                                           const int *__restrict__ rp, const int *__restrict__ ci,
+                                           const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                           const double *__restrict__ val, const double *__restrict__ x,
+                                           double *prod, int *roff, double *xs, const XHalo &halo) {
   const int WG = blockDim.x, tid = threadIdx.x;
-  if (SKEW && (d.kind_g & KIND_SKEW) && tid == 0) skew_list[SKEW_LIST] = 0;   // read only after the products barrier
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -311,14 +348,26 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // the special case of consecutive chunks; stencil-like matrices (a few narrow bands far apart)
   // fit the same way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
   double xw[XU > 0 ? XU : 1];
+  uint64_t xsrc[XU > 0 ? XU : 1];
   if (XU > 0) {
-    if (C16 && !(d.kind_g & KIND_CONTIG)) {                   // workgroup-uniform
+    if (SEAM) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+      const bool chunked = C16 && !(d.kind_g & KIND_CONTIG);
+      int col[XU > 0 ? XU : 1];
+#pragma unroll
+      for (int u = 0; u < XU; u++) {
+        col[u] = min(chunked ? xchunk[u * wpw + wave] + lane : d.cmin + u * WG + tid, n_cols - 1);
+        xsrc[u] = halo_entry(col[u], halo);
+      }
+#pragma unroll
+      for (int u = 0; u < XU; u++) xsrc[u] = halo_source(x, col[u], xsrc[u], halo);
+    } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
 #pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, n_cols - 1)];
+      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, xlim)];
     } else {                                                  // one window: no chunk table on the critical path
 #pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, n_cols - 1)];
+      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, xlim)];
     }
   }
   const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
@@ -342,6 +391,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
       c[u] = stream_load<NT>(ci2 + p);
     }
   }
+  if (XU > 0 && SEAM) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xw[u] = load_at(xsrc[u]);
+  }
 
   CASK_STAMP(1);
   if (XU > 0) {
@@ -362,12 +415,27 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
       if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
   }
   dbl2 xv[IPT / 2];
+  if (XU > 0) {
 #pragma unroll
-  for (int u = 0; u < IPT / 2; u++) {
-    if (XU > 0) {
+    for (int u = 0; u < IPT / 2; u++) {
       xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
       xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
-    } else {
+    }
+  } else if (SEAM) {                                          // gathers, some of them from peers
+    uint64_t ex[IPT / 2], ey[IPT / 2];
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      ex[u] = halo_entry(c[u].x, halo);
+      ey[u] = halo_entry(c[u].y, halo);
+    }
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = load_at(halo_source(x, c[u].x, ex[u], halo));
+      xv[u].y = load_at(halo_source(x, c[u].y, ey[u], halo));
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
       xv[u].x = x[c[u].x];
       xv[u].y = x[c[u].y];
     }
@@ -383,15 +451,42 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
   __syncthreads();
   CASK_STAMP(4);
+}
 
+template <int IPT, int XU, bool NT, bool C16, bool SKEW>
+__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+                                            const int *__restrict__ rp, const int *__restrict__ ci,
+                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                            const double *__restrict__ val, const double *__restrict__ x,
+                                            double *__restrict__ y, double *prod, int *roff, double *xs,
+                                            const XHalo &halo, const DotEpilogue &dot, int lb) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column
+  if (halo.haddr != nullptr && d.aux >= halo.n_own)           // workgroup-uniform; never taken without a halo
+    merge_load<IPT, XU, NT, C16, true>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs, halo);
+  else
+    merge_load<IPT, XU, NT, C16, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs, halo);
+
+  double dsum;
   switch (d.kind_g & 0xff) {
-    case 1:  reduce_rows<1, SKEW>(d, prod, roff, y, skew_list); break;
-    case 2:  reduce_rows<2, SKEW>(d, prod, roff, y, skew_list); break;
-    case 4:  reduce_rows<4, SKEW>(d, prod, roff, y, skew_list); break;
-    case 8:  reduce_rows<8, SKEW>(d, prod, roff, y, skew_list); break;
-    case 16: reduce_rows<16, SKEW>(d, prod, roff, y, skew_list); break;
-    case 32: reduce_rows<32, SKEW>(d, prod, roff, y, skew_list); break;
-    default: reduce_rows<64, SKEW>(d, prod, roff, y, skew_list); break;
+    case 1:  dsum = reduce_rows<1, SKEW>(d, prod, roff, y, dot.w); break;
+    case 2:  dsum = reduce_rows<2, SKEW>(d, prod, roff, y, dot.w); break;
+    case 4:  dsum = reduce_rows<4, SKEW>(d, prod, roff, y, dot.w); break;
+    case 8:  dsum = reduce_rows<8, SKEW>(d, prod, roff, y, dot.w); break;
+    case 16: dsum = reduce_rows<16, SKEW>(d, prod, roff, y, dot.w); break;
+    case 32: dsum = reduce_rows<32, SKEW>(d, prod, roff, y, dot.w); break;
+    default: dsum = reduce_rows<64, SKEW>(d, prod, roff, y, dot.w); break;
+  }
+  if (dot.w) {                                                // launch-uniform: the block's share of w.y
+    dsum = group_sum<64>(dsum);
+    __syncthreads();                                          // every wave is done reading prod
+    if ((tid & 63) == 0) prod[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int wv = 0; wv < (WG >> 6); wv++) s += prod[wv];
+      dot.dot_part[lb] = s;
+    }
   }
 }
 
@@ -402,10 +497,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
-                             double *__restrict__ y, double *__restrict__ partials) {
+                             double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int skew_list[SKEW ? SKEW_LIST + 1 : 1];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
@@ -429,8 +523,16 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
         c[u] = stream_load<NT>(ci + kk);
         v[u] = stream_load<NT>(val + kk);
       }
+      if (halo.haddr) {                                       // launch-uniform
+        uint64_t ent[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+        for (int u = 0; u < 4; u++) ent[u] = halo_entry(c[u], halo);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = load_at(halo_source(x, c[u], ent[u], halo));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+      }
 #pragma unroll
       for (int u = 0; u < 4; u++)
         if (k + u * WG < end) acc = fma(v[u], xv[u], acc);
@@ -441,16 +543,27 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
     if (tid == 0) {
       double s = 0.0;
       for (int w = 0; w < (WG >> 6); w++) s += prod[w];
-      if (d.kind_g & KIND_PARTIAL) partials[d.aux] = s; else y[d.row_start] = s;
+      if (d.kind_g & KIND_PARTIAL) {
+        partials[d.aux] = s;
+        if (dot.w) dot.dot_part[lb] = 0.0;                    // the fix-up kernel owns this row's share
+      } else {
+        y[d.row_start] = s;
+        if (dot.w) dot.dot_part[lb] = dot.w[d.row_start] * s;
+      }
     }
     return;
   }
 
   const int max_gpair = ((nnz + 1) >> 1) - 1;
+  // last entry of x[] a block without halo columns may touch: its window is padded to whole chunks and
+  // may reach past its largest column, but never past the caller's n_own entries
+  const int xlim = min(n_cols, halo.n_own) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, SKEW>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
+    merge_block<IPT, XU, NT, C16, SKEW>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs,
+                                        halo, dot, lb);
   else
-    merge_block<IPT, 0, NT, false, SKEW>(d, n_cols, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, skew_list);
+    merge_block<IPT, 0, NT, false, SKEW>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs,
+                                         halo, dot, lb);
   CASK_STAMP(5);
 }
 
@@ -676,13 +789,14 @@ __global__ void k_spmv_long(const BlockDesc *__restrict__ blocks, int n_blocks,
 // Sums the pieces of rows that were split over several workgroups, in piece
 // order (deterministic; no float atomics anywhere in the engine).
 __global__ void k_spmv_fixup(const SplitRow *__restrict__ rows, int n, const double *__restrict__ partials,
-                             double *__restrict__ y) {
+                             double *__restrict__ y, DotEpilogue dot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const SplitRow r = rows[i];
   double s = 0.0;
   for (int k = 0; k < r.n_slots; k++) s += partials[r.first_slot + k];
   y[r.row] = s;
+  if (dot.w) dot.dot_part[i] = dot.w[r.row] * s;              // slots behind the blocks' (caller offsets the pointer)
 }
 
 // ------------------------------------------------------------ plan helpers

@@ -80,13 +80,14 @@ class ShardedSpmv:
 
     @classmethod
     def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None,
-                    exchange="all_gather", fence=None):
+                    exchange="all_gather", fence=None, fused_halo=False):
         """Build this rank's block of a globally known CSR matrix on the current GPU.
 
         exchange="all_gather": block with global columns, x all-gathered per product.
         exchange="p2p": block with extended columns [own | halo], halo pulled from the peers' shared
         slices per product (collective construction; raises on every rank if any rank cannot map a peer).
-        ``fence`` orders device work across ranks for the p2p path (default: a 1-element all-reduce)."""
+        ``fence`` orders device work across ranks for the p2p path (default: a 1-element all-reduce).
+        ``fused_halo`` (p2p only): no pull step -- the product kernel loads the halo from the peers."""
         import torch
         from . import capi
         n = len(row_ptr) - 1
@@ -114,6 +115,10 @@ class ShardedSpmv:
             ex = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects, fence)
             mat = capi.CsrMatrix.from_host(n_local, n_local + ex.n_halo, rp, ci_ext, va, params)
             obj = cls(bounds, rank, world, lambda xe, yl: mat.spmv_device(xe, yl), dev, group, exchange=ex)
+            obj.fused_halo = False
+            if fused_halo and mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2:
+                ex.attach(mat)                  # the product kernel reads the halo from the peers itself
+                obj.fused_halo = True
         elif exchange == "all_gather":
             mat = capi.CsrMatrix.from_host(n_local, n_cols, rp, ci, va, params)
             obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
@@ -147,9 +152,13 @@ class ShardedSpmv:
             if x_local.data_ptr() != ex.x_local.data_ptr():
                 ex.x_local.copy_(x_local)
             ex.fence()              # every slice is final ...
-            ex.pull()
-            ex.fence()              # ... and nobody overwrites its slice while a peer still pulls from it
-            self.local_product(ex.x_ext, y_local)
+            if getattr(self, "fused_halo", False):
+                self.local_product(ex.x_ext, y_local)    # remote loads happen inside the product kernel
+            else:
+                ex.pull()
+            ex.fence()              # ... and nobody overwrites its slice while a peer still reads from it
+            if not getattr(self, "fused_halo", False):
+                self.local_product(ex.x_ext, y_local)
             return y_local
         xf = self.gather_x(x_local)
         self.local_product(xf, y_local)

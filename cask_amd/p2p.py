@@ -14,6 +14,10 @@ product the halo is refreshed by ``cask_hip_halo_pull_device``: remote loads
 over xGMI straight from the owners' slices -- no collective and no host on the
 data path, and legal inside a HIP graph.  For banded / stencil matrices the
 halo is a few hundred entries instead of the 8*n bytes of an all-gather.
+``PeerExchange.attach(matrix)`` goes one step further and hands the address
+table to the product kernel (``cask_hip_csr_set_halo_sources``): the workgroups
+at a seam stage their x window with remote loads themselves, and a sharded
+product is a single launch.
 
 The caller orders accesses across ranks (a peer must have finished writing its
 slice before it is pulled, and must not overwrite it while someone pulls):
@@ -35,7 +39,8 @@ from . import capi
 
 HANDLE_BYTES = 64
 P2P_SYMBOLS = ("cask_hip_shared_alloc", "cask_hip_shared_free", "cask_hip_shared_open", "cask_hip_shared_close",
-               "cask_hip_copy_to_device", "cask_hip_copy_to_host", "cask_hip_halo_pull_device")
+               "cask_hip_copy_to_device", "cask_hip_copy_to_host", "cask_hip_halo_pull_device",
+               "cask_hip_csr_set_halo_sources")
 
 
 def _lib():
@@ -49,6 +54,7 @@ def _lib():
         L.cask_hip_copy_to_device.argtypes = [vp, vp, i64]
         L.cask_hip_copy_to_host.argtypes = [vp, vp, i64]
         L.cask_hip_halo_pull_device.argtypes = [i64, vp, vp, vp]
+        L.cask_hip_csr_set_halo_sources.argtypes = [vp, ctypes.c_int32, vp]
         for s in P2P_SYMBOLS:
             getattr(L, s).restype = ctypes.c_int
         L._p2p_bound = True
@@ -209,6 +215,13 @@ class PeerExchange:
         if self.n_halo:
             capi._check(_lib().cask_hip_halo_pull_device(self.n_halo, c_void_p(self.addr.data_ptr()),
                                                          c_void_p(self._halo_ptr), c_void_p(capi._stream_ptr(stream))))
+
+    def attach(self, matrix):
+        """Fold the exchange into ``matrix``'s product kernel (``cask_hip_csr_set_halo_sources``): its halo
+        columns are then read straight from the owners' slices by the kernel, and ``pull`` is not needed
+        for products of that handle.  ``matrix`` is a ``capi.CsrMatrix`` with the extended column layout."""
+        if self.n_halo:
+            matrix.set_halo_sources(self.n_local, self.addr)
 
     def fence(self):
         if self.fence_fn is not None:

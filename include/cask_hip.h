@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 1
+#define CASK_HIP_ABI_VERSION 2
 
 /* status codes */
 #define CASK_HIP_OK               0
@@ -135,6 +135,15 @@ int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y);
  * stream), asynchronously.  This is the device run function alone, the
  * counterpart of the timed region in Spmv.cpp:270-285. */
 int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream);
+
+/* y = A x and *d_result = w . y in one pass (device vectors, asynchronous on `stream`): with a
+ * MERGE design point every workgroup leaves its rows' share of the dot behind and a one-workgroup
+ * kernel adds the shares in block order (reproducible); other design points run the product and
+ * the dot separately.  This is the "Ap = A p; alpha = rsold / (p.Ap)" pair of the reference's CG
+ * (mkl_dcsrsymv + cblas_ddot, src/runtime/SparseLinearSolvers.hpp:206-208) without the second
+ * pass over p and Ap; cask_hip_cg / cask_hip_bicg use the same epilogue internally. */
+int cask_hip_spmv_dot_device(cask_hip_matrix *m, const double *d_x, double *d_y, const double *d_w,
+                             double *d_result, void *stream);
 
 /* y = A^T x (device vectors; x has n_rows entries, y n_cols).  Built on first
  * use as a second CSR (explicit transpose, no atomics).  No reference

@@ -19,6 +19,8 @@
 
 #include <stdint.h>
 
+#include "cask_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -46,6 +48,19 @@ int cask_hip_copy_to_host(void *h_dst, const void *d_src, int64_t bytes);
  * absolute device addresses (own or peer allocations, 8-byte aligned), built once per
  * matrix from the opened base pointers.  Asynchronous on `stream`. */
 int cask_hip_halo_pull_device(int64_t n_halo, const uint64_t *d_src_addr, double *d_dst, void *stream);
+
+/* Fold the exchange into the product kernel.  After this call the columns >= n_own of `m` are
+ * halo columns: column n_own + j is read from *(const double *)d_src_addr[j] by the product
+ * kernel itself (the x window of a workgroup at a seam is staged with remote loads; everything
+ * else is untouched), so a sharded product is ONE launch: no pull kernel, no launch boundary,
+ * no copy of the halo.  The x argument of a product then only needs its first n_own entries.
+ * d_src_addr is a DEVICE array of n_cols - n_own absolute addresses (own or peer allocations,
+ * 8-byte aligned), borrowed until the handle is destroyed or the call is repeated; NULL
+ * returns the handle to the plain layout.  MERGE design points only.  The caller orders
+ * accesses across ranks exactly as for cask_hip_halo_pull_device.  Takes the place of the
+ * per-controller x upload of Spmv::spmv (src/runtime/Spmv.cpp:144-183): there every pipe gets
+ * its own copy of x through dramWrite, here a rank reads the entries it needs where they live. */
+int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint64_t *d_src_addr);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,8 @@ def _worker(rank, world, port, case, out):
             dist.barrier()
 
         sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, balance=case.get("balance", "nnz"),
-                                           exchange="p2p", fence=fence)
+                                           exchange="p2p", fence=fence, fused_halo=case.get("fused", False))
+        assert sh.fused_halo == bool(case.get("fused", False))
         b0, b1 = sh.bounds[rank], sh.bounds[rank + 1]
         res = {"n_halo": sh.exchange.n_halo, "owners": sorted(sh.exchange.peers)}
         ys = []
@@ -55,11 +56,13 @@ def _worker(rank, world, port, case, out):
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
-            sh.exchange.pull()
+            if not sh.fused_halo:
+                sh.exchange.pull()
             sh.matrix.spmv_device(sh.exchange.x_ext, y)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
-            sh.exchange.pull()
+            if not sh.fused_halo:
+                sh.exchange.pull()
             sh.matrix.spmv_device(sh.exchange.x_ext, y)
         y.zero_()
         g.replay()
@@ -80,12 +83,12 @@ def run_world(world, case):
     return [out[r] for r in range(world)]
 
 
-def check(world, matrix, balance="nnz"):
+def check(world, matrix, balance="nnz", fused=False):
     from cask_amd import dist as cdist
     n, rp, ci, va = matrix
     rng = np.random.default_rng(7)
     xs = [np.arange(n, dtype=np.float64) * 0.25, rng.uniform(-1, 1, n), rng.standard_normal(n)]
-    res = run_world(world, {"matrix": matrix, "xs": xs, "balance": balance})
+    res = run_world(world, {"matrix": matrix, "xs": xs, "balance": balance, "fused": fused})
     bounds = cdist.partition_rows_by_nnz(rp, world) if balance == "nnz" else cdist.partition_rows_even(n, world)
     for k, x in enumerate(xs):
         exp = oracle.csr_spmv(rp, ci, va, x)
@@ -96,15 +99,17 @@ def check(world, matrix, balance="nnz"):
     return res, bounds
 
 
-def test_two_ranks_power_law_matrix():
+@pytest.mark.parametrize("fused", [False, True], ids=["pull", "in_kernel"])
+def test_two_ranks_power_law_matrix(fused):
     """30 % of the columns are uniformly random: every rank pulls from every other rank."""
-    res, _ = check(2, synth.webbase_like(n=20_000, nnz_target=70_000, max_row=900, seed=5))
+    res, _ = check(2, synth.webbase_like(n=20_000, nnz_target=70_000, max_row=900, seed=5), fused=fused)
     assert all(r["n_halo"] > 1000 for r in res)
     assert res[0]["owners"] == [1] and res[1]["owners"] == [0]
 
 
-def test_three_ranks_banded_matrix_even_split():
-    res, _ = check(3, synth.cant_like(n=9_000, per_row=17, band=200, seed=3), balance="even")
+@pytest.mark.parametrize("fused", [False, True], ids=["pull", "in_kernel"])
+def test_three_ranks_banded_matrix_even_split(fused):
+    res, _ = check(3, synth.cant_like(n=9_000, per_row=17, band=200, seed=3), balance="even", fused=fused)
     assert res[1]["owners"] == [0, 2] and res[0]["owners"] == [1]      # a band couples neighbours only
     assert all(0 < r["n_halo"] <= 400 for r in res)
 

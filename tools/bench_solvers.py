@@ -11,7 +11,9 @@ from cask_amd import capi, synth
 
 def run(name, solver, maxiters):
     n, rp, ci, va, src = synth.load_or_make(name)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    import os
+    prm = capi.make_params(nontemporal=int(os.environ.get("CASK_SOLVER_NT", "0")))   # 0 = default (streaming), -1 = cached
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, prm)
     ones = np.random.default_rng(5).uniform(-1, 1, n)         # the solution the solver must find
     b = m.spmv(ones)
     t0 = time.perf_counter()
@@ -30,6 +32,7 @@ def run(name, solver, maxiters):
     m.close()
 
 if __name__ == "__main__":
-    run("G3_circuit", "cg", 2000)
-    run("atmosmodd", "bicg", 2000)
-    run("cant", "cg", 2000)
+    only = sys.argv[1:] or ["G3_circuit", "atmosmodd", "cant"]
+    for name, solver in (("G3_circuit", "cg"), ("atmosmodd", "bicg"), ("cant", "cg")):
+        if name in only:
+            run(name, solver, 2000)
