@@ -39,10 +39,17 @@ build/test_spmv_hip: tests/clients/test_spmv_client.cpp $(LIBDIR)/libCaskHip.so 
 
 clients: build/test_spmv_hip
 
-ENGINESRC  := cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip
-$(LIBDIR)/libcask_hip.so: $(ENGINESRC) cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp cask_amd/csrc/internal.hpp include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h
+# libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
+# instantiations (merge_ipt<N>.hip, the slow part) in parallel
+ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
+ENGINEOBJ  := $(ENGINESRC:%=build/obj/%.o)
+ENGINEHDR  := $(wildcard cask_amd/csrc/*.hpp) include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h
+build/obj/%.o: cask_amd/csrc/%.hip $(ENGINEHDR)
+	mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/libcask_hip.so: $(ENGINEOBJ)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINESRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINEOBJ)
 
 oracle:
 	$(MAKE) -C oracle _build/libcask_oracle.so
@@ -53,6 +60,6 @@ clean:
 .PHONY: all oracle clean clients
 
 # diagnostic build with in-kernel phase stamps (tools/stamps.py); never used by tests or bench
-build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip cask_amd/csrc/spmv_kernels.hpp cask_amd/csrc/blas1_kernels.hpp include/cask_hip.h
+build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -shared -o $@ cask_amd/csrc/cask_hip.hip
+	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip

@@ -9,7 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "spmv_kernels.hpp"
+#include "spmv_common.hpp"
 
 namespace caskhip {
 

@@ -15,7 +15,17 @@
 
 #include "blas1_kernels.hpp"
 #include "cask_hip.h"
+#include "merge_launch.hpp"
 #include "spmv_kernels.hpp"
+#ifdef CASK_UNITY   // single-translation-unit build (diagnostic builds: tools/stamps.py)
+#include "merge_launch_impl.hpp"
+namespace caskhip {
+template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
+template void launch_merge_blocks<4>(const MergeLaunch &, const double *, double *, hipStream_t);
+template void launch_merge_blocks<8>(const MergeLaunch &, const double *, double *, hipStream_t);
+template void launch_merge_blocks<16>(const MergeLaunch &, const double *, double *, hipStream_t);
+}
+#endif
 
 #include "internal.hpp"
 
@@ -534,41 +544,34 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   return CASK_HIP_OK;
 }
 
-template <int IPT, int XU>
-void launch_merge_ix(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot) {
-  const Plan &pl = m.plan;
-  const dim3 grid(pl.grid), block(pl.prm.wg_size);
-  const int remap = pl.prm.xcd_remap > 0;
-  const unsigned *ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
-  const XHalo halo{m.halo_n_own, m.halo_addr};
-#define CASK_LAUNCH_M(NT, C16, SKEW)                                                                        \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, SKEW>), grid, block, pl.lds_bytes, s, pl.blocks.p,     \
-                     pl.grid, remap, m.n_cols, (int)m.nnz, m.d_rp, m.d_ci, ci16, pl.xchunk.p, pl.maxch, m.d_val,  \
-                     x, y, pl.partials.p, halo, dot)
-  // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
-  const bool nt = pl.prm.nontemporal > 0 || pl.any_skew;
-  if (XU > 0 && ci16) {
-    if (pl.any_skew) CASK_LAUNCH_M(true, (XU > 0), true);
-    else if (nt)     CASK_LAUNCH_M(true, (XU > 0), false);
-    else             CASK_LAUNCH_M(false, (XU > 0), false);
-  } else {
-    if (pl.any_skew) CASK_LAUNCH_M(true, false, true);
-    else if (nt)     CASK_LAUNCH_M(true, false, false);
-    else             CASK_LAUNCH_M(false, false, false);
-  }
-#undef CASK_LAUNCH_M
-}
+// a launch with the dot epilogue parks the block's slice of w (2*wg_size doubles) and its per-wave sums
+// (16 doubles) in dynamic LDS behind the x tile
+int dot_lds_bytes(int wg_size) { return 16 * wg_size + 128; }
 
 template <int IPT>
 int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot) {
   const Plan &pl = m.plan;
-  switch (pl.xu) {
-    case 0:  launch_merge_ix<IPT, 0>(m, x, y, s, dot); break;
-    case 1:  launch_merge_ix<IPT, 1>(m, x, y, s, dot); break;
-    case 2:  launch_merge_ix<IPT, 2>(m, x, y, s, dot); break;
-    case 4:  launch_merge_ix<IPT, 4>(m, x, y, s, dot); break;
-    default: launch_merge_ix<IPT, 8>(m, x, y, s, dot); break;
-  }
+  MergeLaunch l{};
+  l.grid = pl.grid;
+  l.wg_size = pl.prm.wg_size;
+  l.lds_bytes = pl.lds_bytes + (dot.w ? dot_lds_bytes(pl.prm.wg_size) : 0);
+  l.xu = pl.xu;
+  l.remap = pl.prm.xcd_remap > 0;
+  l.n_cols = m.n_cols;
+  l.nnz = (int)m.nnz;
+  l.maxch = pl.maxch;
+  l.nontemporal = pl.prm.nontemporal > 0;
+  l.any_skew = pl.any_skew;
+  l.blocks = pl.blocks.p;
+  l.rp = m.d_rp;
+  l.ci = m.d_ci;
+  l.ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
+  l.xchunk = pl.xchunk.p;
+  l.val = m.d_val;
+  l.partials = pl.partials.p;
+  l.halo = XHalo{m.halo_n_own, m.halo_addr};
+  l.dot = dot;
+  launch_merge_blocks<IPT>(l, x, y, s);
   if (pl.n_split_rows > 0) {
     const DotEpilogue fix{dot.w, dot.w ? dot.dot_part + pl.grid : nullptr};
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
@@ -605,7 +608,10 @@ int launch_merge_wave_i(const cask_hip_matrix &m, const double *x, double *y, hi
 }
 
 // The merge kernel can leave the shares of w.y behind (one per block + one per split row).
-bool plan_fuses_dot(const Plan &pl) { return pl.prm.variant == CASK_HIP_VARIANT_MERGE && pl.grid > 0; }
+bool plan_fuses_dot(const Plan &pl) {
+  return pl.prm.variant == CASK_HIP_VARIANT_MERGE && pl.grid > 0 &&
+         pl.lds_bytes + dot_lds_bytes(pl.prm.wg_size) <= MAX_LDS_BYTES;
+}
 int dot_part_count(const Plan &pl) { return pl.grid + pl.n_split_rows; }
 
 // y = A x; with w != NULL (MERGE plans only) also plan.dot_part[0 .. dot_part_count) = shares of w.y
@@ -688,6 +694,59 @@ int blas_grid(int64_t n) {
   const int64_t want = (n / 2 + BLAS_WG - 1) / BLAS_WG;
   return (int)std::max<int64_t>(1, std::min<int64_t>(BLAS_MAX_PARTIALS, want));
 }
+
+// A solver re-reads the matrix every iteration.  When matrix + vectors fit the 256 MiB Infinity Cache,
+// cached loads can beat the streaming ("nt") ones the one-shot product prefers -- or lose to them: on
+// the G3_circuit-like system the cached product is 8 % faster, on the cant-like one 20 % slower.  So
+// the solver MEASURES (the DSE idea applied at run time): unless the caller pinned `nontemporal`,
+// iterations 16-31 run with streaming loads, 32-47 with cached loads, and from 48 on the faster of the
+// two.  The load policy changes no arithmetic, so the iterates are the same either way; the plan is
+// restored when the solver returns.
+struct SolverLoadPolicy {
+  cask_hip_matrix *m, *mt;
+  int saved = 0, saved_t = 0;
+  bool choosing = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  SolverLoadPolicy(cask_hip_matrix *m_, cask_hip_matrix *mt_, int n_vectors) : m(m_), mt(mt_) {
+    saved = m->plan.prm.nontemporal;
+    if (mt) saved_t = mt->plan.prm.nontemporal;
+    const int64_t per_matrix = 12 * m->nnz + 4 * ((int64_t)m->n_rows + 1);
+    const int64_t working_set = per_matrix * (mt ? 2 : 1) + 8 * (int64_t)m->n_rows * n_vectors;
+    choosing = m->requested.nontemporal == 0 && working_set < (int64_t)(224 << 20) && !m->plan.any_skew &&
+               !(mt && mt->plan.any_skew);
+    if (choosing)
+      for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) choosing = false;
+  }
+  void set(int nt) {
+    m->plan.prm.nontemporal = nt;
+    if (mt) mt->plan.prm.nontemporal = nt;
+  }
+  // call at every 16-iteration checkpoint, before the stream is synchronised
+  void record(int launched, hipStream_t s) {
+    if (!choosing) return;
+    if (launched == 16) (void)hipEventRecord(ev[0], s);
+    if (launched == 32) { (void)hipEventRecord(ev[1], s); set(-1); }
+    if (launched == 48) (void)hipEventRecord(ev[2], s);
+  }
+  // ... and after it
+  void decide(int launched) {
+    if (!choosing || launched != 48) return;
+    float t_stream = 0.f, t_cached = 0.f;
+    if (hipEventElapsedTime(&t_stream, ev[0], ev[1]) == hipSuccess &&
+        hipEventElapsedTime(&t_cached, ev[1], ev[2]) == hipSuccess && t_cached < t_stream)
+      set(-1);
+    else
+      set(1);
+    choosing = false;
+  }
+  ~SolverLoadPolicy() {
+    m->plan.prm.nontemporal = saved;
+    if (mt) mt->plan.prm.nontemporal = saved_t;
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
 
 // Scratch owned by a solver run.
 struct SolverScratch {
@@ -1128,6 +1187,7 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   int launched = 0;
   double clean_us = 0.0;
   const bool fused = plan_fuses_dot(m->plan);
+  SolverLoadPolicy load_policy(m, nullptr, 5);
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
     // Ap = A p (:206); with a MERGE plan the shares of p.Ap fall out of the same launch
@@ -1149,8 +1209,10 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
+      load_policy.record(launched, s);
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
+      load_policy.decide(launched);
       if (h_flags[0]) break;
       // a checkpoint reached without convergence: every pass so far did real work
       float ms_so_far = 0.f;
@@ -1215,6 +1277,7 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   int launched = 0;
   double clean_us = 0.0;
   const bool fused = plan_fuses_dot(m->plan);
+  SolverLoadPolicy load_policy(m, &mt, 8);
   for (int i = 0; i < maxiters; i++) {
     double *rho_old = rho[i & 1], *rho_new = rho[(i + 1) & 1];
     // q = A p with the shares of pt.q from the same launch (MERGE plans); qt = A^T pt
@@ -1238,8 +1301,10 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
+      load_policy.record(launched, s);
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
+      load_policy.decide(launched);
       if (h_flags[0]) break;
       // a checkpoint reached without convergence: every pass so far did real work
       float ms_so_far = 0.f;

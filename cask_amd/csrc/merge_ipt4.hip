@@ -1,0 +1,6 @@
+// k_spmv_merge instantiations for items_per_thread = 4 (see merge_launch.hpp).
+#include "merge_launch_impl.hpp"
+
+namespace caskhip {
+template void launch_merge_blocks<4>(const MergeLaunch &, const double *, double *, hipStream_t);
+}

@@ -1,0 +1,402 @@
+// The workgroup-level merge kernel (variant MERGE), the headline kernel of the engine.  Kept in its own
+// header because its instantiations are what takes time to compile: merge_ipt*.hip instantiate one
+// items-per-thread value each, in parallel.
+#pragma once
+#include "spmv_common.hpp"
+
+namespace caskhip {
+
+// ------------------------------------------------------------- merge variant
+// Merge-based family.  The host cuts the merge path of (row ends) x (nonzero
+// indices) into pieces of at most CAP = blockDim.x*IPT items and snaps each
+// cut to a row boundary, so every workgroup owns whole rows and the same
+// amount of work whatever the row-length distribution; rows longer than a
+// threshold become their own "long row" pieces.  Phase 1 streams the block's
+// nonzeros with 16-byte loads in nonzero order (perfectly coalesced, IPT
+// elements in flight per lane, independent of row structure) and parks the
+// products in LDS; phase 2 sums each row's run of products with G lanes per
+// row (G chosen per block from its mean row length) and a DPP butterfly.
+// Rows longer than SKEW_FACTOR*G products are left to a second pass in which a whole wave sums one row
+// (power-law blocks: a 500-nonzero row among 3-nonzero rows would otherwise keep one lane busy for
+// microseconds while 255 idle).  The host flags such blocks (KIND_SKEW); others pay one compare.
+
+template <int G, bool EXT>
+__device__ __forceinline__ double reduce_rows_plain(const BlockDesc &d, const double *prod, const int *roff,
+                                                    double *__restrict__ y, const double *w) {
+  const int tid = threadIdx.x;
+  const int rows_per_pass = blockDim.x / G;
+  const int j = tid & (G - 1);
+  double dsum = 0.0;
+  for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
+    const int r = r0 + tid / G;
+    double acc = 0.0;
+    if (r < d.n_rows) {
+      const int s = roff[r], e = roff[r + 1];
+#pragma unroll 4
+      for (int k = s + j; k < e; k += G) acc += prod[k];
+    }
+    acc = group_sum<G>(acc);
+    if (j == 0 && r < d.n_rows) {
+      y[d.row_start + r] = acc;
+      if (EXT && w) dsum = fma(w[r], acc, dsum);              // launch-uniform; w = the block's slice, in LDS
+    }
+  }
+  return dsum;
+}
+
+template <int G, bool SKEW, bool EXT>
+__device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
+                                              double *__restrict__ y, const double *w) {
+  const bool skew = SKEW && (d.kind_g & KIND_SKEW);           // workgroup-uniform
+  if (!skew)                                                  // the common case keeps the lean loop
+    return reduce_rows_plain<G, EXT>(d, prod, roff, y, w);
+  const int tid = threadIdx.x;
+  const int rows_per_pass = blockDim.x / G;
+  const int j = tid & (G - 1);
+  double dsum = 0.0;
+  // pass 1: rows of ordinary length, G lanes each; long rows are left to pass 2
+  for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
+    const int r = r0 + tid / G;
+    double acc = 0.0;
+    bool mine = r < d.n_rows;
+    if (mine) {
+      const int s = roff[r], e = roff[r + 1];
+      if (e - s > SKEW_FACTOR * G) {
+        mine = false;
+      } else {
+#pragma unroll 4
+        for (int k = s + j; k < e; k += G) acc += prod[k];
+      }
+    }
+    acc = group_sum<G>(acc);
+    if (j == 0 && mine) {
+      y[d.row_start + r] = acc;
+      if (EXT && w) dsum = fma(w[r], acc, dsum);
+    }
+  }
+  // pass 2: a whole wave per long row.  Every wave scans the row lengths 64 at a time (one ballot per
+  // chunk) and takes the long rows round-robin IN ROW ORDER, so which wave sums which row -- and with it
+  // the order of every floating-point addition -- is a function of the matrix alone (no queue, no atomics).
+  const int lane = tid & 63, wave = tid >> 6, wave_mask = (blockDim.x >> 6) - 1;
+  int seen = 0;
+  for (int c0 = 0; c0 < d.n_rows; c0 += 64) {                 // workgroup-uniform
+    const int r = c0 + lane;
+    const bool is_long = r < d.n_rows && roff[r + 1] - roff[r] > SKEW_FACTOR * G;
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {                                            // wave-uniform
+      const int b = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      if (((seen++) & wave_mask) != wave) continue;
+      const int row = c0 + b;
+      const int s = roff[row], e = roff[row + 1];
+      double a0 = 0.0, a1 = 0.0;
+      int k = s + lane;
+      for (; k + 64 < e; k += 128) {
+        a0 += prod[k];
+        a1 += prod[k + 64];
+      }
+      if (k < e) a0 += prod[k];
+      const double acc = group_sum<64>(a0 + a1);
+      if (lane == 0) {
+        y[d.row_start + row] = acc;
+        if (EXT && w) dsum = fma(w[row], acc, dsum);
+      }
+    }
+  }
+  return dsum;
+}
+
+// One block of the merge kernel, straight-line so that hipcc can count the
+// outstanding loads exactly.  Issue order is the point (membench2, stage 3 vs
+// 4: 11.0 -> 9.2 us on the cant payload):
+//   1. the block's x window (XU 8-byte loads per lane)      -- oldest
+//   2. its row offsets (2 loads per lane)
+//   3. the value/index stream (IPT/2 16-byte + 8-byte loads) -- youngest
+// vmcnt retires in order, so parking the window and the offsets in LDS waits
+// only for (1) and (2) while the stream is still in flight; when the stream
+// lands the gathers are LDS reads (~100 ns, no TA traffic) instead of a second
+// dependent trip to L2.  XU = 0 gathers from L2 (window wider than the tile).
+//
+// C16 (only with an x window): the block's column indices are read from the
+// 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
+// per nonzero and already LDS offsets -- the stream shrinks from 12 to 10
+// bytes per nonzero, which on a bandwidth-bound kernel is the whole game.
+//
+// Sharded product (SEAM = true, only for blocks that read halo columns; cask_hip_p2p.h): the block
+// fetches the address-table entries of its window first, issues its stream like any block, then the
+// window loads themselves -- some of them remote: one local and one xGMI round trip, overlapped with
+// the stream.  A separate instantiation, so the code of every other block is exactly the one above.
+typedef __attribute__((address_space(1))) const double gdouble;
+__device__ __forceinline__ double load_at(uint64_t addr) { return *reinterpret_cast<gdouble *>(addr); }
+
+template <int IPT, int XU, bool NT, bool C16, bool SEAM, bool EXT>
+__device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+                                           const int *__restrict__ rp, const int *__restrict__ ci,
+                                           const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                           const double *__restrict__ val, const double *__restrict__ x,
+                                           double *prod, int *roff, double *xs, const XHalo &halo,
+                                           const double *__restrict__ w, double *wl) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  // 16-byte loads need an even element index: start one element early if the
+  // block starts on an odd nonzero (that element belongs to the previous block;
+  // its product lands in prod[0] and no row of this block references it).
+  const int base = d.nnz_start & ~1;
+  const int lead = d.nnz_start - base;
+  const int total = d.nnz_count + lead;
+  // An odd total ends in a pair whose second element is foreign (the next
+  // block's first nonzero, or -- for the very last nonzero of an odd-nnz matrix
+  // -- the 8 bytes after the array: a 16-byte-aligned 16-byte load that holds
+  // one valid element cannot cross a page, so it is memory-safe).
+  const int npairs = (total + 1) >> 1;
+
+  // x tile.  With 16-bit indices the tile is a SET of column ranges cut into 64-column chunks
+  // (xchunk[c] = first column of chunk c; built on the host): chunk c = u*(WG/64) + wave lands in
+  // LDS slots [64c, 64c+64), and a nonzero's 16-bit index is its slot.  One contiguous window is
+  // the special case of consecutive chunks; stencil-like matrices (a few narrow bands far apart)
+  // fit the same way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
+  double xw[XU > 0 ? XU : 1];
+  uint64_t xsrc[XU > 0 ? XU : 1];
+  if (XU > 0) {
+    if (SEAM) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+      const bool chunked = C16 && !(d.kind_g & KIND_CONTIG);
+      int col[XU > 0 ? XU : 1];
+#pragma unroll
+      for (int u = 0; u < XU; u++) {
+        col[u] = min(chunked ? xchunk[u * wpw + wave] + lane : d.cmin + u * WG + tid, n_cols - 1);
+        xsrc[u] = halo_entry(col[u], halo);
+      }
+#pragma unroll
+      for (int u = 0; u < XU; u++) xsrc[u] = halo_source(x, col[u], xsrc[u], halo);
+    } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+#pragma unroll
+      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, xlim)];
+    } else {                                                  // one window: no chunk table on the critical path
+#pragma unroll
+      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, xlim)];
+    }
+  }
+  const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
+  const int ro1 = rp[d.row_start + min(tid + WG, d.n_rows)] - base;
+
+  dbl2 v[IPT / 2];
+  int2v c[IPT / 2];
+  unsigned c16[IPT / 2];                                      // C16: two 16-bit slots per word, unpacked after the park
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  const int first = base >> 1;
+  const int last = min(first + max(npairs - 1, 0), max_gpair);
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
+    v[u] = stream_load<NT>(val2 + p);
+    if (C16) c16[u] = stream_load<NT>(ci16 + p);
+    else     c[u] = stream_load<NT>(ci2 + p);
+  }
+  if (XU > 0 && SEAM) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xw[u] = load_at(xsrc[u]);
+  }
+  // dot epilogue (EXT kernels, launch-uniform test): the block's slice of w, requested behind the stream
+  // (youngest loads: nothing waits for them until the products are stored), parked in LDS for the row sums
+  double w0 = 0.0, w1 = 0.0;
+  if (EXT && w) {
+    w0 = w[d.row_start + min(tid, d.n_rows - 1)];
+    w1 = w[d.row_start + min(tid + WG, d.n_rows - 1)];
+  }
+
+  CASK_STAMP(1);
+  if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
+  }
+  roff[tid] = ro0;
+  roff[tid + WG] = ro1;
+  if (XU > 0) __syncthreads();
+  CASK_STAMP(2);
+  if (C16) {                                                  // unpack the 16-bit slots only now: the stream is still landing
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      c[u].x = (int)(c16[u] & 0xffffu);
+      c[u].y = (int)(c16[u] >> 16);
+    }
+  }
+
+  // foreign elements: give them a column this block owns, so their gather stays
+  // inside the x window / inside x (their products land in slots no row uses)
+  if (lead && tid == 0) c[0].x = c[0].y;
+  if (total & 1) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++)
+      if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+  }
+  dbl2 xv[IPT / 2];
+  if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
+      xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
+    }
+  } else if (SEAM) {                                          // gathers, some of them from peers
+    uint64_t ex[IPT / 2], ey[IPT / 2];
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      ex[u] = halo_entry(c[u].x, halo);
+      ey[u] = halo_entry(c[u].y, halo);
+    }
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = load_at(halo_source(x, c[u].x, ex[u], halo));
+      xv[u].y = load_at(halo_source(x, c[u].y, ey[u], halo));
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = x[c[u].x];
+      xv[u].y = x[c[u].y];
+    }
+  }
+  // every lane stores: lanes past the last pair hold a duplicate of it and land
+  // in slots no row offset points to
+  dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
+#ifdef CASK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CASK_STAMP(3);
+#endif
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
+  if (EXT && w) {
+    wl[tid] = w0;
+    wl[tid + WG] = w1;
+  }
+  __syncthreads();
+  CASK_STAMP(4);
+}
+
+template <int IPT, int XU, bool NT, bool C16, bool SKEW, bool EXT>
+__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+                                            const int *__restrict__ rp, const int *__restrict__ ci,
+                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                            const double *__restrict__ val, const double *__restrict__ x,
+                                            double *__restrict__ y, double *prod, int *roff, double *xs,
+                                            const XHalo &halo, const DotEpilogue &dot, int lb) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
+  // the per-wave sums.  No static LDS: on gfx950 LDS is allocated in 1280-byte granules and the
+  // bench's 26 640-byte blocks sit 240 bytes under a granule edge -- 256 bytes of static LDS cost a
+  // sixth of the occupancy (measured: 8.75 -> 8.88 us per launch).
+  double *wl = xs + XU * WG, *dot_red = wl + 2 * WG;
+  // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
+  // load phase is a copy of its own, so the one every other block runs has no halo code in it
+  if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
+    merge_load<IPT, XU, NT, C16, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                            halo, dot.w, wl);
+  else
+    merge_load<IPT, XU, NT, C16, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                             halo, dot.w, wl);
+  const double *wrow = EXT && dot.w ? wl : nullptr;           // w[row_start + r] sits in wl[r]
+
+  double dsum;
+  switch (d.kind_g & 0xff) {
+    case 1:  dsum = reduce_rows<1, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    case 2:  dsum = reduce_rows<2, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    case 4:  dsum = reduce_rows<4, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    case 8:  dsum = reduce_rows<8, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    case 16: dsum = reduce_rows<16, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    case 32: dsum = reduce_rows<32, SKEW, EXT>(d, prod, roff, y, wrow); break;
+    default: dsum = reduce_rows<64, SKEW, EXT>(d, prod, roff, y, wrow); break;
+  }
+  if (EXT && dot.w) {                                         // launch-uniform: the block's share of w.y
+    dsum = group_sum<64>(dsum);
+    if ((tid & 63) == 0) dot_red[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int wv = 0; wv < (WG >> 6); wv++) s += dot_red[wv];
+      dot.dot_part[lb] = s;
+    }
+  }
+}
+
+// SKEW: the plan holds blocks flagged KIND_SKEW (matrices without any run the instantiation that
+// carries no second-pass code at all: 0.13 us per launch on cant).
+// EXT: the launch may carry halo sources and/or a dot epilogue.  Ordinary products run the EXT = false
+// instantiation, which contains none of that code: a kernel this close to the memory system's limits
+// pays for every extra branch, register and byte of LDS (measured while adding them: +1 to +6 %).
+template <int IPT, int XU, bool NT, bool C16, bool SKEW, bool EXT>
+__global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
+                             const int *__restrict__ rp, const int *__restrict__ ci,
+                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
+                             const double *__restrict__ val, const double *__restrict__ x,
+                             double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot) {
+  static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
+  double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
+  int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
+  double *xs = reinterpret_cast<double *>(roff + 2 * WG);     // XU*WG doubles
+
+  CASK_STAMP(0);
+  const int lb = logical_block(blockIdx.x, n_blocks, remap);
+  const BlockDesc d = blocks[lb];
+  const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
+
+  if (d.kind_g & KIND_LONG) {
+    // One piece of one long row: the whole workgroup strides over it.
+    const int end = d.nnz_start + d.nnz_count;
+    double acc = 0.0;
+    for (int k = d.nnz_start + tid; k < end; k += 4 * WG) {
+      int c[4];
+      double v[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int kk = min(k + u * WG, end - 1);
+        c[u] = stream_load<NT>(ci + kk);
+        v[u] = stream_load<NT>(val + kk);
+      }
+      if (EXT && halo.haddr) {                                // launch-uniform
+        uint64_t ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ent[u] = halo_entry(c[u], halo);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = load_at(halo_source(x, c[u], ent[u], halo));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (k + u * WG < end) acc = fma(v[u], xv[u], acc);
+    }
+    acc = group_sum<64>(acc);
+    if ((tid & 63) == 0) prod[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < (WG >> 6); w++) s += prod[w];
+      if (d.kind_g & KIND_PARTIAL) {
+        partials[d.aux] = s;
+        if (EXT && dot.w) dot.dot_part[lb] = 0.0;             // the fix-up kernel owns this row's share
+      } else {
+        y[d.row_start] = s;
+        if (EXT && dot.w) dot.dot_part[lb] = dot.w[d.row_start] * s;
+      }
+    }
+    return;
+  }
+
+  const int max_gpair = ((nnz + 1) >> 1) - 1;
+  // last entry of x[] a block without halo columns may touch: its window is padded to whole chunks and
+  // may reach past its largest column, but never past the caller's n_own entries
+  const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
+  if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
+    merge_block<IPT, XU, NT, C16, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                             xs, halo, dot, lb);
+  else
+    merge_block<IPT, 0, NT, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                              xs, halo, dot, lb);
+  CASK_STAMP(5);
+}
+
+}  // namespace caskhip

@@ -1,0 +1,49 @@
+// Definition of launch_merge_blocks<IPT>: picks the k_spmv_merge instantiation for the plan's window
+// shape, load policy and index width.  Included by merge_ipt<N>.hip only.
+#pragma once
+#include "merge_kernel.hpp"
+#include "merge_launch.hpp"
+
+namespace caskhip {
+
+template <int IPT, int XU>
+static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
+  const dim3 grid(l.grid), block(l.wg_size);
+#define CASK_LAUNCH_K(NT, C16, SKEW, EXT)                                                                         \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, SKEW, EXT>), grid, block, l.lds_bytes, s, l.blocks, l.grid, \
+                     l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, y, l.partials,    \
+                     l.halo, l.dot)
+  // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one
+  const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
+#define CASK_LAUNCH_M(NT, C16, SKEW)                                   \
+  do {                                                                 \
+    if (ext) CASK_LAUNCH_K(NT, C16, SKEW, true);                       \
+    else     CASK_LAUNCH_K(NT, C16, SKEW, false);                      \
+  } while (0)
+  // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
+  const bool nt = l.nontemporal || l.any_skew;
+  if (XU > 0 && l.ci16) {
+    if (l.any_skew) CASK_LAUNCH_M(true, (XU > 0), true);
+    else if (nt)    CASK_LAUNCH_M(true, (XU > 0), false);
+    else            CASK_LAUNCH_M(false, (XU > 0), false);
+  } else {
+    if (l.any_skew) CASK_LAUNCH_M(true, false, true);
+    else if (nt)    CASK_LAUNCH_M(true, false, false);
+    else            CASK_LAUNCH_M(false, false, false);
+  }
+#undef CASK_LAUNCH_K
+#undef CASK_LAUNCH_M
+}
+
+template <int IPT>
+void launch_merge_blocks(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
+  switch (l.xu) {
+    case 0:  launch_merge_ix<IPT, 0>(l, x, y, s); break;
+    case 1:  launch_merge_ix<IPT, 1>(l, x, y, s); break;
+    case 2:  launch_merge_ix<IPT, 2>(l, x, y, s); break;
+    case 4:  launch_merge_ix<IPT, 4>(l, x, y, s); break;
+    default: launch_merge_ix<IPT, 8>(l, x, y, s); break;
+  }
+}
+
+}  // namespace caskhip

@@ -1,0 +1,134 @@
+// Shared pieces of the SpMV device kernels for MI355X (gfx950, CDNA4): wave-64, DPP reductions,
+// LDS-staged x tiles, XCD-aware workgroup mapping.  fp64, bandwidth bound: the
+// design goal is coalesced 16-byte streams of values/col_ind with many bytes in
+// flight per CU, and a cheap x gather (LDS window when the row block is banded,
+// L2 otherwise).  No MFMA: arithmetic intensity is ~0.16 flop/byte.
+//
+// What these kernels replace in the reference: the MaxJ dataflow design
+// src/spmv/src/SpmvKernel.java:18-309 (multiply lanes + adder tree + per-row
+// accumulate + cross-block reduction), ParallelCsrReadControl.java:6-316 (row
+// -> lane scheduling) and SpmvCacheKernel (SpmvKernel.java:107-196, the x tile
+// cache, here a single LDS copy instead of input_width BRAM replicas).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace caskhip {
+
+// Diagnostic build only (-DCASK_STAMPS, tools/stamps.py): wave 0 of every merge workgroup records
+// s_memrealtime (100 MHz) at phase boundaries into a side buffer no other code reads.
+#ifdef CASK_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#define CASK_STAMP(i)                                                                     \
+  do {                                                                                    \
+    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CASK_STAMP(i) do {} while (0)
+#endif
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef int    int2v __attribute__((ext_vector_type(2)));
+
+// One workgroup's share of the merge path.  32 bytes, read through the scalar
+// cache (address depends on blockIdx only).
+struct BlockDesc {
+  int32_t row_start;   // first row of the block
+  int32_t n_rows;      // rows finished by this block (1 for a long-row piece)
+  int32_t nnz_start;   // first nonzero
+  int32_t nnz_count;   // nonzeros in the block
+  int32_t cmin;        // smallest column referenced (x window start)
+  int32_t cwidth;      // window width in doubles (0 when the block has no nonzeros)
+  int32_t kind_g;      // bits 0-7: lanes per row in the reduce phase; bit 8: long-row piece; bit 9: piece writes a partial
+  int32_t aux;         // long-row piece: slot in the partials buffer; other blocks: largest column referenced
+};
+constexpr int KIND_LONG = 0x100;
+constexpr int KIND_PARTIAL = 0x200;
+constexpr int KIND_SKEW = 0x800;      // block holds rows much longer than its lanes-per-row suits: second, wave-per-row pass
+constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutive: chunk c starts at cmin + 64c
+
+struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
+  int32_t row, first_slot, n_slots, pad;
+};
+
+// Where a launch reads x from.  Without a halo every column comes from x[] (n_own = INT_MAX,
+// haddr = NULL).  With one (row-sharded product, include/cask_hip_p2p.h) columns >= n_own are
+// halo columns: column n_own + j is read from the absolute device address haddr[j], which may
+// lie in a peer GPU's shared slice -- the remote load over xGMI happens inside the product
+// kernel, so the sharded product is one launch with no exchange step in front of it.
+struct XHalo {
+  int n_own;
+  const uint64_t *haddr;
+};
+// Two steps so that a lane's loads stay batched: first the table entries of all its columns (entry 0
+// for own columns: harmless, one cached line), then the values from wherever they live.
+__device__ __forceinline__ uint64_t halo_entry(int col, const XHalo &h) { return h.haddr[max(col - h.n_own, 0)]; }
+__device__ __forceinline__ uint64_t halo_source(const double *x, int col, uint64_t entry, const XHalo &h) {
+  return col < h.n_own ? reinterpret_cast<uint64_t>(x + col) : entry;
+}
+
+// Optional epilogue of the merge kernel: dot_part[block] = sum over the block's rows of
+// w[row] * y[row] (fixed order => reproducible), so that the p.Ap of a CG iteration costs no
+// extra pass over the vectors.  w = NULL switches it off.
+struct DotEpilogue {
+  const double *w;
+  double *dot_part;
+};
+
+// ---------------------------------------------------------------- cross-lane
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swap16_f64(double v) {      // lane i <-> i^16
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum_halves_f64(double v) {  // v[i%32] + v[i%32+32] in every lane
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Sum over aligned groups of L consecutive lanes; every lane of a group ends
+// with the group's total.  Fixed butterfly order => deterministic.  Must be
+// called with all 64 lanes active (DPP reads neighbours' registers).
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+  if (L >= 2)  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+  if (L >= 4)  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+  if (L >= 8)  v += dpp_f64<0x141>(v);   // row_half_mirror      (other quad of 8)
+  if (L >= 16) v += dpp_f64<0x140>(v);   // row_mirror           (other half of 16)
+  if (L >= 32) v += swap16_f64(v);       // ds_swizzle SWAP,16
+  if (L >= 64) v = sum_halves_f64(v);    // v_permlane32_swap
+  return v;
+}
+
+// Contiguous row blocks per XCD: hardware deals workgroups round-robin over the
+// 8 XCDs (MI355X_MICROARCH "Workgroup dispatch"), so hardware block b lands on
+// XCD b%8.  Map it to a logical block so that each XCD walks one contiguous
+// eighth of the matrix: neighbouring row blocks share x lines and the partial
+// cache lines at their seams in the same 4 MiB L2.  Bijective for any grid.
+__device__ __forceinline__ int logical_block(int hw, int n, int remap) {
+  if (!remap) return hw;
+  const int xcd = hw & 7, idx = hw >> 3;
+  const int q = n >> 3, rem = n & 7;
+  return xcd * q + (xcd < rem ? xcd : rem) + idx;
+}
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// Rows longer than SKEW_FACTOR * (lanes per row) products get a whole wave each in a second pass.
+constexpr int SKEW_FACTOR = 32;
+
+}  // namespace caskhip
