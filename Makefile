@@ -37,11 +37,15 @@ build/test_spmv_hip: tests/clients/test_spmv_client.cpp $(LIBDIR)/libCaskHip.so 
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -L$(GENDIR) -Loracle/_build -lCaskHip -lSpmv_hip -lcask_hip -lcask_oracle \
 	  $(RPATHS) -Wl,-rpath,'$$ORIGIN/../oracle/_build'
 
-clients: build/test_spmv_hip
+build/test_precond_hip: tests/clients/test_precond_client.cpp $(LIBDIR)/libCaskHip.so
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lCaskHip -lcask_hip $(RPATHS)
+
+clients: build/test_spmv_hip build/test_precond_hip
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel
-ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
+ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p cask_hip_precond merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
 ENGINEOBJ  := $(ENGINESRC:%=build/obj/%.o)
 ENGINEHDR  := $(wildcard cask_amd/csrc/*.hpp) include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h
 build/obj/%.o: cask_amd/csrc/%.hip $(ENGINEHDR)
@@ -54,6 +58,14 @@ $(LIBDIR)/libcask_hip.so: $(ENGINEOBJ)
 oracle:
 	$(MAKE) -C oracle _build/libcask_oracle.so
 
+# development microbenchmarks (tools/profile_round.sh uses membench as the FETCH_SIZE calibration kernel)
+build/membench: tools/membench.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+build/membench2: tools/membench2.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+
 clean:
 	rm -rf $(LIBDIR) build oracle/_build
 
@@ -62,4 +74,4 @@ clean:
 # diagnostic build with in-kernel phase stamps (tools/stamps.py); never used by tests or bench
 build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip
+	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip

@@ -25,7 +25,10 @@ EXPORTED_SYMBOLS = (
     "cask_hip_csr_get_params", "cask_hip_csr_get_info", "cask_hip_spmv", "cask_hip_spmv_device",
     "cask_hip_spmv_dot_device", "cask_hip_spmv_transpose_device", "cask_hip_spmv_time", "cask_hip_tune", "cask_hip_ddot_device",
     "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
+    "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
+    "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
 )
+PRECOND_JACOBI, PRECOND_ILU0, PRECOND_ILU0_UNIT = 1, 2, 3
 
 
 class Params(Structure):
@@ -107,6 +110,15 @@ def load() -> ctypes.CDLL:
     L.cask_hip_daxpby_device.argtypes = [i64, dbl, vp, dbl, dbl, vp, vp, vp, vp]
     for name in ("cask_hip_cg", "cask_hip_bicg"):
         getattr(L, name).argtypes = [vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
+    if hasattr(L, "cask_hip_pcg") or not os.environ.get("CASK_HIP_DIAGNOSTIC_LIB"):
+        L.cask_hip_precond_create.argtypes = [i32, i32, i64, vp, vp, vp, POINTER(vp)]
+        L.cask_hip_precond_destroy.argtypes = [vp]
+        L.cask_hip_precond_factor_values.argtypes = [vp, vp]
+        L.cask_hip_precond_info.argtypes = [vp, POINTER(i32), POINTER(i32), POINTER(i32)]
+        L.cask_hip_precond_apply.argtypes = [vp, vp, vp]
+        L.cask_hip_precond_apply_device.argtypes = [vp, vp, vp, vp]
+        L.cask_hip_trsolve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp]
+        L.cask_hip_pcg.argtypes = [vp, vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
     for name in EXPORTED_SYMBOLS:
         if os.environ.get("CASK_HIP_DIAGNOSTIC_LIB") and not hasattr(L, name):
             continue                                            # an older build loaded for an A/B timing
@@ -294,6 +306,66 @@ class CsrMatrix:
 
     def bicg(self, rhs, x0=None, maxiters=2000, tol=1e-5):
         return self._solve(load().cask_hip_bicg, rhs, x0, maxiters, tol)
+
+    def pcg(self, precond, rhs, x0=None, maxiters=2000, tol=1e-5):
+        """Preconditioned CG (pcg<double, Precon>, SparseLinearSolvers.hpp:162-239) with a ``Preconditioner``."""
+        fn = load().cask_hip_pcg
+        return self._solve(lambda h, *a: fn(h, precond._h if precond is not None else None, *a), rhs, x0, maxiters, tol)
+
+
+class Preconditioner:
+    """Jacobi or ILU(0) (``cask_hip_precond*``): factored once on the host, applied on the device."""
+
+    def __init__(self, kind, n, row_ptr, col_ind, values):
+        kind = {"jacobi": PRECOND_JACOBI, "ilu0": PRECOND_ILU0, "ilu0_unit": PRECOND_ILU0_UNIT}.get(kind, kind)
+        rp, ci, va = _np(row_ptr, np.int32), _np(col_ind, np.int32), _np(values, np.float64)
+        if rp.size != n + 1 or ci.size != va.size:
+            raise ValueError("malformed CSR arrays")
+        self.n, self.nnz, self.kind = n, int(ci.size), kind
+        h = c_void_p()
+        _check(load().cask_hip_precond_create(kind, n, ci.size, _p(rp), _p(ci), _p(va), byref(h)))
+        self._h = h
+
+    def factor_values(self) -> np.ndarray:
+        out = np.empty(self.nnz, dtype=np.float64)
+        _check(load().cask_hip_precond_factor_values(self._h, _p(out) if out.size else None))
+        return out
+
+    def info(self):
+        a, b, c = c_int32(0), c_int32(0), c_int32(0)
+        _check(load().cask_hip_precond_info(self._h, byref(a), byref(b), byref(c)))
+        return {"levels_lower": a.value, "levels_upper": b.value, "launches_per_apply": c.value}
+
+    def apply(self, r) -> np.ndarray:
+        r = _np(r, np.float64)
+        if r.size != self.n:
+            raise ValueError("vector length mismatch")
+        z = np.empty(self.n, dtype=np.float64)
+        _check(load().cask_hip_precond_apply(self._h, _p(r), _p(z)))
+        return z
+
+    def apply_device(self, r_t, z_t, stream=None):
+        _check(load().cask_hip_precond_apply_device(self._h, c_void_p(r_t.data_ptr()), c_void_p(z_t.data_ptr()),
+                                                    c_void_p(_stream_ptr(stream))))
+
+    def close(self):
+        if self._h:
+            load().cask_hip_precond_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def trsolve(n, row_ptr, col_ind, values, rhs, lower=True) -> np.ndarray:
+    """cask::mkl::unittrsolve on the device: the chosen triangle with its stored diagonal."""
+    rp, ci, va, b = _np(row_ptr, np.int32), _np(col_ind, np.int32), _np(values, np.float64), _np(rhs, np.float64)
+    x = np.empty(n, dtype=np.float64)
+    _check(load().cask_hip_trsolve(n, ci.size, _p(rp), _p(ci), _p(va), int(bool(lower)), _p(b), _p(x)))
+    return x
 
 
 def _stream_ptr(stream):

@@ -63,29 +63,6 @@ constexpr int MAX_LDS_BYTES = 64 * 1024;      // per workgroup; keeps >= 2 workg
 constexpr int DEFAULT_TILE = 4096;            // doubles (32 KiB)
 constexpr int LONG_PIECE_FACTOR = 16;         // a long-row piece is at most 16*CAP nonzeros
 
-template <typename T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  hipError_t alloc(size_t count) {
-    release();
-    n = count;
-    return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
-  }
-  hipError_t upload(const T *h, size_t count) {
-    hipError_t e = alloc(count);
-    if (e != hipSuccess || count == 0) return e;
-    return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
-  }
-  hipError_t upload(const std::vector<T> &h) { return upload(h.data(), h.size()); }
-};
-
 struct Plan {
   cask_hip_params prm{};          // resolved
   int grid = 0;
@@ -1323,6 +1300,94 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
   if (converged) *converged = h_flags[0];
   // passes launched after the converged one are no-ops: prefer the rate measured up to the last
   // checkpoint that had not converged yet
+  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
+  return CASK_HIP_OK;
+}
+
+// Preconditioned CG, pcg<double, Precon> of the reference (SparseLinearSolvers.hpp:162-239) with the
+// preconditioner applied on the device: r = b - A x ; z = M^-1 r ; p = z ; rsold = r.z ; then per pass
+// Ap = A p ; alpha = rsold / p.Ap ; x += alpha p ; r -= alpha Ap ; z = M^-1 r ; rsnew = r.z ;
+// stop if rsnew <= tol^2 ; p = z + (rsnew/rsold) p.  `iterations` as the reference counts them.
+int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x, int32_t maxiters,
+                 double tol, int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+  int rc = solver_common_checks(m, rhs, x, maxiters, tol);
+  if (rc) return rc;
+  if (!precond) return cask_hip_cg(m, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+  HIP_TRY(hipSetDevice(m->device));
+  const int64_t n = m->n_rows;
+  hipStream_t s = m->stream;
+  DevBuf<double> dx, db, r, z, p, Ap, partials, partials_rz, scal;
+  DevBuf<int> flags;
+  HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
+  HIP_TRY(r.alloc(n)); HIP_TRY(z.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
+  HIP_TRY(partials.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(partials_rz.alloc(BLAS_MAX_PARTIALS));
+  HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  double *rs[2] = {scal.p, scal.p + 1};
+  int *done = flags.p, *iters = flags.p + 1;
+  const int g = blas_grid(n);
+  const dim3 bg(g), bw(BLAS_WG);
+  rc = launch_spmv(*m, dx.p, r.p, s);                                                   // :189-190
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
+                     r.p, (const int *)nullptr);
+  rc = cask_hip_precond_apply_device(precond, r.p, z.p, s);                             // :193
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(p.p, z.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));    // :195
+  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, z.p, partials.p, (const int *)nullptr);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  const int check_every = 16;
+  int h_flags[2] = {0, 0};
+  int launched = 0;
+  double clean_us = 0.0;
+  const bool fused = plan_fuses_dot(m->plan);
+  for (int i = 0; i < maxiters; i++) {
+    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
+    const double *pAp_part = partials.p;
+    int n_pAp = g;
+    if (fused) {
+      rc = launch_spmv(*m, p.p, Ap.p, s, p.p);                                          // :206-208
+      pAp_part = m->plan.dot_part.p;
+      n_pAp = dot_part_count(m->plan);
+    } else {
+      rc = launch_spmv(*m, p.p, Ap.p, s);
+      hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
+    }
+    if (rc) return rc;
+    // x += alpha p ; r -= alpha Ap  (:210-212; the r.r shares this kernel also leaves are not used here)
+    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rz.p,
+                       (const int *)done);
+    rc = cask_hip_precond_apply_device(precond, r.p, z.p, s);                           // :215
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, z.p, partials_rz.p, (const int *)done);   // :218
+    // rsnew = r.z ; converged? ; p = z + (rsnew/rsold) p   (:220-231)
+    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, tol * tol, i, z.p, p.p, done,
+                       iters);
+    launched = i + 1;
+    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h_flags[0]) break;
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / launched;
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (iterations) *iterations = h_flags[1];
+  if (converged) *converged = h_flags[0];
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
   return CASK_HIP_OK;
 }

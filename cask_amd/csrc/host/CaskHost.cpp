@@ -11,6 +11,7 @@
 
 #include "cask/Cask.hpp"
 #include "cask/Cg.hpp"
+#include "cask/MklLayer.hpp"
 #include "cask/Dse.hpp"
 #include "cask/SparseLinearSolvers.hpp"
 #include "cask/Spmv.hpp"
@@ -242,6 +243,67 @@ Vector DfeBiCgSolver::solve(const CsrMatrix &A, const Vector &b) {
   return run_solver(*this, A, b, cask_hip_bicg, "cask_hip_bicg");
 }
 
+// ---- preconditioning ---------------------------------------------------------------------------
+void cask_precond_deleter::operator()(void *p) const { cask_hip_precond_destroy(static_cast<cask_hip_precond *>(p)); }
+
+namespace {
+std::shared_ptr<void> make_precond(int kind, const CsrMatrix &a) {
+  cask_hip_precond *h = nullptr;
+  check(cask_hip_precond_create(kind, a.n, a.nnzs, a.row_ptr.data(), a.col_ind.data(), a.values.data(), &h),
+        "cask_hip_precond_create");
+  return std::shared_ptr<void>(h, cask_precond_deleter());
+}
+}  // namespace
+
+ILUPreconditioner::ILUPreconditioner(const CsrMatrix &a) {
+  if (!a.isSymmetric()) throw std::invalid_argument("ILUPreconditioner only supports symmetric CSR matrices");
+  if (a.n != a.m) throw std::invalid_argument("ILUPreconditioner needs a square matrix");
+  device = make_precond(CASK_HIP_PRECOND_ILU0, a);
+  CsrMatrix factored = a;
+  check(cask_hip_precond_factor_values(static_cast<cask_hip_precond *>(device.get()), factored.values.data()),
+        "cask_hip_precond_factor_values");
+  pc = factored.toDok();
+  l = CsrMatrix{pc.getLowerTriangular()};
+  u = CsrMatrix{pc.getUpperTriangular()};
+}
+
+std::vector<double> ILUPreconditioner::apply(const std::vector<double> &x) {
+  if ((int)x.size() != pc.n) throw std::invalid_argument("ILUPreconditioner::apply: vector has the wrong length");
+  std::vector<double> res(x.size());
+  check(cask_hip_precond_apply(static_cast<cask_hip_precond *>(device.get()), x.data(), res.data()),
+        "cask_hip_precond_apply");
+  return res;
+}
+
+namespace {
+bool run_pcg(const CsrMatrix &a, cask_hip_precond *pc, double *rhs, double *x, int &iterations, bool verbose,
+             cask::utils::Timer *t) {
+  if (a.n != a.m) throw std::invalid_argument("pcg needs a square matrix");
+  if (t) t->tic("cg:setup");
+  auto dev = upload(expandSymmetric(a), nullptr);      // mkl_dcsrsymv('l') semantics: a holds the lower triangle
+  if (t) t->toc("cg:setup");
+  if (t) t->tic("cg:solve");
+  int32_t it = iterations, conv = 0;
+  double us = 0;
+  check(cask_hip_pcg(dev.get(), pc, rhs, x, 2000, 1E-5, &it, &conv, &us), "cask_hip_pcg");
+  if (t) t->toc("cg:solve");
+  iterations = it;
+  if (verbose) std::cout << " iterations " << iterations << " converged " << conv << " us/iteration " << us << "\n";
+  return conv != 0;
+}
+}  // namespace
+
+bool pcgIdentity(const CsrMatrix &a, double *rhs, double *x, int &iterations, bool verbose, cask::utils::Timer *t) {
+  return run_pcg(a, nullptr, rhs, x, iterations, verbose, t);
+}
+
+bool pcgIlu(const CsrMatrix &a, double *rhs, double *x, int &iterations, bool verbose, cask::utils::Timer *t) {
+  if (t) t->tic("cg:setup");
+  ILUPreconditioner precon{a};
+  if (t) t->toc("cg:setup");
+  return run_pcg(a, static_cast<cask_hip_precond *>(precon.device.get()), rhs, x, iterations, verbose, t);
+}
+
 #ifdef CASK_HAVE_EIGEN
 Eigen::VectorXd Solver::solve(const Eigen::SparseMatrix<double> &A, const Eigen::VectorXd &b) {
   Eigen::SparseMatrix<double, Eigen::RowMajor, int32_t> R(A);
@@ -360,4 +422,28 @@ void write_dse_results(const std::vector<DseResult> &results, double took, const
 }
 
 }  // namespace dse
+namespace mkl {
+
+std::vector<double> unittrsolve(const CsrMatrix &m, const std::vector<double> &rhs, bool lowerTriangular) {
+  if ((int)rhs.size() != m.n) throw std::invalid_argument("unittrsolve: right-hand side has the wrong length");
+  std::vector<double> res(m.n);
+  check(cask_hip_trsolve(m.n, m.nnzs, m.row_ptr.data(), m.col_ind.data(), m.values.data(), lowerTriangular ? 1 : 0,
+                         rhs.data(), res.data()),
+        "cask_hip_trsolve");
+  return res;
+}
+
+void unittrsolve(const double *values, const int *row_ptr, const int *col_ind, const std::vector<double> &rhs,
+                 double *res, bool lowerTriangular) {
+  const int n = (int)rhs.size();
+  std::vector<int> rp(row_ptr, row_ptr + n + 1);
+  for (int &v : rp) v -= 1;                                   // the reference hands MKL 1-based arrays
+  std::vector<int> ci(col_ind, col_ind + rp[n]);
+  for (int &v : ci) v -= 1;
+  check(cask_hip_trsolve(n, rp[n], rp.data(), ci.data(), values, lowerTriangular ? 1 : 0, rhs.data(), res),
+        "cask_hip_trsolve");
+}
+
+}  // namespace mkl
+
 }  // namespace cask

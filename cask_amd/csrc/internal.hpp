@@ -1,8 +1,37 @@
 // Shared between the translation units of libcask_hip.so (not installed).
 #pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <string>
+#include <vector>
 
 namespace caskhip {
 // records the thread-local message behind cask_hip_last_error() and returns `code`
 int report_failure(int code, const std::string &msg);
+
+// Owning device buffer.
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+  }
+  hipError_t upload(const T *h, size_t count) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  hipError_t upload(const std::vector<T> &h) { return upload(h.data(), h.size()); }
+};
+
 }  // namespace caskhip

@@ -8,6 +8,8 @@
 #ifndef CASK_SPARSE_LINEAR_SOLVERS_HPP
 #define CASK_SPARSE_LINEAR_SOLVERS_HPP
 
+#include <memory>
+
 #include "SparseMatrix.hpp"
 #include "Utils.hpp"
 
@@ -64,6 +66,49 @@ class IdentityPreconditioner {
   virtual ~IdentityPreconditioner() {}
   virtual std::vector<double> apply(const std::vector<double> &x) { return x; }
 };
+
+// ILU(0) preconditioner with the reference's members and semantics (SparseLinearSolvers.hpp:77-156):
+// `pc` is the factored matrix in the pattern of `a`, `l` / `u` its lower / upper triangle INCLUDING the
+// diagonal, apply() solves with both of them dividing by that diagonal (mkl_dcsrtrsv, diag 'N').  The
+// factorisation runs once on the host, every apply() on the GPU (level-scheduled triangular solves).
+struct cask_precond_deleter { void operator()(void *p) const; };
+class ILUPreconditioner {
+ public:
+  DokMatrix pc;
+  CsrMatrix l, u;
+  std::shared_ptr<void> device;                  // cask_hip_precond*
+
+  // pre - a is a symmetric matrix (the reference only checks CsrMatrix::isSymmetric(), which is `true`)
+  ILUPreconditioner(const CsrMatrix &a);
+  virtual ~ILUPreconditioner() {}
+  virtual std::vector<double> apply(const std::vector<double> &x);
+  void pretty_print() { pc.pretty_print(); }
+};
+
+// Standard preconditioned CG with the reference's signature and constants (tol 1E-5, 2000 passes,
+// SparseLinearSolvers.hpp:162-239): `a` is the stored (lower) triangle of a symmetric matrix, as
+// SymCsrMatrix::matrix holds it; the preconditioner is built from that same CsrMatrix (:171); `x`
+// holds the initial guess; `iterations` is written at the end of every non-converged pass.
+// Returns true when r.z <= tol^2 was reached.  Runs on the GPU (cask_hip_pcg).
+bool pcgIdentity(const CsrMatrix &a, double *rhs, double *x, int &iterations, bool verbose, cask::utils::Timer *t);
+bool pcgIlu(const CsrMatrix &a, double *rhs, double *x, int &iterations, bool verbose, cask::utils::Timer *t);
+template <typename Precon> struct PcgDispatch;
+template <> struct PcgDispatch<IdentityPreconditioner> {
+  static bool run(const CsrMatrix &a, double *rhs, double *x, int &it, bool v, cask::utils::Timer *t) {
+    return pcgIdentity(a, rhs, x, it, v, t);
+  }
+};
+template <> struct PcgDispatch<ILUPreconditioner> {
+  static bool run(const CsrMatrix &a, double *rhs, double *x, int &it, bool v, cask::utils::Timer *t) {
+    return pcgIlu(a, rhs, x, it, v, t);
+  }
+};
+template <typename T = double, typename Precon = IdentityPreconditioner>
+bool pcg(const CsrMatrix &a, double *rhs, double *x, int &iterations, bool verbose = false,
+         cask::utils::Timer *t = nullptr) {
+  static_assert(sizeof(T) == sizeof(double), "the GPU solvers are fp64");
+  return PcgDispatch<Precon>::run(a, rhs, x, iterations, verbose, t);
+}
 
 }  // namespace sparse_linear_solvers
 }  // namespace cask

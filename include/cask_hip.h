@@ -195,6 +195,48 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
 int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
                   int32_t *iterations, int32_t *converged, double *usec_per_iteration);
 
+/* ---- preconditioning -------------------------------------------------------------
+ * The reference's preconditioned CG, pcg<T, Precon> (src/runtime/SparseLinearSolvers.hpp:162-239),
+ * knows IdentityPreconditioner (:64-74) and ILUPreconditioner (:77-156): an ILU(0) sweep on the
+ * pattern of the matrix, then z = U^-1 (L^-1 r) with two mkl_dcsrtrsv calls on the factors
+ * extracted WITH the diagonal (src/runtime/MklLayer.hpp:29-85).  Here the factorisation runs once on
+ * the host (it is sequential in the reference too) and every application on the device:
+ * level-scheduled triangular solves.  JACOBI (z = r / diag) has no reference counterpart; it is the
+ * preconditioner that costs one streaming pass.  ILU0 reproduces the reference bit for bit,
+ * including that its "L" solve divides by U's diagonal (L is extracted with the diagonal of the
+ * factored matrix): M is then not A's incomplete factorisation and PCG stagnates on most systems --
+ * the reference's own test pins the iterate after 2000 stagnating passes
+ * (test/LinearSolvers.cpp:54-77).  ILU0_UNIT applies the same factors the textbook way (unit lower
+ * diagonal) and is the one to use for solving.  A preconditioner handle is built from ANY square
+ * CSR matrix with strictly ascending columns per row (the reference hands pcg the lower triangle of
+ * a symmetric matrix and factors exactly that). */
+typedef struct cask_hip_precond cask_hip_precond;
+#define CASK_HIP_PRECOND_JACOBI    1
+#define CASK_HIP_PRECOND_ILU0      2   /* the reference's: both triangular solves divide by the stored diagonal */
+#define CASK_HIP_PRECOND_ILU0_UNIT 3   /* textbook ILU(0): same factors, L applied with a unit diagonal          */
+int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t *row_ptr,
+                            const int32_t *col_ind, const double *values, cask_hip_precond **out);
+int cask_hip_precond_destroy(cask_hip_precond *p);
+/* ILU0: the factored values in the pattern of the input (ILUPreconditioner::pc): strictly-lower
+ * entries hold the multipliers, the rest the upper factor. */
+int cask_hip_precond_factor_values(const cask_hip_precond *p, double *values_out);
+/* dependency levels of the two triangular solves and kernel launches per application */
+int cask_hip_precond_info(const cask_hip_precond *p, int32_t *levels_lower, int32_t *levels_upper,
+                          int32_t *launches_per_apply);
+/* z = M^-1 r: host vectors (ILUPreconditioner::apply, :143-151) / device vectors on `stream` */
+int cask_hip_precond_apply(cask_hip_precond *p, const double *r, double *z);
+int cask_hip_precond_apply_device(cask_hip_precond *p, const double *d_r, double *d_z, void *stream);
+/* Solve T x = rhs with the lower (lower != 0) or upper triangle of a CSR matrix, diagonal taken
+ * from the matrix: cask::mkl::unittrsolve (src/runtime/MklLayer.hpp:29-85, mkl_dcsrtrsv with
+ * diag = 'N').  Host vectors; level-scheduled on the device. */
+int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32_t *col_ind,
+                     const double *values, int32_t lower, const double *rhs, double *x);
+/* Preconditioned CG on a full symmetric CSR handle; precond == NULL is cask_hip_cg.  The test is
+ * r.z <= tol^2 like the reference's. */
+int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x,
+                 int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
+                 double *usec_per_iteration);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,14 @@ def lib() -> ctypes.CDLL:
             f = getattr(L, name)
             f.argtypes = [i32, p, p, p, p, p, i32, dbl, ctypes.POINTER(i32)]
             f.restype = ctypes.c_int
+        L.oracle_ilu0.argtypes = [i32, p, p, p]
+        L.oracle_ilu0.restype = None
+        L.oracle_trsolve.argtypes = [i32, p, p, p, ctypes.c_int, p, p]
+        L.oracle_trsolve.restype = None
+        L.oracle_ilu_apply.argtypes = [i32, p, p, p, p, p, p]
+        L.oracle_ilu_apply.restype = None
+        L.oracle_pcg_precond.argtypes = [i32, p, p, p, ctypes.c_int, ctypes.c_int, p, p, i32, dbl, ctypes.POINTER(i32)]
+        L.oracle_pcg_precond.restype = ctypes.c_int
         L.oracle_partition_decode_spmv.argtypes = [i32, i32, i32, i32, i32, p, i64, p, i64, p, p]
         L.oracle_partition_decode_spmv.restype = ctypes.c_int
         _lib = L
@@ -182,6 +190,48 @@ def cg_full(row_ptr, col_ind, values, rhs, x0=None, maxiters=2000, tol=1e-5):
 def bicg(row_ptr, col_ind, values, rhs, x0=None, maxiters=2000, tol=1e-5):
     """Classical BiCG (parity unpinned: no reference body)."""
     return _solve(lib().oracle_bicg, row_ptr, col_ind, values, rhs, x0, maxiters, tol)
+
+
+def ilu0(row_ptr, col_ind, values) -> np.ndarray:
+    """Factored values in the input pattern: ILUPreconditioner::pc (SparseLinearSolvers.hpp:88-113)."""
+    row_ptr, col_ind = _i32(row_ptr), _i32(col_ind)
+    a = _f64(values).copy()
+    lib().oracle_ilu0(row_ptr.size - 1, _ptr(row_ptr), _ptr(col_ind), _ptr(a))
+    return a
+
+
+def trsolve(row_ptr, col_ind, values, rhs, lower=True) -> np.ndarray:
+    """cask::mkl::unittrsolve (MklLayer.hpp:29-85): triangle + its diagonal, textbook substitution."""
+    row_ptr, col_ind, values, rhs = _i32(row_ptr), _i32(col_ind), _f64(values), _f64(rhs)
+    n = row_ptr.size - 1
+    x = np.zeros(n, dtype=np.float64)
+    lib().oracle_trsolve(n, _ptr(row_ptr), _ptr(col_ind), _ptr(values), int(bool(lower)), _ptr(rhs), _ptr(x))
+    return x
+
+
+def ilu_apply(row_ptr, col_ind, factored, r) -> np.ndarray:
+    """ILUPreconditioner::apply (:143-151) given the factored values."""
+    row_ptr, col_ind, factored, r = _i32(row_ptr), _i32(col_ind), _f64(factored), _f64(r)
+    n = row_ptr.size - 1
+    tmp, z = np.zeros(n), np.zeros(n)
+    lib().oracle_ilu_apply(n, _ptr(row_ptr), _ptr(col_ind), _ptr(factored), _ptr(r), _ptr(tmp), _ptr(z))
+    return z
+
+
+def pcg_precond(row_ptr, col_ind, values, rhs, kind="ilu0", x0=None, maxiters=2000, tol=1e-5, full=False):
+    """pcg<double, ILUPreconditioner> on a LOWER-triangular symmetric CSR (kind="jacobi": z = r/diag;
+    kind="ilu0_unit": the ILU factors applied with a unit lower diagonal, the textbook way);
+    full=True: the arrays hold the whole symmetric matrix (product and preconditioner see all of it).
+    Returns (x, iterations, converged)."""
+    row_ptr, col_ind, values, rhs = _i32(row_ptr), _i32(col_ind), _f64(values), _f64(rhs)
+    n = row_ptr.size - 1
+    x = np.zeros(n) if x0 is None else _f64(x0).copy()
+    it = ctypes.c_int32(0)
+    rc = lib().oracle_pcg_precond(n, _ptr(row_ptr), _ptr(col_ind), _ptr(values), {"ilu0": 0, "jacobi": 1, "ilu0_unit": 2}[kind], int(bool(full)), _ptr(rhs),
+                                  _ptr(x), int(maxiters), float(tol), ctypes.byref(it))
+    if rc < 0:
+        raise MemoryError("oracle solver")
+    return x, int(it.value), bool(rc)
 
 
 def partition_decode_spmv(n_rows, n_blocks, cache_size, input_width, rle, colptr, records, x):

@@ -216,6 +216,139 @@ int oracle_cg_full(int32_t n, const int32_t *row_ptr, const int32_t *col_ind,
     return converged;
 }
 
+/* ---- preconditioning: ILUPreconditioner, unittrsolve, pcg<double, ILUPreconditioner> ----------- */
+
+/* position of (r, c) in a CSR row with ascending columns, or -1 (DokMatrix::isNnz, SparseMatrix.hpp) */
+static int64_t csr_find(const int32_t *row_ptr, const int32_t *col_ind, int32_t r, int32_t c)
+{
+    for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++)
+        if (col_ind[k] == c) return k;
+    return -1;
+}
+
+/* In-place ILU(0) of ILUPreconditioner's constructor (SparseLinearSolvers.hpp:88-113), statement by
+ * statement: for i = 1..n-1, for every stored (i,k) in ascending k while k < i: skip if (k,k) is not
+ * stored; a[i][k] /= a[k][k]; then for every stored (i,j) with j >= k+1: if (k,j) is stored,
+ * a[i][j] -= a[k][j] * a[i][k].  Columns must ascend within a row (the reference iterates a std::map). */
+void oracle_ilu0(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, double *a)
+{
+    for (int32_t i = 1; i < n; i++) {
+        for (int64_t kk = row_ptr[i]; kk < row_ptr[i + 1]; kk++) {
+            const int32_t k = col_ind[kk];
+            if (k >= i) break;
+            const int64_t dk = csr_find(row_ptr, col_ind, k, k);
+            if (dk < 0) continue;
+            a[kk] = a[kk] / a[dk];
+            const double beta = a[kk];
+            for (int64_t jj = row_ptr[i]; jj < row_ptr[i + 1]; jj++) {
+                const int32_t j = col_ind[jj];
+                if (j < k + 1) continue;
+                const int64_t kj = csr_find(row_ptr, col_ind, k, j);
+                if (kj >= 0) a[jj] = a[jj] - a[kj] * beta;
+            }
+        }
+    }
+}
+
+/* x = T^-1 b for the lower (lower != 0) or upper triangle of a CSR matrix with the diagonal taken from
+ * the matrix: mkl_dcsrtrsv(uplo, 'N', 'N') as cask::mkl::unittrsolve calls it (MklLayer.hpp:29-85).
+ * MKL is a binary; the restatement is the textbook substitution over the stored entries in order. */
+static void trsolve_impl(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, const double *values,
+                         int lower, int unit, const double *b, double *x)
+{
+    for (int32_t step = 0; step < n; step++) {
+        const int32_t r = lower ? step : n - 1 - step;
+        double s = b[r], diag = 0.0;
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+            const int32_t c = col_ind[k];
+            if (c == r) diag = values[k];
+            else if (lower ? c < r : c > r) s -= values[k] * x[c];
+        }
+        x[r] = unit ? s : s / diag;
+    }
+}
+void oracle_trsolve(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, const double *values,
+                    int lower, const double *b, double *x)
+{
+    trsolve_impl(n, row_ptr, col_ind, values, lower, 0, b, x);
+}
+
+/* z = U^-1 (L^-1 r) with L / U = lower / upper triangle of the factored matrix INCLUDING its diagonal
+ * (ILUPreconditioner::apply :143-151 over getLowerTriangular/getUpperTriangular, SparseMatrix.hpp:227-253). */
+void oracle_ilu_apply(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, const double *factored,
+                      const double *r, double *tmp, double *z)
+{
+    oracle_trsolve(n, row_ptr, col_ind, factored, 1, r, tmp);
+    oracle_trsolve(n, row_ptr, col_ind, factored, 0, tmp, z);
+}
+/* the textbook application of the same factors: unit diagonal in L (not what the reference does) */
+void oracle_ilu_apply_unit(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, const double *factored,
+                           const double *r, double *tmp, double *z)
+{
+    trsolve_impl(n, row_ptr, col_ind, factored, 1, 1, r, tmp);
+    trsolve_impl(n, row_ptr, col_ind, factored, 0, 0, tmp, z);
+}
+
+/* pcg<double, ILUPreconditioner> (SparseLinearSolvers.hpp:162-239): the matrix is given by its LOWER
+ * triangle, which is also what the preconditioner factors (`Precon precon{a}` :171 receives the same
+ * CsrMatrix the symmetric product uses).  jacobi = 1 replaces the ILU by z = r / diag, jacobi = 2 applies
+ * the ILU factors with a unit lower diagonal (neither has a reference counterpart; same recurrence).  full != 0: the arrays hold the whole symmetric matrix instead -- product
+ * and preconditioner both see all of it (the sensible use; what a GPU solve over io::readMatrix output does).
+ * Returns 1 converged / 0 not / -1 out of memory. */
+int oracle_pcg_precond(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, const double *values,
+                       int jacobi, int full, const double *rhs, double *x, int32_t maxiters, double tol,
+                       int32_t *iterations)
+{
+    const int64_t nnz = row_ptr[n];
+    size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    double *r = (double *)malloc(nb), *z = (double *)malloc(nb), *p = (double *)malloc(nb);
+    double *Ap = (double *)malloc(nb), *tmp = (double *)malloc(nb);
+    double *f = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+    if (!r || !z || !p || !Ap || !tmp || !f) { free(r); free(z); free(p); free(Ap); free(tmp); free(f); return -1; }
+    memcpy(f, values, (size_t)nnz * sizeof(double));
+    if (jacobi != 1) oracle_ilu0(n, row_ptr, col_ind, f);
+#define ORACLE_PRECOND(src, dst)                                                              \
+    do {                                                                                      \
+        if (jacobi == 2) {                                                                    \
+            oracle_ilu_apply_unit(n, row_ptr, col_ind, f, (src), tmp, (dst));                 \
+        } else if (jacobi) {                                                                  \
+            for (int32_t q = 0; q < n; q++) {                                                 \
+                const int64_t dq = csr_find(row_ptr, col_ind, q, q);                          \
+                (dst)[q] = (dq >= 0 && values[dq] != 0.0) ? (src)[q] * (1.0 / values[dq]) : (src)[q]; \
+            }                                                                                 \
+        } else {                                                                              \
+            oracle_ilu_apply(n, row_ptr, col_ind, f, (src), tmp, (dst));                      \
+        }                                                                                     \
+    } while (0)
+    int converged = 0;
+#define ORACLE_PRODUCT(src, dst)                                                              \
+    do {                                                                                      \
+        if (full) oracle_csr_spmv(n, row_ptr, col_ind, values, (src), (dst));                 \
+        else      oracle_symcsr_spmv(n, row_ptr, col_ind, values, (src), (dst));              \
+    } while (0)
+    ORACLE_PRODUCT(x, r);                                          /* :189-190 */
+    oracle_daxpby(n, 1.0, rhs, -1.0, r);
+    ORACLE_PRECOND(r, z);                                          /* :193 */
+    memcpy(p, z, (size_t)n * sizeof(double));                      /* :195 */
+    double rsold = oracle_ddot(n, r, z);                           /* :198 */
+    for (int32_t i = 0; i < maxiters; i++) {
+        ORACLE_PRODUCT(p, Ap);                                     /* :206 */
+        double alpha = rsold / oracle_ddot(n, p, Ap);              /* :208 */
+        oracle_daxpy(n, alpha, p, x);                              /* :210 */
+        oracle_daxpby(n, -alpha, Ap, 1.0, r);                      /* :212 */
+        ORACLE_PRECOND(r, z);                                      /* :215 */
+        double rsnew = oracle_ddot(n, r, z);                       /* :218 */
+        if (rsnew <= tol * tol) { converged = 1; break; }          /* :220-226 */
+        oracle_daxpby(n, 1.0, z, rsnew / rsold, p);                /* :229 */
+        rsold = rsnew;
+        *iterations = i;                                           /* :231 */
+    }
+#undef ORACLE_PRECOND
+#undef ORACLE_PRODUCT
+    free(r); free(z); free(p); free(Ap); free(tmp); free(f);
+    return converged;
+}
+
 /* Classical (Fletcher) BiCG on a general CSR matrix with A and A^T products.
  * PARITY UNPINNED: the reference declares DfeBiCgSolver::solve but never
  * defines it (SparseLinearSolvers.hpp:56-61) and its only working solver is

@@ -82,6 +82,15 @@ def test_integration_client_over_reference_fixtures(plain_mtx_dir):
 
 
 @pytest.mark.gpu
+def test_preconditioning_client_known_answers(plain_mtx_dir):
+    """test/MklLayer.cpp + the ILU tests of test/LinearSolvers.cpp through the C++ surface, on the GPU."""
+    make("clients")
+    out = subprocess.run([str(REPO / "build" / "test_precond_hip"), str(plain_mtx_dir / "systems")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-600:], out.stderr[-600:])
+
+
+@pytest.mark.gpu
 def test_dse_executable_writes_dse_out(plain_mtx_dir, tmp_path):
     make("build/main")
     out = subprocess.run([str(REPO / "build" / "main"), str(plain_mtx_dir / "benchmark"),

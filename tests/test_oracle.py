@@ -233,3 +233,70 @@ def test_dfe_format_restatement_decodes_to_the_product(arch, expected_y):
         oracle.assert_almost_equal(y, expected_y[key], what=f"{key} {arch}")
         for p in parts:                                   # Spmv.cpp:76-77: records padded per block to input_width
             assert p["records"].size % width == 0 and p["colptr"].size == p["n"] * p["n_blocks"]
+
+
+# ---- preconditioning known answers (test/LinearSolvers.cpp:54-146, test/MklLayer.cpp:10-50) ------
+
+def _dense_to_csr(rows):
+    a = sp.csr_matrix(np.array(rows, dtype=np.float64))
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
+
+
+def test_ilu_factor_and_apply_known_answers(known_answers):
+    c = known_answers["ilu"]["factor_cases"][0]
+    rp, ci, va = _dense_to_csr(c["dense_rows"])
+    f = oracle.ilu0(rp, ci, va)
+    got = sp.csr_matrix((f, ci, rp), shape=(4, 4)).toarray()
+    assert np.array_equal(got, np.array(c["factored_rows"], dtype=np.float64))          # ASSERT_EQ
+    z = oracle.ilu_apply(rp, ci, f, c["apply_to"])
+    assert all(ulp_close(g, e) for g, e in zip(z, c["apply_expected"])), z
+    # ILUCompute: the explicitly symmetric tinysym factors to all ones in its own pattern
+    c2 = known_answers["ilu"]["factor_cases"][1]
+    m = mmio.read_matrix(GOLDEN / c2["matrix_explicit_symmetric"])
+    assert list(m.row_ptr) == c2["factored_csr"]["row_ptr"] and list(m.col_ind) == c2["factored_csr"]["col_ind"]
+    assert list(oracle.ilu0(m.row_ptr, m.col_ind, m.values)) == c2["factored_csr"]["values"]
+
+
+def test_unittrsolve_known_answers(known_answers):
+    for c in known_answers["unittrsolve"]["cases"]:
+        rp, ci, va = _dense_to_csr(c["dense_rows"])
+        x = oracle.trsolve(rp, ci, va, c["rhs"], lower=c["lower"])
+        assert list(x) == c["expected"], (c, x)                                             # ASSERT_EQ
+
+
+def test_pcg_with_ilu_known_answer(known_answers):
+    """CGSymWithILUPC: the preconditioner is built from the stored LOWER triangle, the iteration
+    stagnates for all 2000 passes and the reference pins where it ends up (4 ULP)."""
+    c = known_answers["ilu"]["pcg_ilu"]
+    low = mmio.read_sym_matrix(GOLDEN / c["matrix"])
+    rhs = mmio.read_vector(GOLDEN / c["rhs"])
+    x, iters, conv = oracle.pcg_precond(low.row_ptr, low.col_ind, low.values, rhs, kind="ilu0")
+    assert conv == c["converges"] and iters == 1999
+    assert all(ulp_close(g, e) for g, e in zip(x, c["expected"])), [float(v).hex() for v in x]
+
+
+def test_pcg_precond_solves_spd_systems():
+    """On a diagonally dominant SPD matrix both preconditioners converge to the solution (the ILU is built
+    from the stored LOWER triangle, as the reference's pcg does, so it is no better than Jacobi)."""
+    n, rp, ci, va = synth_small_spd()
+    low = sp.tril(sp.csr_matrix((va, ci, rp), shape=(n, n))).tocsr()
+    low.sort_indices()
+    x0 = np.random.default_rng(4).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    its = {}
+    for kind in ("jacobi", "ilu0"):
+        x, it, conv = oracle.pcg_precond(low.indptr, low.indices, low.data, b, kind=kind, tol=1e-10)
+        assert conv
+        np.testing.assert_allclose(x, x0, rtol=1e-7, atol=1e-9)
+        its[kind] = it
+    assert max(its.values()) < 200
+
+
+def synth_small_spd(n=400, seed=6):
+    rng = np.random.default_rng(seed)
+    a = sp.random(n, n, 0.02, format="csr", random_state=rng)
+    a = a + a.T + sp.diags(np.full(n, 1.0) + np.abs(a + a.T).sum(axis=1).A1)
+    a = sp.csr_matrix(a)
+    a.sort_indices()
+    return n, a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)

@@ -1,0 +1,150 @@
+"""Preconditioning on the device against the oracle and the reference's known answers:
+ILU(0) factor values (test/LinearSolvers.cpp:79-123), ILUPreconditioner::apply (:125-146), unittrsolve
+(test/MklLayer.cpp:10-50, exact), pcg<double, ILUPreconditioner> (:54-77) and the level-scheduled
+triangular solves on matrices with thousands of dependency levels.
+
+Tolerances: factor values are computed by the same statements in the same order on the host ->
+bitwise equal to the oracle; triangular solves run the same per-row substitution but the device
+contracts "s -= v*x" into an FMA -> the reference's almost_equal(1e-8, 1e-11) against the oracle
+(exact on the known answers); pcg sums dots in a different (tree) order -> relative 1e-10 against the oracle at
+convergence, and 1e-9 relative after the 2000 stagnating passes of the reference's ILU test."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from oracle import mmio
+from cask_amd import capi, synth
+from conftest import GOLDEN, have_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a GPU")]
+
+
+def dense_csr(rows):
+    a = sp.csr_matrix(np.array(rows, dtype=np.float64))
+    a.sort_indices()
+    return a.shape[0], a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
+
+
+def test_ilu_known_answers(known_answers):
+    c = known_answers["ilu"]["factor_cases"][0]
+    n, rp, ci, va = dense_csr(c["dense_rows"])
+    pc = capi.Preconditioner("ilu0", n, rp, ci, va)
+    got = sp.csr_matrix((pc.factor_values(), ci, rp), shape=(n, n)).toarray()
+    assert np.array_equal(got, np.array(c["factored_rows"], dtype=np.float64))
+    assert list(pc.apply(c["apply_to"])) == c["apply_expected"]
+    pc.close()
+    c2 = known_answers["ilu"]["factor_cases"][1]
+    m = mmio.read_matrix(GOLDEN / c2["matrix_explicit_symmetric"])
+    pc = capi.Preconditioner("ilu0", m.n, m.row_ptr, m.col_ind, m.values)
+    assert list(pc.factor_values()) == c2["factored_csr"]["values"]
+    pc.close()
+
+
+def test_unittrsolve_known_answers(known_answers):
+    for c in known_answers["unittrsolve"]["cases"]:
+        n, rp, ci, va = dense_csr(c["dense_rows"])
+        assert list(capi.trsolve(n, rp, ci, va, c["rhs"], lower=c["lower"])) == c["expected"]
+
+
+def test_pcg_ilu_known_answer(known_answers):
+    c = known_answers["ilu"]["pcg_ilu"]
+    low = mmio.read_sym_matrix(GOLDEN / c["matrix"])
+    full = mmio.read_matrix(GOLDEN / c["matrix"])
+    rhs = mmio.read_vector(GOLDEN / c["rhs"])
+    pc = capi.Preconditioner("ilu0", low.n, low.row_ptr, low.col_ind, low.values)     # the stored triangle (:171)
+    m = capi.CsrMatrix.from_host(full.n, full.m, full.row_ptr, full.col_ind, full.values)
+    x, it, conv, _ = m.pcg(pc, rhs)
+    assert not conv and it == 1999
+    np.testing.assert_allclose(x, c["expected"], rtol=1e-9)
+    m.close()
+    pc.close()
+
+
+@pytest.mark.parametrize("name", ["G3_circuit", "cant", "atmosmodd"])
+def test_ilu_factor_and_solves_match_the_oracle(name):
+    n, rp, ci, va = synth.small(name)
+    pc = capi.Preconditioner("ilu0", n, rp, ci, va)
+    f = pc.factor_values()
+    assert np.array_equal(f, oracle.ilu0(rp, ci, va))
+    info = pc.info()
+    assert info["levels_lower"] > 1 and info["levels_upper"] > 1 and info["launches_per_apply"] >= 2
+    r = np.random.default_rng(2).uniform(-1, 1, n)
+    z = pc.apply(r)
+    oracle.assert_almost_equal(z, oracle.ilu_apply(rp, ci, f, r), what="ILU apply")
+    # the two triangles on their own
+    for lower in (True, False):
+        oracle.assert_almost_equal(capi.trsolve(n, rp, ci, f, r, lower=lower), oracle.trsolve(rp, ci, f, r, lower=lower),
+                                   what=f"trsolve lower={lower}")
+    pc.close()
+
+
+def test_wide_levels_get_their_own_launch():
+    """A diagonal block structure: one level with 40 000 independent rows, then a dependent level."""
+    n = 60_000
+    rows = np.concatenate([np.arange(n), np.arange(40_000, n)])
+    cols = np.concatenate([np.arange(n), np.arange(0, 20_000)])
+    vals = np.concatenate([np.full(n, 2.0), np.full(20_000, -1.0)])
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    a.sort_indices()
+    rp, ci, va = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    b = np.random.default_rng(1).standard_normal(n)
+    oracle.assert_almost_equal(capi.trsolve(n, rp, ci, va, b, lower=True), oracle.trsolve(rp, ci, va, b, lower=True))
+
+
+@pytest.mark.parametrize("kind", ["jacobi", "ilu0_unit"])
+def test_pcg_converges_like_the_oracle(kind):
+    """Whole symmetric matrix for product and preconditioner; ILU applied the textbook way (the reference's
+    application divides by the diagonal twice: pinned by its known answer above and by the few-pass test
+    below -- PCG stagnates with it)."""
+    n, rp, ci, va = synth.small("G3_circuit")
+    x0 = np.random.default_rng(5).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, it_want, conv_want = oracle.pcg_precond(rp, ci, va, b, kind=kind, tol=1e-9, full=True)
+    pc = capi.Preconditioner(kind, n, rp, ci, va)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    x, it, conv, us = m.pcg(pc, b, tol=1e-9)
+    assert conv and conv_want and abs(it - it_want) <= 2, (conv, conv_want, it, it_want)
+    np.testing.assert_allclose(x, want, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(x, x0, rtol=1e-6, atol=1e-8)
+    m.close()
+    pc.close()
+
+
+def test_reference_ilu_recurrence_first_passes():
+    """The reference's ILU application on a real system: compare the iterate after 6 passes with the oracle."""
+    n, rp, ci, va = synth.small("G3_circuit")
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    low = sp.tril(a).tocsr()
+    low.sort_indices()
+    b = oracle.csr_spmv(rp, ci, va, np.random.default_rng(8).uniform(-1, 1, n))
+    want, _, _ = oracle.pcg_precond(low.indptr, low.indices, low.data, b, kind="ilu0", maxiters=6, tol=1e-30)
+    pc = capi.Preconditioner("ilu0", n, low.indptr, low.indices, low.data)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    x, it, conv, _ = m.pcg(pc, b, maxiters=6, tol=1e-30)
+    assert not conv and it == 5
+    np.testing.assert_allclose(x, want, rtol=1e-9, atol=1e-12)
+    m.close()
+    pc.close()
+
+
+def test_pcg_with_textbook_ilu_beats_plain_cg():
+    """ILU(0) of the whole matrix applied with a unit lower diagonal is a real preconditioner."""
+    n, rp, ci, va = synth.small("G3_circuit")
+    x0 = np.random.default_rng(6).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    _, it_plain, conv_plain, _ = m.cg(b, tol=1e-9)
+    pc = capi.Preconditioner("ilu0_unit", n, rp, ci, va)
+    x, it_ilu, conv_ilu, _ = m.pcg(pc, b, tol=1e-9)
+    assert conv_plain and conv_ilu and it_ilu < it_plain
+    np.testing.assert_allclose(x, x0, rtol=1e-6, atol=1e-8)
+    m.close()
+    pc.close()
+
+
+def test_argument_checks():
+    with pytest.raises(ValueError, match="ascending"):
+        capi.Preconditioner("ilu0", 2, [0, 2, 2], [1, 0], [1.0, 2.0])
+    with pytest.raises(ValueError, match="kind"):
+        capi.Preconditioner(7, 1, [0, 1], [0], [1.0])

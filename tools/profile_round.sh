@@ -1,24 +1,33 @@
 #!/bin/bash
 # Round profile for the headline bench (run on the GPU box via gpurun):
-#   tools/profile_round.sh <tag>     e.g. r01
+#   tools/profile_round.sh <tag> [workload ...]     e.g. r01 cant webbase-1M
 # 1. bench.py as the driver runs it              -> gpurun_out/bench_<tag>.json
 # 2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/prof_<tag>/
-# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, for the SpMV
+# 3. HBM traffic per workload: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, for the SpMV
 #    kernel and for a calibration kernel that streams a known byte count with the
 #    same 16-byte access shape (tools/membench.hip k_oneshot), because gfx950's
 #    FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM).
 set -u
 tag=${1:-r01}
+shift || true
+workloads=${*:-cant}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
+make build/membench > /dev/null 2>&1
 python3 bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
 cat $out/bench_$tag.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline > $out/prof_$tag.json 2> $out/prof_$tag.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_spmv_$c -- python3 $root/bench.py --steps 40 --warmup 10 --launch eager --no-cpu-baseline > /dev/null 2> $out/pmc_${tag}_spmv_$c.err
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
+  for w in $workloads; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline > /dev/null 2> $out/pmc_${tag}_${w}_$c.err
+  done
 done
-python3 $root/tools/traffic_summary.py $tag
+for w in $workloads; do python3 $root/tools/traffic_summary.py $tag $w; done
+# gpurun copies back at most 64 MiB: keep the summaries, drop the per-dispatch traces
+find $out -name "*counter_collection.csv" -delete
+find $out -path "*pmc_*" -name "*kernel_trace.csv" -delete
+find $out -path "*prof_*" -name "*kernel_trace.csv" -delete

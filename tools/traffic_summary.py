@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turn the PMC passes of tools/profile_round.sh into profiles/traffic_cant.json.
+"""Turn the PMC passes of tools/profile_round.sh into gpurun_out/traffic_<workload>_<tag>.json
+(copied to profiles/traffic_<workload>.json, which bench.py reads into roofline.traffic).
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  The calibration kernel (tools/membench.hip
 k_oneshot<8,true>) reads exactly 12*nnz bytes with 16-byte-per-lane nontemporal
@@ -15,6 +16,7 @@ import sys
 from pathlib import Path
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload = sys.argv[2] if len(sys.argv) > 2 else "cant"
 root = Path(__file__).resolve().parent.parent
 out = root / "gpurun_out"
 
@@ -36,8 +38,8 @@ factor = known / (fetch_cal * 1024.0) if fetch_cal else None
 res = {"tag": tag, "calibration": {"kernel": "k_oneshot<8,true> (tools/membench.hip)", "known_bytes": known,
                                    "FETCH_SIZE_KiB": fetch_cal, "factor": factor, "samples": n1}}
 for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
-    f, nf = counter(f"pmc_{tag}_spmv_FETCH_SIZE", kern, "FETCH_SIZE")
-    w, nw = counter(f"pmc_{tag}_spmv_WRITE_SIZE", kern, "WRITE_SIZE")
+    f, nf = counter(f"pmc_{tag}_{workload}_FETCH_SIZE", kern, "FETCH_SIZE")
+    w, nw = counter(f"pmc_{tag}_{workload}_WRITE_SIZE", kern, "WRITE_SIZE")
     if f is None:
         continue
     res["kernel"] = kern.rstrip("<")
@@ -48,4 +50,5 @@ for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
         res["hbm_bytes_per_launch"] = round(f * 1024.0 * factor + (w or 0) * 1024.0)
     break
 print(json.dumps(res, indent=1))
-(root / "gpurun_out" / f"traffic_{tag}.json").write_text(json.dumps(res, indent=1))
+res["workload"] = workload
+(root / "gpurun_out" / f"traffic_{workload}_{tag}.json").write_text(json.dumps(res, indent=1))
