@@ -5,16 +5,19 @@
 
 A "step" is one pass of the hot path: y = A x over the whole matrix resident in
 HBM.  For N > 1 (weak scaling: every rank owns one cant-sized row block of a
-block-banded global matrix, and the slice of x that goes with it) a step is the
-exchange of the x entries the block references, then the local row-block
-product.  The exchange is peer-to-peer: a small kernel pulls the halo entries
-over xGMI straight from the neighbours' shared x slices (cask_amd/p2p.py) -- no
-collective on the data path; if the slices cannot be mapped the step falls back
-to an RCCL all-gather of x.  To make the number an HBM number and not an Infinity-
-Cache number the steps rotate through enough device copies of the matrix to
-exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one copy is
-reported next to it.  The K timed steps are captured once into a HIP graph
-(one kernel node per step) so the host's launch rate is not what is measured.
+block-banded global matrix, and the slice of x that goes with it) a step is still
+ONE launch per rank: the x slices live in shared allocations and the product
+kernel's seam workgroups load the halo entries they need straight from the
+neighbours' slices over xGMI (cask_hip_csr_set_halo_sources, cask_amd/p2p.py) --
+no collective, no copy and no exchange kernel on the data path.  That mode is
+verified bit-for-bit against the halo-pull mode (a small kernel in front of the
+product) before it is timed; if the slices cannot be mapped the step falls back
+to the pull, then to an RCCL all-gather of x.  To make the number an HBM number
+and not an Infinity-Cache number the steps rotate through enough device copies of
+the matrix to exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one
+copy is reported next to it.  The K timed steps are captured once into a HIP
+graph (one kernel node per step) so the host's launch rate is not what is
+measured.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline      -- algorithmic bytes per launch / mean launch time (HIP events on

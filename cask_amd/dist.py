@@ -206,3 +206,49 @@ class ShardedSpmv:
             rsold = rsnew
             iterations = i                                       # :231
         return x, iterations, False
+
+    def bicg(self, transposed: "ShardedSpmv", b_local, x_local=None, maxiters=2000, tol=1e-5):
+        """Distributed classical BiCG (BASELINE config 5): products with A (this operator) and A^T
+        (``transposed``: the row-sharded transpose, see ``transpose_csr``), all-reduced dot products.
+        Same recurrence, stopping rule (r.r <= tol^2) and `iterations` convention as the single-GPU
+        ``cask_hip_bicg`` and the oracle; the reference only declares this solver
+        (DfeBiCgSolver, src/runtime/SparseLinearSolvers.hpp:56-61).  Returns (x_local, iterations, converged)."""
+        torch = self.torch
+        x = torch.zeros_like(b_local) if x_local is None else x_local.clone()
+        r = b_local - self.spmv(x)
+        rt, p, pt = r.clone(), r.clone(), r.clone()
+        rho = self.dot(rt, r)
+        iterations, tol2 = 0, tol * tol
+        for i in range(maxiters):
+            q = self.spmv(p)
+            qt = transposed.spmv(pt)
+            alpha = rho / self.dot(pt, q)
+            x.add_(alpha * p)
+            r.sub_(alpha * q)
+            rt.sub_(alpha * qt)
+            rr = self.dot(r, r)
+            if float(rr) <= tol2:
+                return x, iterations, True
+            rho_new = self.dot(rt, r)
+            beta = rho_new / rho
+            p = r + beta * p
+            pt = rt + beta * pt
+            rho = rho_new
+            iterations = i
+        return x, iterations, False
+
+
+def transpose_csr(n_rows, n_cols, row_ptr, col_ind, values):
+    """CSR of A^T by counting sort (rows of A^T come out with ascending columns); host arrays.
+    The engine does the same for a single GPU (ensure_transpose in cask_hip.hip); a sharded BiCG needs
+    the transpose BEFORE the rows are dealt to the ranks."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    col_ind = np.asarray(col_ind, dtype=np.int64)
+    values = np.asarray(values, dtype=np.float64)
+    counts = np.bincount(col_ind, minlength=n_cols)
+    trp = np.zeros(n_cols + 1, dtype=np.int64)
+    np.cumsum(counts, out=trp[1:])
+    order = np.argsort(col_ind, kind="stable")                 # stable: original row order within a column
+    rows_of = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(row_ptr))
+    return trp.astype(np.int32), rows_of[order].astype(np.int32), values[order]
+

@@ -41,6 +41,17 @@ def _worker(rank, world, port, case, out):
             b = torch.from_numpy(case["b"][bounds[rank]:bounds[rank + 1]].copy())
             xs, it, conv = sh.cg(b, maxiters=case.get("maxiters", 2000))
             res.update({"cg_x": xs.numpy().copy(), "cg_it": it, "cg_conv": conv})
+        if case.get("bicg"):
+            trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
+            tl = cdist.slice_rows(trp, tci, tva, bounds[rank], bounds[rank + 1])
+
+            def local_product_t(x_full, y_local):
+                y_local.copy_(torch.from_numpy(oracle.csr_spmv(tl[0], tl[1], tl[2], x_full.numpy())))
+
+            sht = cdist.ShardedSpmv(bounds, rank, world, local_product_t, torch.device("cpu"))
+            b = torch.from_numpy(case["b"][bounds[rank]:bounds[rank + 1]].copy())
+            xs, it, conv = sh.bicg(sht, b, tol=case.get("tol", 1e-5))
+            res.update({"bicg_x": xs.numpy().copy(), "bicg_it": it, "bicg_conv": conv})
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -105,3 +116,28 @@ def test_distributed_cg_matches_oracle():
     assert all(r["cg_conv"] == want_conv for r in res)
     assert all(abs(r["cg_it"] - want_it) <= 1 for r in res), ([r["cg_it"] for r in res], want_it)
     np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+
+
+def test_transpose_csr_matches_oracle():
+    n, rp, ci, va = synth.small("atmosmodd", factor=64)
+    trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
+    x = np.random.default_rng(1).standard_normal(n)
+    assert np.array_equal(oracle.csr_spmv(trp, tci, tva, x), oracle.csr_spmv_t(n, rp, ci, va, x))
+    assert all(np.all(np.diff(tci[trp[r]:trp[r + 1]]) > 0) for r in range(0, n, max(1, n // 50)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_bicg_matches_oracle(world):
+    """BASELINE config 5 in small: nonsymmetric atmosmodd-like system, A and A^T products row-sharded."""
+    n, rp, ci, va = synth.small("atmosmodd", factor=64)
+    x0 = np.random.default_rng(2).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b, tol=1e-9)
+    bounds = cdist.partition_rows_by_nnz(rp, world)
+    res = run_world(world, {"matrix": (n, rp, ci, va), "bounds": bounds, "x": x0, "b": b, "bicg": True, "tol": 1e-9})
+    got = np.concatenate([r["bicg_x"] for r in res])
+    assert want_conv and all(r["bicg_conv"] for r in res)
+    assert all(abs(r["bicg_it"] - want_it) <= 1 for r in res), ([r["bicg_it"] for r in res], want_it)
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(got, x0, rtol=1e-6, atol=1e-8)
+

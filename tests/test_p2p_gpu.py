@@ -69,6 +69,17 @@ def _worker(rank, world, port, case, out):
         torch.cuda.synchronize()
         res["y_graph"] = y.cpu().numpy()
         fence()
+        if case.get("bicg") is not None:
+            # BASELINE config 5 in small: BiCG with A and A^T row-sharded, both read their halos in-kernel
+            trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
+            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, balance=case.get("balance", "nnz"),
+                                                exchange="p2p", fence=fence, fused_halo=case.get("fused", False))
+            bl = torch.from_numpy(case["bicg"][b0:b1].copy()).cuda()
+            xs, it, conv = sh.bicg(sht, bl, tol=1e-9)
+            torch.cuda.synchronize()
+            res.update({"bicg_x": xs.cpu().numpy(), "bicg_it": it, "bicg_conv": conv})
+            fence()
+            sht.close()
         sh.close()
         out[rank] = res
     finally:
@@ -124,3 +135,20 @@ def test_two_ranks_block_diagonal_needs_no_halo():
     rp2 = np.cumsum(rp2).astype(np.int32)
     res, _ = check(2, (n, rp2, ci[keep], va[keep]), balance="even")
     assert all(r["n_halo"] == 0 and r["owners"] == [] for r in res)
+
+
+def test_two_ranks_bicg_with_in_kernel_halos():
+    """A and A^T products of a nonsymmetric stencil system sharded over two processes (balance by rows so
+    that both operators use the same slices), dots all-reduced: same answer as the oracle's BiCG."""
+    matrix = synth.small("atmosmodd", factor=32)
+    n, rp, ci, va = matrix
+    x0 = np.random.default_rng(3).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b, tol=1e-9)
+    xs = [np.arange(n, dtype=np.float64) * 0.25]
+    res = run_world(2, {"matrix": matrix, "xs": xs, "balance": "even", "fused": True, "bicg": b})
+    got = np.concatenate([r["bicg_x"] for r in res])
+    assert want_conv and all(r["bicg_conv"] for r in res)
+    assert all(abs(r["bicg_it"] - want_it) <= 1 for r in res)
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+
