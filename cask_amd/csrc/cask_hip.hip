@@ -80,7 +80,7 @@ struct Plan {
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
-  DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y (allocated on first use)
+  DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y
   // VECTOR
   DevBuf<int2v> xspan;
 };
@@ -476,6 +476,9 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       HIP_TRY(pl.blocks.upload(blocks));
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
+    // shares of a fused dot (a few KB): allocated with the plan, so that a product with the dot epilogue
+    // never allocates -- it may be running under stream capture
+    HIP_TRY(pl.dot_part.alloc((size_t)pl.grid + (size_t)pl.n_split_rows));
     pl.ldsx = pl.xu > 0;
     pl.lds_bytes = base_lds + 8 * pl.xu * prm.wg_size;
   } else {
@@ -586,7 +589,7 @@ int launch_merge_wave_i(const cask_hip_matrix &m, const double *x, double *y, hi
 
 // The merge kernel can leave the shares of w.y behind (one per block + one per split row).
 bool plan_fuses_dot(const Plan &pl) {
-  return pl.prm.variant == CASK_HIP_VARIANT_MERGE && pl.grid > 0 &&
+  return pl.prm.variant == CASK_HIP_VARIANT_MERGE && pl.grid > 0 && pl.dot_part.p != nullptr &&
          pl.lds_bytes + dot_lds_bytes(pl.prm.wg_size) <= MAX_LDS_BYTES;
 }
 int dot_part_count(const Plan &pl) { return pl.grid + pl.n_split_rows; }
@@ -596,7 +599,6 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
   Plan &pl = m.plan;
   if (w) {
     if (!plan_fuses_dot(pl)) return fail(CASK_HIP_ERR_INVALID, "this design point has no fused dot epilogue");
-    if (!pl.dot_part.p) HIP_TRY(pl.dot_part.alloc((size_t)dot_part_count(pl)));
   }
   const DotEpilogue dot{w, w ? pl.dot_part.p : nullptr};
   if (m.n_rows == 0 || (pl.grid == 0 && pl.n_long_blocks == 0)) return CASK_HIP_OK;

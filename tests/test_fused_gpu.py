@@ -135,3 +135,30 @@ def test_p2p_symbols_exported():
     lib = capi.load()
     for sym in p2p.P2P_SYMBOLS:
         assert hasattr(lib, sym), sym
+
+
+def test_dot_epilogue_inside_a_graph():
+    """The fused product+dot allocates nothing at launch time, so it can be captured."""
+    import torch
+    n, rp, ci, va = synth.small("G3_circuit")
+    rng = np.random.default_rng(4)
+    x, w = rng.uniform(-1, 1, n), rng.standard_normal(n)
+    want_y = oracle.csr_spmv(rp, ci, va, x)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge"))
+    xt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    yt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.spmv_dot_device(xt, yt, wt, out)          # also warms the one-off scratch of the plain dot path
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        m.spmv_dot_device(xt, yt, wt, out)
+    yt.zero_()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    oracle.assert_almost_equal(yt.cpu().numpy(), want_y)
+    assert abs(float(out[0]) - float(np.dot(w, want_y))) <= 1e-12 * float(np.abs(w * want_y).sum())
+    m.close()
