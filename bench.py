@@ -216,7 +216,8 @@ def main():
     copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // matrix_bytes) + 1)
 
     forced = capi.make_params(variant=args.variant or 0, lanes_per_row=args.lanes, tile_width=args.tile,
-                              items_per_thread=args.items, wg_size=args.wg)
+                              items_per_thread=args.items, wg_size=args.wg,
+                              index16=int(os.environ.get("CASK_BENCH_INDEX16", "0")))   # development A/B only
     mats = []
     rp_t = torch.from_numpy(rp).to(dev)
     for _ in range(copies):

@@ -75,7 +75,8 @@ struct Plan {
   int n_blocks = 0, n_long_blocks = 0;
   DevBuf<SplitRow> split_rows;
   DevBuf<double> partials;
-  DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz)
+  DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz), or
+  bool packed12 = false;           //   12-byte records of eight 12-bit slots per thread, [block][thread] (1.5 B/nnz)
   DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
@@ -147,6 +148,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.xcd_remap == 0) out.xcd_remap = 1;
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.index16 == 0) out.index16 = 1;
+  if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
@@ -285,6 +287,59 @@ void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks,
   }
 }
 
+// 12-bit packed slots for the IPT = 8 merge kernel: record (b*wg + t) holds the eight slots thread t of block b
+// needs, in the order the kernel consumes them -- pair u (u = 0..3) is elements 2p, 2p+1 of pair index
+// p = min(first + u*wg + t, last) exactly as merge_load computes it.  Elements that are not the block's own
+// (the lead element of an odd start, the half-foreign last pair, clamped duplicates) get the slot of a
+// neighbouring own element, which is what the kernel's fix-up does for the 16-bit layout at run time.
+// Stored as 6 unsigned shorts (3 dwords, little endian bit stream) per record.
+void pack_slots12(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks, const std::vector<unsigned short> &ci16,
+                  int wg, std::vector<unsigned short> &packed) {
+  packed.assign(blocks.size() * (size_t)wg * 6, 0);
+  const int max_gpair = (int)((m.nnz + 1) / 2) - 1;
+  auto work = [&](size_t b0, size_t b1) {
+    for (size_t b = b0; b < b1; b++) {
+      const BlockDesc &d = blocks[b];
+      if ((d.kind_g & KIND_LONG) || d.cwidth <= 0) continue;   // long pieces and untiled blocks read 32-bit indices
+      const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;
+      const int npairs = (total + 1) >> 1, first = base >> 1;
+      const int last = std::min(first + std::max(npairs - 1, 0), max_gpair);
+      const int own0 = d.nnz_start, own1 = d.nnz_start + d.nnz_count;      // own elements [own0, own1)
+      for (int t = 0; t < wg; t++) {
+        unsigned slots[8];
+        for (int u = 0; u < 4; u++) {
+          const int pr = std::min(first + u * wg + t, last);
+          int e0 = 2 * pr, e1 = 2 * pr + 1;
+          // replace foreign elements by the pair's own element (or the block's first nonzero)
+          const bool f0 = e0 < own0 || e0 >= own1, f1 = e1 < own0 || e1 >= own1;
+          if (f0 && !f1) e0 = e1;
+          if (f1 && !f0) e1 = e0;
+          if (f0 && f1) e0 = e1 = own0;
+          slots[2 * u] = ci16[e0];
+          slots[2 * u + 1] = ci16[e1];
+        }
+        unsigned w0 = slots[0] | (slots[1] << 12) | (slots[2] << 24);
+        unsigned w1 = (slots[2] >> 8) | (slots[3] << 4) | (slots[4] << 16) | (slots[5] << 28);
+        unsigned w2 = (slots[5] >> 4) | (slots[6] << 8) | (slots[7] << 20);
+        unsigned short *rec = packed.data() + (b * (size_t)wg + t) * 6;
+        rec[0] = (unsigned short)(w0 & 0xffff); rec[1] = (unsigned short)(w0 >> 16);
+        rec[2] = (unsigned short)(w1 & 0xffff); rec[3] = (unsigned short)(w1 >> 16);
+        rec[4] = (unsigned short)(w2 & 0xffff); rec[5] = (unsigned short)(w2 >> 16);
+      }
+    }
+  };
+  const size_t nb = blocks.size();
+  size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
+  if (n_threads <= 1) {
+    work(0, nb);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
+    for (auto &th : pool) th.join();
+  }
+}
+
 // Host twin of logical_block() (spmv_kernels.hpp).
 int logical_block_host(int hw, int n, bool remap) {
   if (!remap) return hw;
@@ -352,6 +407,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.blocks.release();
   pl.long_blocks.release();
   pl.ci16.release();
+  pl.packed12 = false;
   pl.xchunk.release();
   pl.maxch = 0;
   pl.any_skew = false;
@@ -440,7 +496,16 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         for (size_t b = 0; b < chunk_starts.size(); b++)
           std::copy(chunk_starts[b].begin(), chunk_starts[b].end(), xchunk.begin() + b * pl.maxch);
         HIP_TRY(pl.xchunk.upload(xchunk));
-        HIP_TRY(pl.ci16.upload(ci16));
+        // index16 = 1 packs the slots 12 bits each where the kernel has that layout (8 items per thread, tile of
+        // at most 4096 slots): 1.5 instead of 2 bytes per nonzero; index16 = 2 keeps 16-bit slots
+        pl.packed12 = prm.index16 == 1 && prm.items_per_thread == 8 && pl.prm.tile_width <= 4096;
+        if (pl.packed12) {
+          std::vector<unsigned short> packed;
+          pack_slots12(m, blocks, ci16, prm.wg_size, packed);
+          HIP_TRY(pl.ci16.upload(packed));
+        } else {
+          HIP_TRY(pl.ci16.upload(ci16));
+        }
       }
       HIP_TRY(pl.blocks.upload(blocks));               // cwidth now holds the slots each block uses
     } else if (tile > 0 && m.nnz > 0) {
@@ -546,6 +611,7 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.rp = m.d_rp;
   l.ci = m.d_ci;
   l.ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
+  l.packed12 = pl.packed12;
   l.xchunk = pl.xchunk.p;
   l.val = m.d_val;
   l.partials = pl.partials.p;

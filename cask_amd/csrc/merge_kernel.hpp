@@ -117,6 +117,7 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
 // lands the gathers are LDS reads (~100 ns, no TA traffic) instead of a second
 // dependent trip to L2.  XU = 0 gathers from L2 (window wider than the tile).
 //
+// C12 (with C16, IPT = 8): the same slots, 12 bits each, packed per thread by the planner (see the load).
 // C16 (only with an x window): the block's column indices are read from the
 // 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
 // per nonzero and already LDS offsets -- the stream shrinks from 12 to 10
@@ -129,13 +130,13 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
 typedef __attribute__((address_space(1))) const double gdouble;
 __device__ __forceinline__ double load_at(uint64_t addr) { return *reinterpret_cast<gdouble *>(addr); }
 
-template <int IPT, int XU, bool NT, bool C16, bool SEAM, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool SEAM, bool EXT>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
                                            double *prod, int *roff, double *xs, const XHalo &halo,
-                                           const double *__restrict__ w, double *wl) {
+                                           const double *__restrict__ w, double *wl, int lb) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
@@ -183,14 +184,25 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   dbl2 v[IPT / 2];
   int2v c[IPT / 2];
   unsigned c16[IPT / 2];                                      // C16: two 16-bit slots per word, unpacked after the park
+  unsigned c12[3] = {0u, 0u, 0u};                             // C12: this thread's eight 12-bit slots, one 12-byte record
   const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
   const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
   const int first = base >> 1;
   const int last = min(first + max(npairs - 1, 0), max_gpair);
+  // C12 (IPT = 8): the planner packed the eight slots THIS thread needs -- foreign elements already replaced
+  // by a slot the block owns -- into record lb*WG + tid: one 12-byte load instead of four 4-byte ones, 1.5
+  // instead of 2 bytes per nonzero
+  if (C12) {
+    const unsigned *rec = ci16 + ((size_t)lb * WG + tid) * 3;  // (a 3-vector type would be padded to 16 bytes)
+    c12[0] = stream_load<NT>(rec);
+    c12[1] = stream_load<NT>(rec + 1);
+    c12[2] = stream_load<NT>(rec + 2);
+  }
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
     const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
     v[u] = stream_load<NT>(val2 + p);
+    if (C12) continue;
     if (C16) c16[u] = stream_load<NT>(ci16 + p);
     else     c[u] = stream_load<NT>(ci2 + p);
   }
@@ -215,7 +227,20 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   roff[tid + WG] = ro1;
   if (XU > 0) __syncthreads();
   CASK_STAMP(2);
-  if (C16) {                                                  // unpack the 16-bit slots only now: the stream is still landing
+  if (C12) {                                                  // unpack only now: the stream is still landing
+    static_assert(!C12 || IPT == 8, "12-bit packed slots are laid out for 8 items per thread");
+    const unsigned q0 = c12[0], q1 = c12[1], q2 = c12[2];
+    c[0].x = (int)(q0 & 0xfffu);
+    c[0].y = (int)((q0 >> 12) & 0xfffu);
+    c[1].x = (int)((q0 >> 24) | ((q1 & 0xfu) << 8));
+    c[1].y = (int)((q1 >> 4) & 0xfffu);
+    if (IPT / 2 > 2) {
+      c[IPT / 2 > 2 ? 2 : 0].x = (int)((q1 >> 16) & 0xfffu);
+      c[IPT / 2 > 2 ? 2 : 0].y = (int)((q1 >> 28) | ((q2 & 0xffu) << 4));
+      c[IPT / 2 > 3 ? 3 : 0].x = (int)((q2 >> 8) & 0xfffu);
+      c[IPT / 2 > 3 ? 3 : 0].y = (int)(q2 >> 20);
+    }
+  } else if (C16) {                                           // unpack the 16-bit slots only now
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
       c[u].x = (int)(c16[u] & 0xffffu);
@@ -224,12 +249,15 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   }
 
   // foreign elements: give them a column this block owns, so their gather stays
-  // inside the x window / inside x (their products land in slots no row uses)
-  if (lead && tid == 0) c[0].x = c[0].y;
-  if (total & 1) {
+  // inside the x window / inside x (their products land in slots no row uses); the packed records
+  // come with that done
+  if (!C12) {
+    if (lead && tid == 0) c[0].x = c[0].y;
+    if (total & 1) {
 #pragma unroll
-    for (int u = 0; u < IPT / 2; u++)
-      if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+      for (int u = 0; u < IPT / 2; u++)
+        if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+    }
   }
   dbl2 xv[IPT / 2];
   if (XU > 0) {
@@ -274,7 +302,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool SKEW, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool SKEW, bool EXT>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
@@ -290,11 +318,11 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                            halo, dot.w, wl);
+    merge_load<IPT, XU, NT, C16, C12, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                            halo, dot.w, wl, lb);
   else
-    merge_load<IPT, XU, NT, C16, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                             halo, dot.w, wl);
+    merge_load<IPT, XU, NT, C16, C12, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                             halo, dot.w, wl, lb);
   const double *wrow = EXT && dot.w ? wl : nullptr;           // w[row_start + r] sits in wl[r]
 
   double dsum;
@@ -324,7 +352,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 // EXT: the launch may carry halo sources and/or a dot epilogue.  Ordinary products run the EXT = false
 // instantiation, which contains none of that code: a kernel this close to the memory system's limits
 // pays for every extra branch, register and byte of LDS (measured while adding them: +1 to +6 %).
-template <int IPT, int XU, bool NT, bool C16, bool SKEW, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool SKEW, bool EXT>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
@@ -391,10 +419,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, XU, NT, C16, C12, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                              xs, halo, dot, lb);
   else
-    merge_block<IPT, 0, NT, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, 0, NT, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                               xs, halo, dot, lb);
   CASK_STAMP(5);
 }

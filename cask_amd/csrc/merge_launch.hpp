@@ -15,7 +15,8 @@ struct MergeLaunch {
   bool nontemporal, any_skew;
   const BlockDesc *blocks;
   const int *rp, *ci;
-  const unsigned *ci16;            // NULL: 32-bit indices
+  const unsigned *ci16;            // NULL: 32-bit indices; else 16-bit slots per nonzero, or (packed12) 12-byte records
+  bool packed12;                   //   of eight 12-bit slots per thread, [block][thread]
   const int *xchunk;
   const double *val;
   double *partials;                // long-row pieces

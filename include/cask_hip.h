@@ -53,7 +53,9 @@ typedef struct cask_hip_params {
   int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
   int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off                 */
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
-  int32_t index16;          /* MERGE with an x tile: 1 = stream 16-bit (col - tile start) indices, -1 = off */
+  int32_t index16;          /* MERGE with an x tile: 1 = stream tile-relative slot indices instead of 32-bit columns
+                             * (12 bits each, packed per thread, where the kernel has that layout; else 16 bits),
+                             * 2 = 16-bit slots only, -1 = off */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {

@@ -24,6 +24,7 @@ MERGE_POINTS = [
     dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=2048, index16=-1),
     dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=256, xcd_remap=-1),
     dict(variant="merge", items_per_thread=16, wg_size=256, tile_width=4096),
+    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096, index16=2),
 ]
 IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) for dp in MERGE_POINTS]
 

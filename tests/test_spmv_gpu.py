@@ -27,6 +27,8 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=16, wg_size=256, tile_width=-1, nontemporal=-1),
     dict(variant="merge", items_per_thread=8, wg_size=512, tile_width=1024),
     dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, index16=-1),
+    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096, index16=2),       # 16-bit slots, not packed
+    dict(variant="merge", items_per_thread=8, wg_size=128, tile_width=1024, index16=1, nontemporal=-1),   # 12-bit packed
     dict(variant="merge_wave", items_per_thread=2, wg_size=64),
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
