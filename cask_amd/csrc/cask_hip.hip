@@ -1414,6 +1414,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   int launched = 0;
   double clean_us = 0.0;
   const bool fused = plan_fuses_dot(m->plan);
+  SolverLoadPolicy load_policy(m, nullptr, 6);
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
     const double *pAp_part = partials.p;
@@ -1430,17 +1431,26 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
     // x += alpha p ; r -= alpha Ap  (:210-212; the r.r shares this kernel also leaves are not used here)
     hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rz.p,
                        (const int *)done);
-    rc = cask_hip_precond_apply_device(precond, r.p, z.p, s);                           // :215
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, z.p, partials_rz.p, (const int *)done);   // :218
+    // z = M^-1 r (:215) and the shares of r.z (:218): one pass when the preconditioner can (Jacobi)
+    int n_rz = g;
+    const int fused_pc = cask_hip_precond_apply_dot(precond, r.p, z.p, partials_rz.p, BLAS_MAX_PARTIALS, &n_rz, done, s);
+    if (fused_pc < 0) return fail(CASK_HIP_ERR_RUNTIME, "preconditioner launch failed");
+    if (fused_pc == 0) {
+      rc = cask_hip_precond_apply_device(precond, r.p, z.p, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, z.p, partials_rz.p, (const int *)done);
+      n_rz = g;
+    }
     // rsnew = r.z ; converged? ; p = z + (rsnew/rsold) p   (:220-231)
-    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, tol * tol, i, z.p, p.p, done,
+    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rz.p, n_rz, rsold, rsnew, tol * tol, i, z.p, p.p, done,
                        iters);
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
+      load_policy.record(launched, s);
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
+      load_policy.decide(launched);
       if (h_flags[0]) break;
       float ms_so_far = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
