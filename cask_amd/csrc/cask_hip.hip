@@ -78,6 +78,7 @@ struct Plan {
   DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz), or
   bool packed12 = false;           //   12-byte records of eight 12-bit slots per thread, [block][thread] (1.5 B/nnz)
   DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
+  bool one_window = false;         // every tiled block's chunks are consecutive (KIND_CONTIG): paired window loads
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
@@ -253,14 +254,14 @@ void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks,
       while (i < uniq.size() && fits) {
         size_t j = i;
         while (j + 1 < uniq.size() && uniq[j + 1] - uniq[j] <= GAP) j++;
-        for (int c = uniq[i]; c <= uniq[j]; c += 64) {
+        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) {     // even starts: the kernel loads the tile in 16-byte pairs
           if ((int)starts.size() == max_chunks) { fits = false; break; }
           starts.push_back(c);
         }
         i = j + 1;
       }
       if (!fits) continue;
-      d.cmin = uniq.front();
+      d.cmin = starts.front();
       d.cwidth = (int)starts.size() * 64;
       bool contiguous = true;
       for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
@@ -408,6 +409,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.long_blocks.release();
   pl.ci16.release();
   pl.packed12 = false;
+  pl.one_window = false;
   pl.xchunk.release();
   pl.maxch = 0;
   pl.any_skew = false;
@@ -496,6 +498,9 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         for (size_t b = 0; b < chunk_starts.size(); b++)
           std::copy(chunk_starts[b].begin(), chunk_starts[b].end(), xchunk.begin() + b * pl.maxch);
         HIP_TRY(pl.xchunk.upload(xchunk));
+        pl.one_window = true;
+        for (const BlockDesc &d : blocks)
+          if (!(d.kind_g & KIND_LONG) && d.cwidth > 0 && !(d.kind_g & KIND_CONTIG)) pl.one_window = false;
         // index16 = 1 packs the slots 12 bits each where the kernel has that layout (8 items per thread, tile of
         // at most 4096 slots): 1.5 instead of 2 bytes per nonzero; index16 = 2 keeps 16-bit slots
         pl.packed12 = prm.index16 == 1 && prm.items_per_thread == 8 && pl.prm.tile_width <= 4096;
@@ -612,6 +617,7 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.ci = m.d_ci;
   l.ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
   l.packed12 = pl.packed12;
+  l.one_window = pl.one_window;
   l.xchunk = pl.xchunk.p;
   l.val = m.d_val;
   l.partials = pl.partials.p;
@@ -940,6 +946,8 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out) {
 int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   if ((m->n_cols > 0 && !d_x) || (m->n_rows > 0 && !d_y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  if (reinterpret_cast<uintptr_t>(d_x) & 15)                  // the x tile is staged in 16-byte pairs
+    return fail(CASK_HIP_ERR_INVALID, "x must be 16-byte aligned");
   return launch_spmv(*m, d_x, d_y, static_cast<hipStream_t>(stream));
 }
 
@@ -948,6 +956,7 @@ int cask_hip_spmv_dot_device(cask_hip_matrix *m, const double *d_x, double *d_y,
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   if ((m->n_cols > 0 && !d_x) || (m->n_rows > 0 && (!d_y || !d_w)) || !d_result)
     return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  if (reinterpret_cast<uintptr_t>(d_x) & 15) return fail(CASK_HIP_ERR_INVALID, "x must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (plan_fuses_dot(m->plan)) {
     int rc = launch_spmv(*m, d_x, d_y, s, d_w);

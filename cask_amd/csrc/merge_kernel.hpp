@@ -117,6 +117,7 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
 // lands the gathers are LDS reads (~100 ns, no TA traffic) instead of a second
 // dependent trip to L2.  XU = 0 gathers from L2 (window wider than the tile).
 //
+// WIDE (with C12, XU >= 2): all tiled blocks of the plan have one contiguous window; it is loaded in pairs.
 // C12 (with C16, IPT = 8): the same slots, 12 bits each, packed per thread by the planner (see the load).
 // C16 (only with an x window): the block's column indices are read from the
 // 16-bit side array (col_ind - cmin, built at plan time), 2 instead of 4 bytes
@@ -130,7 +131,7 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
 typedef __attribute__((address_space(1))) const double gdouble;
 __device__ __forceinline__ double load_at(uint64_t addr) { return *reinterpret_cast<gdouble *>(addr); }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool SEAM, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, bool EXT>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
@@ -169,6 +170,22 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
       }
 #pragma unroll
       for (int u = 0; u < XU; u++) xsrc[u] = halo_source(x, col[u], xsrc[u], halo);
+    } else if (WIDE) {
+      // WIDE plans: every tiled block has ONE window (the planner starts it on an even column) and loads it in
+      // 16-byte pairs, half the load instructions: 8.31 -> 8.19 us on the cant payload.  (Chunked tiles measured
+      // 1-3 % SLOWER with paired loads -- per-lane or scalar chunk lookups alike -- and a per-block choice inside
+      // one kernel loses the gain to the merged wait states, so this is a plan-level instantiation.)  Pair
+      // j = u*WG + tid covers slots 2j, 2j+1.  The last pair may reach one element past the entries the block may
+      // use (past the end of x when n_cols is odd): x is 16-byte aligned, so the aligned 16-byte load cannot
+      // cross a page, and its slot is one no nonzero refers to.
+      const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x);
+      const int plim = xlim >> 1;
+#pragma unroll
+      for (int u = 0; u < XU / 2; u++) {
+        const dbl2 pr = x2[min((d.cmin >> 1) + u * WG + tid, plim)];
+        xw[2 * u] = pr.x;
+        xw[2 * u + 1] = pr.y;
+      }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
 #pragma unroll
@@ -219,7 +236,16 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   }
 
   CASK_STAMP(1);
-  if (XU > 0) {
+  if (WIDE && !SEAM) {                                        // pairs: slots 2j, 2j+1 for j = u*WG + tid
+    dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
+#pragma unroll
+    for (int u = 0; u < XU / 2; u++) {
+      dbl2 pr;
+      pr.x = xw[2 * u];
+      pr.y = xw[2 * u + 1];
+      xs2[u * WG + tid] = pr;
+    }
+  } else if (XU > 0) {
 #pragma unroll
     for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
   }
@@ -302,7 +328,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool SKEW, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, bool EXT>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
@@ -318,10 +344,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, C12, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                             halo, dot.w, wl, lb);
   else
-    merge_load<IPT, XU, NT, C16, C12, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                              halo, dot.w, wl, lb);
   const double *wrow = EXT && dot.w ? wl : nullptr;           // w[row_start + r] sits in wl[r]
 
@@ -352,7 +378,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 // EXT: the launch may carry halo sources and/or a dot epilogue.  Ordinary products run the EXT = false
 // instantiation, which contains none of that code: a kernel this close to the memory system's limits
 // pays for every extra branch, register and byte of LDS (measured while adding them: +1 to +6 %).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool SKEW, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, bool EXT>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
@@ -419,10 +445,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, C12, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                              xs, halo, dot, lb);
   else
-    merge_block<IPT, 0, NT, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                               xs, halo, dot, lb);
   CASK_STAMP(5);
 }

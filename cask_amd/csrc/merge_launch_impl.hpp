@@ -9,33 +9,38 @@ namespace caskhip {
 template <int IPT, int XU>
 static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
   const dim3 grid(l.grid), block(l.wg_size);
-#define CASK_LAUNCH_K(NT, C16, C12, SKEW, EXT)                                                                    \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, SKEW, EXT>), grid, block, l.lds_bytes, s, l.blocks,    \
+#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT)                                                              \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>), grid, block, l.lds_bytes, s, l.blocks, \
                      l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, y,        \
                      l.partials, l.halo, l.dot)
   // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
-#define CASK_LAUNCH_M(NT, C16, C12, SKEW)                              \
+#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                        \
   do {                                                                 \
-    if (ext) CASK_LAUNCH_K(NT, C16, C12, SKEW, true);                  \
-    else     CASK_LAUNCH_K(NT, C16, C12, SKEW, false);                 \
+    if (ext) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, true);            \
+    else     CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, false);           \
   } while (0)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = l.nontemporal || l.any_skew;
   constexpr bool TILED = XU > 0;
   constexpr bool CAN12 = TILED && IPT == 8;                   // 12-bit packed slots exist for 8 items per thread
-  if (TILED && l.ci16 && l.packed12 && CAN12) {
-    if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, true);
-    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, false);
-    else            CASK_LAUNCH_M(false, TILED, CAN12, false);
+  constexpr bool CANWIDE = CAN12 && XU >= 2;                  // paired window loads: packed plans whose tiles are one window
+  if (TILED && l.ci16 && l.packed12 && CAN12 && l.one_window && CANWIDE) {
+    if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, true);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, false);
+    else            CASK_LAUNCH_M(false, TILED, CAN12, CANWIDE, false);
+  } else if (TILED && l.ci16 && l.packed12 && CAN12) {
+    if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, false, true);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, false, false);
+    else            CASK_LAUNCH_M(false, TILED, CAN12, false, false);
   } else if (TILED && l.ci16) {
-    if (l.any_skew) CASK_LAUNCH_M(true, TILED, false, true);
-    else if (nt)    CASK_LAUNCH_M(true, TILED, false, false);
-    else            CASK_LAUNCH_M(false, TILED, false, false);
+    if (l.any_skew) CASK_LAUNCH_M(true, TILED, false, false, true);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, false, false, false);
+    else            CASK_LAUNCH_M(false, TILED, false, false, false);
   } else {
-    if (l.any_skew) CASK_LAUNCH_M(true, false, false, true);
-    else if (nt)    CASK_LAUNCH_M(true, false, false, false);
-    else            CASK_LAUNCH_M(false, false, false, false);
+    if (l.any_skew) CASK_LAUNCH_M(true, false, false, false, true);
+    else if (nt)    CASK_LAUNCH_M(true, false, false, false, false);
+    else            CASK_LAUNCH_M(false, false, false, false, false);
   }
 #undef CASK_LAUNCH_K
 #undef CASK_LAUNCH_M

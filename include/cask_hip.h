@@ -134,7 +134,7 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out);
 int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y);
 
 /* y = A x with device vectors on `stream` (a hipStream_t; NULL = default
- * stream), asynchronously.  This is the device run function alone, the
+ * stream), asynchronously.  d_x must be 16-byte aligned (any hipMalloc'd vector is).  This is the device run function alone, the
  * counterpart of the timed region in Spmv.cpp:270-285. */
 int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream);
 
