@@ -6,7 +6,8 @@
 # 3. HBM traffic per workload: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, for the SpMV
 #    kernel and for a calibration kernel that streams a known byte count with the
 #    same 16-byte access shape (tools/membench.hip k_oneshot), because gfx950's
-#    FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM).
+#    FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM); and a third pass
+#    with the read requests by size, which counts the bytes exactly.
 set -u
 tag=${1:-r01}
 shift || true
@@ -20,10 +21,14 @@ python3 bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
 cat $out/bench_$tag.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline > $out/prof_$tag.json 2> $out/prof_$tag.err
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
+# three separate counter passes: FETCH_SIZE, WRITE_SIZE, and the L2->memory read requests split by size
+# (32/64/128 bytes: an exact byte count that needs no correction; the cross-check of the corrected FETCH_SIZE)
+for c in FETCH_SIZE WRITE_SIZE RDREQ; do
+  ctr=$c
+  if [ $c = RDREQ ]; then ctr="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; fi
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
   for w in $workloads; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline > /dev/null 2> $out/pmc_${tag}_${w}_$c.err
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline --no-tune > /dev/null 2> $out/pmc_${tag}_${w}_$c.err
   done
 done
 for w in $workloads; do python3 $root/tools/traffic_summary.py $tag $w; done

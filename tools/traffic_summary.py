@@ -35,8 +35,14 @@ CAL_NNZ = 4010891
 fetch_cal, n1 = counter(f"pmc_{tag}_calib_FETCH_SIZE", "k_oneshot<8, true>", "FETCH_SIZE")
 known = 12.0 * CAL_NNZ
 factor = known / (fetch_cal * 1024.0) if fetch_cal else None
+cal_sizes = {n: counter(f"pmc_{tag}_calib_RDREQ", "k_oneshot<8, true>", n)[0]
+             for n in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")}
 res = {"tag": tag, "calibration": {"kernel": "k_oneshot<8,true> (tools/membench.hip)", "known_bytes": known,
-                                   "FETCH_SIZE_KiB": fetch_cal, "factor": factor, "samples": n1}}
+                                   "FETCH_SIZE_KiB": fetch_cal, "factor": factor, "samples": n1,
+                                   "read_bytes_by_request_size": (round(32 * cal_sizes["TCC_EA0_RDREQ_32B_sum"] +
+                                                                        64 * cal_sizes["TCC_EA0_RDREQ_64B_sum"] +
+                                                                        128 * cal_sizes["TCC_EA0_RDREQ_128B_sum"])
+                                                                  if all(v is not None for v in cal_sizes.values()) else None)}}
 for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
     f, nf = counter(f"pmc_{tag}_{workload}_FETCH_SIZE", kern, "FETCH_SIZE")
     w, nw = counter(f"pmc_{tag}_{workload}_WRITE_SIZE", kern, "WRITE_SIZE")
@@ -48,6 +54,18 @@ for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
     res["samples"] = [nf, nw]
     if factor:
         res["hbm_bytes_per_launch"] = round(f * 1024.0 * factor + (w or 0) * 1024.0)
+    # cross-check: L2 -> memory read requests by size (exact, no correction)
+    sizes = {}
+    for name, nbytes in (("TCC_EA0_RDREQ_32B_sum", 32), ("TCC_EA0_RDREQ_64B_sum", 64), ("TCC_EA0_RDREQ_128B_sum", 128)):
+        v, _ = counter(f"pmc_{tag}_{workload}_RDREQ", kern, name)
+        if v is not None:
+            sizes[name] = v
+    if sizes:
+        rd = sum(v * {"TCC_EA0_RDREQ_32B_sum": 32, "TCC_EA0_RDREQ_64B_sum": 64, "TCC_EA0_RDREQ_128B_sum": 128}[k]
+                 for k, v in sizes.items())
+        res["read_requests_by_size"] = sizes
+        res["read_bytes_by_request_size"] = round(rd)
+        res["hbm_bytes_per_launch_by_request_size"] = round(rd + (w or 0) * 1024.0)
     break
 print(json.dumps(res, indent=1))
 res["workload"] = workload
