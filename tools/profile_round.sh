@@ -15,6 +15,7 @@ workloads=${*:-cant}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
+rm -rf $out/prof_$tag $out/pmc_${tag}_*          # a merged gpurun_out/ may still hold an earlier run's files
 cd $root
 make build/membench > /dev/null 2>&1
 python3 bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
