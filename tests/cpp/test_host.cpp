@@ -6,6 +6,7 @@
 #include <iostream>
 #include <string>
 
+#include "cask/Converters.hpp"
 #include "cask/IO.hpp"
 #include "cask/SparseMatrix.hpp"
 #include "cask/Utils.hpp"
@@ -111,6 +112,16 @@ static void test_io(const std::string &dir) {
   auto coo = r.mmreadMatrix("");
   CHECK(coo.n == 4 && coo.m == 4 && coo.data.size() == 6);
   CHECK(std::get<0>(coo.data[1]) == 0 && std::get<1>(coo.data[1]) == 3 && std::get<2>(coo.data[1]) == 1);
+  // test_spmv.cpp's golden operand without Eigen: the COO goes to CSR and dot() is the row-major product
+  CsrMatrix fromCoo = converters::tripletToCsr(coo);
+  CHECK(fromCoo == io::readMatrix(dir + "/systems/tinysym.mtx"));
+  CHECK(fromCoo.dot(Vector{1, 2, 3, 4}) == (Vector{5, 2, 3, 9}));
+  cask::sparse::SparkCooMatrix<double> dup(2, 2);
+  dup.data.push_back(std::make_tuple(1, 0, 3.0));
+  dup.data.push_back(std::make_tuple(0, 1, 1.0));
+  dup.data.push_back(std::make_tuple(1, 0, 5.0));                     // later duplicate wins (DokMatrix::set)
+  CsrMatrix d2 = converters::tripletToCsr(dup);
+  CHECK(d2.nnzs == 2 && d2.values == (std::vector<double>{1.0, 5.0}) && d2.row_ptr == (std::vector<int>{0, 1, 2}));
   // errors
   CHECK_THROWS(io::readHeader(dir + "/nope.mtx"), std::invalid_argument);
   CHECK_THROWS(io::readSymMatrix(dir + "/matrices/test_dense_4.mtx"), std::invalid_argument);
