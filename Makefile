@@ -41,7 +41,11 @@ build/test_precond_hip: tests/clients/test_precond_client.cpp $(LIBDIR)/libCaskH
 	mkdir -p build
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lCaskHip -lcask_hip $(RPATHS)
 
-clients: build/test_spmv_hip build/test_precond_hip
+build/test_bicg_hip: tests/clients/test_bicg_client.cpp $(LIBDIR)/libCaskHip.so
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lCaskHip -lcask_hip $(RPATHS)
+
+clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel
