@@ -45,7 +45,11 @@ build/test_bicg_hip: tests/clients/test_bicg_client.cpp $(LIBDIR)/libCaskHip.so
 	mkdir -p build
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lCaskHip -lcask_hip $(RPATHS)
 
-clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip
+build/test_context_hip: tests/clients/test_context_client.cpp $(LIBDIR)/libCaskHip.so $(GENDIR)/libSpmv_hip.so
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -L$(GENDIR) -lCaskHip -lSpmv_hip -lcask_hip $(RPATHS)
+
+clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip build/test_context_hip
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel

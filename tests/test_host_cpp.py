@@ -91,6 +91,15 @@ def test_preconditioning_client_known_answers(plain_mtx_dir):
 
 
 @pytest.mark.gpu
+def test_cask_context_clients(plain_mtx_dir):
+    """test/ClientTestSpmv.cpp and test/ClientTestCg.cpp: the CaskContext facade end to end."""
+    make("clients")
+    out = subprocess.run([str(REPO / "build" / "test_context_hip"), str(plain_mtx_dir / "systems")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-800:], out.stderr[-600:])
+
+
+@pytest.mark.gpu
 def test_bicg_client_reference_protocol(plain_mtx_dir):
     """test/test_bicg.cpp: identity, 2I (100, 10000) and bfwb62 through DfeBiCgSolver on the GPU."""
     make("clients")
