@@ -4,6 +4,7 @@
 // src/runtime/Spmv.cpp (host blocking + SLiC calls), Cg.cpp (empty) and Dse.cpp.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <ctime>
 #include <fstream>
 #include <iostream>
@@ -30,9 +31,30 @@ void check(int rc, const char *what) {
   throw std::runtime_error(msg);
 }
 
-std::shared_ptr<cask_hip_matrix> upload(const cask::CsrMatrix &a, const cask_hip_params *p) {
+// Run-time overrides for unchanged clients (the reference selects a design with test_spmv's optional implId
+// argument and a target with -t {dfe,sim,dfe_mock}; a GPU build has one target and many design points):
+//   CASK_HIP_VARIANT = auto | vector | merge | merge_wave   overrides the variant of every matrix uploaded
+//   CASK_HIP_TILE    = <doubles> | -1                        overrides the x tile width (-1: no tile)
+cask_hip_params with_env_overrides(const cask_hip_params *p) {
+  cask_hip_params out{};
+  if (p) out = *p;
+  if (const char *v = std::getenv("CASK_HIP_VARIANT")) {
+    const std::string s(v);
+    if (s == "auto") out.variant = CASK_HIP_VARIANT_AUTO;
+    else if (s == "vector") out.variant = CASK_HIP_VARIANT_VECTOR;
+    else if (s == "merge") out.variant = CASK_HIP_VARIANT_MERGE;
+    else if (s == "merge_wave") out.variant = CASK_HIP_VARIANT_MERGE_WAVE;
+    else throw std::invalid_argument("CASK_HIP_VARIANT must be auto, vector, merge or merge_wave");
+  }
+  if (const char *t = std::getenv("CASK_HIP_TILE")) out.tile_width = std::atoi(t);
+  return out;
+}
+
+std::shared_ptr<cask_hip_matrix> upload(const cask::CsrMatrix &a, const cask_hip_params *p_in) {
   if (static_cast<int>(a.row_ptr.size()) != a.n + 1)
     throw std::invalid_argument("CsrMatrix: row_ptr must have n+1 entries");
+  const cask_hip_params prm = with_env_overrides(p_in);
+  const cask_hip_params *p = &prm;
   cask_hip_matrix *h = nullptr;
   check(cask_hip_csr_create(a.n, a.m, static_cast<int64_t>(a.col_ind.size()), a.row_ptr.data(), a.col_ind.data(),
                             a.values.data(), p, &h),

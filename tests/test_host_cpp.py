@@ -3,6 +3,7 @@ CPU part: unit tests against the reference's gtest known answers, link seams.
 GPU part: the integration client over every reference fixture and the DSE executable."""
 import json
 import re
+import os
 import subprocess
 
 import pytest
@@ -88,6 +89,20 @@ def test_preconditioning_client_known_answers(plain_mtx_dir):
     out = subprocess.run([str(REPO / "build" / "test_precond_hip"), str(plain_mtx_dir / "systems")],
                          capture_output=True, text=True)
     assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-600:], out.stderr[-600:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["vector", "merge_wave"])
+def test_env_override_selects_the_variant(plain_mtx_dir, variant):
+    """CASK_HIP_VARIANT reaches the engine through the unchanged client (the reference picks designs by implId)."""
+    make("clients")
+    exe = REPO / "build" / "test_spmv_hip"
+    env = dict(os.environ, CASK_HIP_VARIANT=variant)
+    out = subprocess.run([str(exe), str(plain_mtx_dir / "matrices" / "test_cage6.mtx")], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-600:], out.stderr[-300:])
+    bad = subprocess.run([str(exe), str(plain_mtx_dir / "matrices" / "test_cage6.mtx")], capture_output=True, text=True,
+                         env=dict(os.environ, CASK_HIP_VARIANT="fpga"))
+    assert bad.returncode != 0
 
 
 @pytest.mark.gpu
