@@ -337,9 +337,9 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
                                             const XHalo &halo, const DotEpilogue &dot, int lb) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
-  // the per-wave sums.  No static LDS: on gfx950 LDS is allocated in 1280-byte granules and the
-  // bench's 26 640-byte blocks sit 240 bytes under a granule edge -- 256 bytes of static LDS cost a
-  // sixth of the occupancy (measured: 8.75 -> 8.88 us per launch).
+  // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
+  // slower (8.75 -> 8.88 us per launch in an interleaved A/B) although the occupancy calculator still
+  // reports 6 workgroups per CU for 26 896 bytes (tools/lds_granule.hip); the cause was not established.
   double *wl = xs + XU * WG, *dot_red = wl + 2 * WG;
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
