@@ -19,7 +19,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pass$i -- python3 $root/bench.py $args > $out/pass$i.json 2> $out/pass$i.err || echo "pass $i failed: $(tail -2 $out/pass$i.err)"
 done
-python3 - "$out" <<'PY'
+python3 - "$out" <<'PY' | tee $out/summary.txt
 import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -34,3 +34,4 @@ for k, d in agg.items():
         v = v[len(v)//3:]          # skip the warm-up launches
         print(f"  {c:34s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
 PY
+find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -delete
