@@ -45,8 +45,8 @@ INFINITY_CACHE_BYTES = 256 << 20
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cant", choices=["cant", "G3_circuit", "webbase-1M", "atmosmodd"])
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
     ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
