@@ -11,8 +11,9 @@ MatrixMarket restatement in ``oracle.mmio``.  Each function names the reference
 lines it follows (paths relative to /root/reference).
 
 Parity status: pinned against the known answers in the reference's own gtest
-suites (test/SparseMatrix.cpp, test/Io.cpp, test/LinearSolvers.cpp,
-test/TestUtils.cpp -> tests/golden/known_answers.json) and cross-checked
+suites (test/SparseMatrix.cpp, test/Io.cpp, test/LinearSolvers.cpp incl. the ILU
+factor / apply / pcg+ILU answers, test/MklLayer.cpp, test/TestUtils.cpp ->
+tests/golden/known_answers.json) and cross-checked
 against MKL, the CPU library the reference calls.  The reference host code
 cannot be built in this image (no Eigen/Boost/dfe-snippets), so there is no
 ``oracle/_ref``.  BiCG is "parity unpinned": the reference never defines it.

@@ -1,5 +1,5 @@
 /*
- * cask_oracle.c -- CPU restatement of the reference's SpMV / CG arithmetic.
+ * cask_oracle.c -- CPU restatement of the reference's SpMV / CG / ILU / triangular-solve arithmetic.
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under cask_amd/ or include/ may link,
  * import or call this file; it is the checker for tests/, for
