@@ -1390,6 +1390,8 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   int rc = solver_common_checks(m, rhs, x, maxiters, tol);
   if (rc) return rc;
   if (!precond) return cask_hip_cg(m, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+  if (cask_hip_precond_rows(precond) != m->n_rows)
+    return fail(CASK_HIP_ERR_INVALID, "the preconditioner was built for a matrix of a different order");
   HIP_TRY(hipSetDevice(m->device));
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;

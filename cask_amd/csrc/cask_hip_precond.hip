@@ -370,6 +370,8 @@ int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32
 
 }  // extern "C"
 
+int cask_hip_precond_rows(const cask_hip_precond *p) { return p ? p->n : -1; }
+
 int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d_z, double *d_partials,
                                int max_partials, int *n_partials, const int *d_done, hipStream_t stream) {
   if (!p || p->kind != CASK_HIP_PRECOND_JACOBI || p->n == 0) return 0;

@@ -40,5 +40,6 @@ struct DevBuf {
 // r.z in ONE pass when the preconditioner allows it (Jacobi); returns 1 if it did (partials[0 .. *n_partials)
 // written, fixed grid => reproducible), 0 if the caller must apply and reduce separately, < 0 on error.
 struct cask_hip_precond;
+int cask_hip_precond_rows(const cask_hip_precond *p);      // order of the matrix the preconditioner was built from
 int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d_z, double *d_partials,
                                int max_partials, int *n_partials, const int *d_done, hipStream_t stream);

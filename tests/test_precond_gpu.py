@@ -143,6 +143,16 @@ def test_pcg_with_textbook_ilu_beats_plain_cg():
     pc.close()
 
 
+def test_pcg_rejects_a_preconditioner_of_another_order():
+    n, rp, ci, va = synth.small("cant")
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pc = capi.Preconditioner("jacobi", 2, [0, 1, 2], [0, 1], [1.0, 1.0])
+    with pytest.raises(ValueError, match="different order"):
+        m.pcg(pc, np.ones(n))
+    pc.close()
+    m.close()
+
+
 def test_argument_checks():
     with pytest.raises(ValueError, match="ascending"):
         capi.Preconditioner("ilu0", 2, [0, 2, 2], [1, 0], [1.0, 2.0])
