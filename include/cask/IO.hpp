@@ -193,6 +193,68 @@ inline cask::CsrMatrix readMatrix(std::string path) {
   return detail::cooToCsr(full);
 }
 
+// Binary cache of a parsed matrix (the text of a 10^6-row SuiteSparse matrix takes seconds to
+// parse, the binary milliseconds): header "CASKCSR1", int64 n, m, nnz, then row_ptr (int32), col_ind (int32) and
+// values (fp64) little-endian as they sit in CsrMatrix.  No reference counterpart.
+inline void writeCsrBinary(const std::string &path, const cask::CsrMatrix &a) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) throw std::invalid_argument("Cannot write " + path);
+  const char magic[8] = {'C', 'A', 'S', 'K', 'C', 'S', 'R', '1'};
+  const long long dims[3] = {a.n, a.m, static_cast<long long>(a.values.size())};
+  f.write(magic, 8);
+  f.write(reinterpret_cast<const char *>(dims), sizeof(dims));
+  f.write(reinterpret_cast<const char *>(a.row_ptr.data()), static_cast<std::streamsize>(a.row_ptr.size() * sizeof(int)));
+  f.write(reinterpret_cast<const char *>(a.col_ind.data()), static_cast<std::streamsize>(a.col_ind.size() * sizeof(int)));
+  f.write(reinterpret_cast<const char *>(a.values.data()), static_cast<std::streamsize>(a.values.size() * sizeof(double)));
+  if (!f) throw std::invalid_argument("Error writing " + path);
+}
+
+inline cask::CsrMatrix readCsrBinary(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::invalid_argument("File not found: " + path);
+  char magic[8];
+  long long dims[3];
+  f.read(magic, 8);
+  f.read(reinterpret_cast<char *>(dims), sizeof(dims));
+  if (!f || std::string(magic, 8) != "CASKCSR1" || dims[0] < 0 || dims[1] < 0 || dims[2] < 0 || dims[2] > 2147483647LL)
+    throw std::invalid_argument("Not a CASK binary CSR file: " + path);
+  cask::CsrMatrix a;
+  a.n = static_cast<int>(dims[0]);
+  a.m = static_cast<int>(dims[1]);
+  a.nnzs = static_cast<int>(dims[2]);
+  a.row_ptr.resize(static_cast<size_t>(a.n) + 1);
+  a.col_ind.resize(static_cast<size_t>(a.nnzs));
+  a.values.resize(static_cast<size_t>(a.nnzs));
+  f.read(reinterpret_cast<char *>(a.row_ptr.data()), static_cast<std::streamsize>(a.row_ptr.size() * sizeof(int)));
+  f.read(reinterpret_cast<char *>(a.col_ind.data()), static_cast<std::streamsize>(a.col_ind.size() * sizeof(int)));
+  f.read(reinterpret_cast<char *>(a.values.data()), static_cast<std::streamsize>(a.values.size() * sizeof(double)));
+  if (!f || a.row_ptr.front() != 0 || a.row_ptr.back() != a.nnzs)
+    throw std::invalid_argument("Truncated or inconsistent binary CSR file: " + path);
+  return a;
+}
+
+// readMatrix with the cache beside the text file (<path>.csrbin): written on the first read, used afterwards.
+inline cask::CsrMatrix readMatrixCached(const std::string &path) {
+  const std::string cache = path + ".csrbin";
+  {
+    std::ifstream probe(cache, std::ios::binary);
+    if (probe) {
+      try {
+        return readCsrBinary(cache);
+      } catch (const std::invalid_argument &) {
+        // stale or foreign file: fall through to the text
+      }
+    }
+  }
+  cask::CsrMatrix a = readMatrix(path);
+  try {
+    writeCsrBinary(cache, a);
+  } catch (const std::invalid_argument &) {
+    // read-only directory: the cache is optional
+  }
+  return a;
+}
+
 // Stored triangle only; general files are rejected.
 inline cask::SymCsrMatrix readSymMatrix(std::string path) {
   MmInfo info = readHeader(path);

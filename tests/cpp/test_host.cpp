@@ -3,6 +3,8 @@
 // test/TestUtils.cpp.  No gtest in the image: a few macros do.  Run by
 // tests/test_host_cpp.py; argv[1] = directory with the plain .mtx fixtures.
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <string>
 
@@ -122,6 +124,22 @@ static void test_io(const std::string &dir) {
   dup.data.push_back(std::make_tuple(1, 0, 5.0));                     // later duplicate wins (DokMatrix::set)
   CsrMatrix d2 = converters::tripletToCsr(dup);
   CHECK(d2.nnzs == 2 && d2.values == (std::vector<double>{1.0, 5.0}) && d2.row_ptr == (std::vector<int>{0, 1, 2}));
+  // binary cache: round trip, and the cached reader returns the same matrix on the first and the second read
+  {
+    const std::string tmp = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/cask_host_test";
+    io::writeCsrBinary(tmp + ".csrbin", fast);
+    CHECK(io::readCsrBinary(tmp + ".csrbin") == fast);
+    std::ofstream(tmp + ".junk") << "not a matrix";
+    CHECK_THROWS(io::readCsrBinary(tmp + ".junk"), std::invalid_argument);
+    std::ifstream src(dir + "/matrices/bfwb62.mtx", std::ios::binary);
+    std::ofstream dst(tmp + ".mtx", std::ios::binary);
+    dst << src.rdbuf();
+    dst.close();
+    std::remove((tmp + ".mtx.csrbin").c_str());
+    CHECK(io::readMatrixCached(tmp + ".mtx") == fast);
+    CHECK(io::readMatrixCached(tmp + ".mtx") == fast);        // from the cache this time
+    CHECK(io::readCsrBinary(tmp + ".mtx.csrbin") == fast);
+  }
   // errors
   CHECK_THROWS(io::readHeader(dir + "/nope.mtx"), std::invalid_argument);
   CHECK_THROWS(io::readSymMatrix(dir + "/matrices/test_dense_4.mtx"), std::invalid_argument);
