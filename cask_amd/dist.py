@@ -144,19 +144,26 @@ class ShardedSpmv:
                 self._pad_out[g * self.max_local: g * self.max_local + self.sizes[g]])
         return self.x_full
 
-    def spmv(self, x_local, y_local=None):
+    def spmv(self, x_local, y_local=None, fence_before=True, fence_after=True):
+        """y_local = A_g x.  With a peer-to-peer exchange two orderings across ranks are needed: every slice
+        is final before anyone reads it (``fence_before``) and nobody overwrites its slice while a peer still
+        reads it (``fence_after``).  A caller whose next step is a collective anyway (the solvers' dot
+        products: an all-reduce completes only after every rank's product has run) passes
+        ``fence_after=False`` and saves one latency-bound collective per product."""
         if y_local is None:
             y_local = self.torch.empty(self.n_local, dtype=self.torch.float64, device=self.device)
         ex = self.exchange
         if ex is not None:
             if x_local.data_ptr() != ex.x_local.data_ptr():
                 ex.x_local.copy_(x_local)
-            ex.fence()              # every slice is final ...
+            if fence_before:
+                ex.fence()          # every slice is final ...
             if getattr(self, "fused_halo", False):
                 self.local_product(ex.x_ext, y_local)    # remote loads happen inside the product kernel
             else:
                 ex.pull()
-            ex.fence()              # ... and nobody overwrites its slice while a peer still reads from it
+            if fence_after:
+                ex.fence()          # ... and nobody overwrites its slice while a peer still reads from it
             if not getattr(self, "fused_halo", False):
                 self.local_product(ex.x_ext, y_local)
             return y_local
@@ -195,7 +202,7 @@ class ShardedSpmv:
         rsold = self.dot(r, r)                                   # :198
         iterations, tol2 = 0, tol * tol
         for i in range(maxiters):
-            Ap = self.spmv(p)                                    # :206
+            Ap = self.spmv(p, fence_after=False)                 # :206 (the all-reduce of p.Ap orders the ranks)
             alpha = rsold / self.dot(p, Ap)                      # :208
             x = x + alpha * p                                    # :210
             r = r - alpha * Ap                                   # :212
@@ -220,9 +227,9 @@ class ShardedSpmv:
         rho = self.dot(rt, r)
         iterations, tol2 = 0, tol * tol
         for i in range(maxiters):
-            q = self.spmv(p)
-            qt = transposed.spmv(pt)
-            alpha = rho / self.dot(pt, q)
+            q = self.spmv(p, fence_after=False)                  # each product publishes its operand and fences
+            qt = transposed.spmv(pt, fence_after=False)          # before reading; the all-reduce of pt.q orders
+            alpha = rho / self.dot(pt, q)                        # the reads against the updates below
             x.add_(alpha * p)
             r.sub_(alpha * q)
             rt.sub_(alpha * qt)
