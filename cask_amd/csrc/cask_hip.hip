@@ -186,7 +186,17 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
     while (by_len < mean && by_len < 64) by_len *= 2;
     d.kind_g = std::min(64, std::max(1, std::min(by_rows, by_len)));
     if (cur_max > SKEW_FACTOR * (d.kind_g & 0xff)) d.kind_g |= KIND_SKEW;   // long rows get a wave each
-    blocks.push_back(d);
+    if (cur_nnz == 0) {
+      // a run of empty rows: nothing to stream.  The stream path would still issue its clamped 16-byte pair
+      // loads, and for a block at the (odd) end of the arrays the pair's second element lies past col_ind --
+      // an uninitialised column fed to an x gather.  Such a block is a zero-fill piece instead (long-row path,
+      // nnz_count == 0, n_rows rows), which touches neither the stream nor x.
+      d.kind_g = KIND_LONG;
+      d.aux = 0;
+      (longs ? *longs : blocks).push_back(d);
+    } else {
+      blocks.push_back(d);
+    }
     cur_rows = 0;
     cur_nnz = 0;
     cur_max = 0;
@@ -229,6 +239,11 @@ int ensure_host_col_ind(cask_hip_matrix &m) {
   if (m.h_ci.size() == (size_t)m.nnz) return CASK_HIP_OK;
   m.h_ci.resize((size_t)m.nnz);
   if (m.nnz) HIP_TRY(hipMemcpy(m.h_ci.data(), m.d_ci, (size_t)m.nnz * sizeof(int), hipMemcpyDeviceToHost));
+  for (int64_t k = 0; k < m.nnz; k++)
+    if (m.h_ci[k] < 0 || m.h_ci[k] >= m.n_cols) {
+      m.h_ci.clear();
+      return fail(CASK_HIP_ERR_INVALID, "column index out of range");
+    }
   return CASK_HIP_OK;
 }
 
@@ -894,6 +909,17 @@ int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz, cons
   HIP_TRY(hipMemcpy(m->h_rp.data(), d_row_ptr, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyDeviceToHost));
   rc = check_csr(n_rows, n_cols, nnz, m->h_rp.data());
   if (rc) return rc;
+  if (nnz > 0) {                                              // columns must lie in [0, n_cols): one small reduction
+    DevBuf<int> range;
+    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::min()};
+    HIP_TRY(range.upload(init, 2));
+    const int grid = (int)std::min<int64_t>(1024, (nnz + 255) / 256);
+    hipLaunchKernelGGL(k_col_range, dim3(grid), dim3(256), 0, nullptr, nnz, d_col_ind, range.p);
+    HIP_TRY(hipGetLastError());
+    int got[2];
+    HIP_TRY(hipMemcpy(got, range.p, sizeof(got), hipMemcpyDeviceToHost));
+    if (got[0] < 0 || got[1] >= n_cols) return fail(CASK_HIP_ERR_INVALID, "column index out of range");
+  }
   m->d_rp = d_row_ptr;
   m->d_ci = d_col_ind;
   m->d_val = d_values;
@@ -1162,14 +1188,23 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
 int cask_hip_ddot_device(int64_t n, const double *d_x, const double *d_y, double *d_result, void *stream) {
   if (n < 0 || !d_result || (n > 0 && (!d_x || !d_y))) return fail(CASK_HIP_ERR_INVALID, "bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // partial buffer: one allocation per (thread, device) kept for reuse
-  static thread_local double *scratch = nullptr;
-  static thread_local int scratch_dev = -1;
+  // partial buffers: one per (device, stream) of the calling thread, kept for reuse -- two dots in flight on
+  // different streams must not share their partials, and a change of device must not leak the old buffer.
+  // (A stream handle reused after hipStreamDestroy simply reuses the buffer.)
+  struct Scratch { int dev; hipStream_t s; double *p; };
+  static thread_local std::vector<Scratch> scratches;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (!scratch || scratch_dev != dev) {
+  double *scratch = nullptr;
+  for (const Scratch &sc : scratches)
+    if (sc.dev == dev && sc.s == s) scratch = sc.p;
+  if (!scratch) {
+    if (scratches.size() >= 64) {                             // bound the cache: drop this device's oldest entries
+      for (auto it = scratches.begin(); it != scratches.end();)
+        if (it->dev == dev) { HIP_TRY(hipStreamSynchronize(it->s)); (void)hipFree(it->p); it = scratches.erase(it); } else ++it;
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), BLAS_MAX_PARTIALS * sizeof(double)));
-    scratch_dev = dev;
+    scratches.push_back(Scratch{dev, s, scratch});
   }
   const int grid = blas_grid(n);
   hipLaunchKernelGGL(k_dot_partial, dim3(grid), dim3(BLAS_WG), 0, s, n, d_x, d_y, scratch, (const int *)nullptr);

@@ -72,8 +72,12 @@ cask::CsrMatrix expandSymmetric(const cask::CsrMatrix &lower) {
   // mirror the stored triangle (reference: DokMatrix::explicitSymmetric, SparseMatrix.hpp:156-189)
   const int n = lower.n;
   std::vector<int> count(static_cast<size_t>(n) + 1, 0);
+  // Only the stored LOWER triangle counts, as for the reference's mkl_dcsrsymv(uplo = 'l')
+  // (SparseLinearSolvers.hpp:189,206), which never reads entries above the diagonal: a caller that hands over
+  // an explicitly symmetric matrix must get the same operator, not one with every off-diagonal doubled.
   for (int i = 0; i < n; i++)
     for (int k = lower.row_ptr[i]; k < lower.row_ptr[i + 1]; k++) {
+      if (lower.col_ind[k] > i) continue;
       count[i + 1]++;
       if (lower.col_ind[k] != i) count[lower.col_ind[k] + 1]++;
     }
@@ -88,13 +92,14 @@ cask::CsrMatrix expandSymmetric(const cask::CsrMatrix &lower) {
   std::vector<int> fill(count.begin(), count.end() - 1);
   for (int i = 0; i < n; i++)          // stored entries: columns <= i, ascending
     for (int k = lower.row_ptr[i]; k < lower.row_ptr[i + 1]; k++) {
+      if (lower.col_ind[k] > i) continue;
       full.col_ind[fill[i]] = lower.col_ind[k];
       full.values[fill[i]++] = lower.values[k];
     }
   for (int i = 0; i < n; i++)          // mirrored entries: columns > row, ascending because i ascends
     for (int k = lower.row_ptr[i]; k < lower.row_ptr[i + 1]; k++) {
       const int j = lower.col_ind[k];
-      if (j == i) continue;
+      if (j >= i) continue;
       full.col_ind[fill[j]] = i;
       full.values[fill[j]++] = lower.values[k];
     }

@@ -397,6 +397,11 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
 
   if (d.kind_g & KIND_LONG) {
+    if (d.nnz_count == 0) {                                   // a run of empty rows (planner: zero-fill piece)
+      for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = 0.0;
+      if (EXT && dot.w && tid == 0) dot.dot_part[lb] = 0.0;
+      return;
+    }
     // One piece of one long row: the whole workgroup strides over it.
     const int end = d.nnz_start + d.nnz_count;
     double acc = 0.0;

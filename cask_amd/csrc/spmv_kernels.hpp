@@ -269,6 +269,10 @@ __global__ void k_spmv_long(const BlockDesc *__restrict__ blocks, int n_blocks,
   __shared__ double red[16];
   const int tid = threadIdx.x, WG = blockDim.x;
   const BlockDesc d = blocks[blockIdx.x];
+  if (d.nnz_count == 0) {                                     // a run of empty rows (planner: zero-fill piece)
+    for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = 0.0;
+    return;
+  }
   const int end = d.nnz_start + d.nnz_count;
   double acc = 0.0;
   for (int k = d.nnz_start + tid; k < end; k += 4 * WG) {
@@ -332,6 +336,24 @@ __global__ void k_col_span_blocks(BlockDesc *blocks, int n_blocks, const int *__
     for (int w = 1; w < (int)(blockDim.x >> 6); w++) { lo = min(lo, smin[w]); hi = max(hi, smax[w]); }
     blocks[b].cmin = hi < 0 ? 0 : lo;
     blocks[b].cwidth = hi < 0 ? 0 : hi - lo + 1;
+  }
+}
+
+// min / max of a column-index array (create_device validates borrowed arrays with it); out[0] = min, out[1] = max,
+// both preset by the host.
+__global__ void k_col_range(int64_t n, const int *__restrict__ ci, int *out) {
+  int lo = INT32_MAX, hi = INT32_MIN;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    const int c = ci[k];
+    lo = min(lo, c); hi = max(hi, c);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(out, lo);
+    atomicMax(out + 1, hi);
   }
 }
 

@@ -11,6 +11,8 @@
 #ifndef CASK_IO_HPP
 #define CASK_IO_HPP
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -194,13 +196,26 @@ inline cask::CsrMatrix readMatrix(std::string path) {
 }
 
 // Binary cache of a parsed matrix (the text of a 10^6-row SuiteSparse matrix takes seconds to
-// parse, the binary milliseconds): header "CASKCSR1", int64 n, m, nnz, then row_ptr (int32), col_ind (int32) and
-// values (fp64) little-endian as they sit in CsrMatrix.  No reference counterpart.
-inline void writeCsrBinary(const std::string &path, const cask::CsrMatrix &a) {
+// parse, the binary milliseconds): header "CASKCSR2", int64 n, m, nnz, int64 size and mtime (ns) of the text file
+// the cache was made from (0, 0 = stand-alone file), then row_ptr (int32), col_ind (int32) and values (fp64)
+// little-endian as they sit in CsrMatrix.  No reference counterpart.
+struct SourceStamp {
+  long long size = 0, mtime_ns = 0;
+  bool operator==(const SourceStamp &o) const { return size == o.size && mtime_ns == o.mtime_ns; }
+};
+inline bool statSource(const std::string &path, SourceStamp &out) {
+  struct stat st;
+  if (::stat(path.c_str(), &st) != 0) return false;
+  out.size = static_cast<long long>(st.st_size);
+  out.mtime_ns = static_cast<long long>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec;
+  return true;
+}
+
+inline void writeCsrBinary(const std::string &path, const cask::CsrMatrix &a, const SourceStamp &src = SourceStamp()) {
   std::ofstream f(path, std::ios::binary);
   if (!f) throw std::invalid_argument("Cannot write " + path);
-  const char magic[8] = {'C', 'A', 'S', 'K', 'C', 'S', 'R', '1'};
-  const long long dims[3] = {a.n, a.m, static_cast<long long>(a.values.size())};
+  const char magic[8] = {'C', 'A', 'S', 'K', 'C', 'S', 'R', '2'};
+  const long long dims[5] = {a.n, a.m, static_cast<long long>(a.values.size()), src.size, src.mtime_ns};
   f.write(magic, 8);
   f.write(reinterpret_cast<const char *>(dims), sizeof(dims));
   f.write(reinterpret_cast<const char *>(a.row_ptr.data()), static_cast<std::streamsize>(a.row_ptr.size() * sizeof(int)));
@@ -209,15 +224,22 @@ inline void writeCsrBinary(const std::string &path, const cask::CsrMatrix &a) {
   if (!f) throw std::invalid_argument("Error writing " + path);
 }
 
-inline cask::CsrMatrix readCsrBinary(const std::string &path) {
+// `src_out` (optional) receives the stamp of the text file the cache was made from.  The arrays are validated
+// (monotone row_ptr, columns inside [0, m)): a cache file may have been written by anybody.
+inline cask::CsrMatrix readCsrBinary(const std::string &path, SourceStamp *src_out = nullptr) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::invalid_argument("File not found: " + path);
   char magic[8];
-  long long dims[3];
+  long long dims[5];
   f.read(magic, 8);
   f.read(reinterpret_cast<char *>(dims), sizeof(dims));
-  if (!f || std::string(magic, 8) != "CASKCSR1" || dims[0] < 0 || dims[1] < 0 || dims[2] < 0 || dims[2] > 2147483647LL)
+  if (!f || std::string(magic, 8) != "CASKCSR2" || dims[0] < 0 || dims[1] < 0 || dims[2] < 0 || dims[0] > 2147483646LL ||
+      dims[1] > 2147483647LL || dims[2] > 2147483647LL)
     throw std::invalid_argument("Not a CASK binary CSR file: " + path);
+  if (src_out) {
+    src_out->size = dims[3];
+    src_out->mtime_ns = dims[4];
+  }
   cask::CsrMatrix a;
   a.n = static_cast<int>(dims[0]);
   a.m = static_cast<int>(dims[1]);
@@ -228,19 +250,27 @@ inline cask::CsrMatrix readCsrBinary(const std::string &path) {
   f.read(reinterpret_cast<char *>(a.row_ptr.data()), static_cast<std::streamsize>(a.row_ptr.size() * sizeof(int)));
   f.read(reinterpret_cast<char *>(a.col_ind.data()), static_cast<std::streamsize>(a.col_ind.size() * sizeof(int)));
   f.read(reinterpret_cast<char *>(a.values.data()), static_cast<std::streamsize>(a.values.size() * sizeof(double)));
-  if (!f || a.row_ptr.front() != 0 || a.row_ptr.back() != a.nnzs)
-    throw std::invalid_argument("Truncated or inconsistent binary CSR file: " + path);
+  bool ok = static_cast<bool>(f) && a.row_ptr.front() == 0 && a.row_ptr.back() == a.nnzs;
+  for (int r = 0; ok && r < a.n; r++) ok = a.row_ptr[r + 1] >= a.row_ptr[r];
+  for (int k = 0; ok && k < a.nnzs; k++) ok = a.col_ind[k] >= 0 && a.col_ind[k] < a.m;
+  if (!ok) throw std::invalid_argument("Truncated or inconsistent binary CSR file: " + path);
   return a;
 }
 
-// readMatrix with the cache beside the text file (<path>.csrbin): written on the first read, used afterwards.
+// readMatrix with the cache beside the text file (<path>.csrbin): written on the first read, used afterwards as
+// long as the text file still has the size and modification time recorded in the cache.
 inline cask::CsrMatrix readMatrixCached(const std::string &path) {
   const std::string cache = path + ".csrbin";
+  SourceStamp now;
+  const bool have_stamp = statSource(path, now);
   {
     std::ifstream probe(cache, std::ios::binary);
-    if (probe) {
+    if (probe && have_stamp) {
       try {
-        return readCsrBinary(cache);
+        SourceStamp made_from;
+        cask::CsrMatrix a = readCsrBinary(cache, &made_from);
+        if (made_from == now) return a;
+        // the text changed since the cache was written: re-parse below and overwrite the cache
       } catch (const std::invalid_argument &) {
         // stale or foreign file: fall through to the text
       }
@@ -248,7 +278,7 @@ inline cask::CsrMatrix readMatrixCached(const std::string &path) {
   }
   cask::CsrMatrix a = readMatrix(path);
   try {
-    writeCsrBinary(cache, a);
+    if (have_stamp) writeCsrBinary(cache, a, now);
   } catch (const std::invalid_argument &) {
     // read-only directory: the cache is optional
   }

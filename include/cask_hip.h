@@ -113,7 +113,9 @@ int cask_hip_csr_create(int32_t n_rows, int32_t n_cols, int64_t nnz,
                         const cask_hip_params *params, cask_hip_matrix **out);
 
 /* Same, but the three arrays already live in device memory and stay owned by
- * the caller (they must outlive the handle). */
+ * the caller: they must outlive the handle and must not be modified while it
+ * exists (the launch plan caches what it derived from them; re-create the
+ * handle after a change).  Columns are range-checked here. */
 int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz,
                                const int32_t *d_row_ptr, const int32_t *d_col_ind,
                                const double *d_values,

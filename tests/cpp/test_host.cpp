@@ -139,6 +139,21 @@ static void test_io(const std::string &dir) {
     CHECK(io::readMatrixCached(tmp + ".mtx") == fast);
     CHECK(io::readMatrixCached(tmp + ".mtx") == fast);        // from the cache this time
     CHECK(io::readCsrBinary(tmp + ".mtx.csrbin") == fast);
+    // a text file that changed after the cache was written is re-parsed, not served from the stale cache
+    {
+      std::ofstream edit(tmp + ".mtx", std::ios::binary);
+      edit << "%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 3.5\n2 2 4.5\n";
+    }
+    CsrMatrix edited = io::readMatrixCached(tmp + ".mtx");
+    CHECK(edited.n == 2 && edited.nnzs == 2 && edited.values == (std::vector<double>{3.5, 4.5}));
+    CHECK(io::readCsrBinary(tmp + ".mtx.csrbin") == edited);  // and the cache was refreshed
+    // a cache with a broken row_ptr or an out-of-range column is rejected
+    {
+      CsrMatrix bad = edited;
+      bad.col_ind[1] = 7;
+      io::writeCsrBinary(tmp + ".bad.csrbin", bad);
+      CHECK_THROWS(io::readCsrBinary(tmp + ".bad.csrbin"), std::invalid_argument);
+    }
   }
   // errors
   CHECK_THROWS(io::readHeader(dir + "/nope.mtx"), std::invalid_argument);

@@ -270,3 +270,54 @@ def test_random_matrices_all_design_points(profile):
         for dp in DESIGN_POINTS:
             got = run_host(n_rows, n_cols, rp, ci, va, x, dp)
             oracle.assert_almost_equal(got, want, what=f"{profile} trial {trial} {n_rows}x{n_cols} nnz={ci.size} {dp}")
+
+
+def test_empty_row_block_at_odd_end_of_arrays():
+    """a block of only empty rows whose (clamped) stream pair straddles the end of col_ind used to
+    feed the uninitialised int behind the array to an x gather.  col_ind sits at the front of a larger device
+    allocation whose next element is poison (a huge column): a wild gather would fault or return garbage."""
+    import torch
+    cases = []
+    # (a) 2 nnz in row 0, a long run of empty rows, 1 trailing nonzero: nnz odd, an all-empty block starts at the
+    #     even index nnz-1
+    for n_empty in (600, 1021, 2500):
+        n = n_empty + 2
+        rp = np.zeros(n + 1, dtype=np.int32)
+        rp[1:] = 2
+        rp[n] = 3
+        cases.append((n, rp, np.array([0, 1, 5], dtype=np.int32), np.array([1.0, 2.0, 3.0])))
+    # (b) odd nnz followed by trailing empty rows: the all-empty block starts at nnz itself
+    for n_empty in (600, 2500):
+        n = n_empty + 3
+        rp = np.zeros(n + 1, dtype=np.int32)
+        rp[1], rp[2], rp[3:] = 1, 2, 3
+        cases.append((n, rp, np.array([0, 1, 2], dtype=np.int32), np.array([1.0, 2.0, 3.0])))
+    for n, rp, ci, va in cases:
+        x = np.arange(1, n + 1, dtype=np.float64)
+        want = oracle.csr_spmv(rp, ci, va, x)
+        for dp in (dict(variant="merge", tile_width=-1), dict(variant="merge"), dict(variant="merge", wg_size=64, items_per_thread=2),
+                   dict(variant="merge_wave"), dict(variant="merge_wave", wg_size=64, items_per_thread=2)):
+            big = torch.full((ci.size + 61,), 0x7ffffff0, dtype=torch.int32, device="cuda")
+            big[: ci.size] = torch.from_numpy(ci).cuda()
+            vbig = torch.full((va.size + 61,), float("nan"), dtype=torch.float64, device="cuda")
+            vbig[: va.size] = torch.from_numpy(va).cuda()
+            m = capi.CsrMatrix.from_device(n, n, torch.from_numpy(rp).cuda(), big[: ci.size], vbig[: va.size],
+                                           capi.make_params(**dp))
+            xt = torch.from_numpy(x).cuda()
+            yt = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            m.spmv_device(xt, yt)
+            torch.cuda.synchronize()
+            m.close()
+            oracle.assert_almost_equal(yt.cpu().numpy(), want, what=f"empty-block n={n} {dp}")
+
+
+def test_create_device_rejects_out_of_range_columns():
+    """borrowed device arrays are range-checked at create time (a wild column is an OOB gather)."""
+    import torch
+    rp = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")
+    va = torch.ones(3, dtype=torch.float64, device="cuda")
+    for bad in ([0, 5, 1], [-1, 0, 1]):
+        ci = torch.tensor(bad, dtype=torch.int32, device="cuda")
+        for dp in (dict(variant="vector"), dict(variant="merge", tile_width=-1), dict()):
+            with pytest.raises(ValueError, match="column index out of range"):
+                capi.CsrMatrix.from_device(2, 3, rp, ci, va, capi.make_params(**dp))
