@@ -27,7 +27,18 @@ EXPORTED_SYMBOLS = (
     "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
     "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
     "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
+    "cask_hip_solve_device",
 )
+SOLVER_CG, SOLVER_BICG = 1, 2
+SOLVER_AUTO, SOLVER_COMPOSED, SOLVER_CLASSIC = 0, 1, 2
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_int32, c_void_p, c_void_p)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+
+
+class SolverConfig(Structure):
+    _fields_ = [("kind", c_int32), ("mode", c_int32), ("d_shared_base", c_void_p), ("stride", c_int64),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p), ("exchange", EXCHANGE_FN),
+                ("exchange_user", c_void_p), ("n_full", c_int64)]
 PRECOND_JACOBI, PRECOND_ILU0, PRECOND_ILU0_UNIT = 1, 2, 3
 
 
@@ -119,6 +130,9 @@ def load() -> ctypes.CDLL:
         L.cask_hip_precond_apply_device.argtypes = [vp, vp, vp, vp]
         L.cask_hip_trsolve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp]
         L.cask_hip_pcg.argtypes = [vp, vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
+    if hasattr(L, "cask_hip_solve_device"):
+        L.cask_hip_solve_device.argtypes = [vp, vp, POINTER(SolverConfig), vp, vp, i32, dbl, POINTER(i32), POINTER(i32),
+                                            POINTER(dbl), vp]
     for name in EXPORTED_SYMBOLS:
         if os.environ.get("CASK_HIP_DIAGNOSTIC_LIB") and not hasattr(L, name):
             continue                                            # an older build loaded for an A/B timing
@@ -306,6 +320,34 @@ class CsrMatrix:
 
     def bicg(self, rhs, x0=None, maxiters=2000, tol=1e-5):
         return self._solve(load().cask_hip_bicg, rhs, x0, maxiters, tol)
+
+    def solve_device(self, b_t, x_t, kind="cg", transposed=None, mode=SOLVER_AUTO, maxiters=2000, tol=1e-5,
+                     shared_base=0, stride=0, allreduce=None, exchange=None, n_full=0, stream=None):
+        """CG / BiCG on device vectors (``cask_hip_solve_device``); ``x_t`` holds the initial guess and receives
+        the solution.  ``allreduce(ptr, count, stream) -> int`` / ``exchange(local_ptr, full_ptr, stream) -> int``
+        are python callables for the row-sharded forms (see include/cask_hip.h).  Returns
+        (iterations, converged, usec_per_iteration)."""
+        cfg = SolverConfig()
+        cfg.kind = {"cg": SOLVER_CG, "bicg": SOLVER_BICG}.get(kind, kind)
+        cfg.mode = mode
+        cfg.d_shared_base = shared_base or None
+        cfg.stride = stride
+        cfg.n_full = n_full
+        keep = []
+        if allreduce is not None:
+            cb = ALLREDUCE_FN(lambda p, c, s, u: int(allreduce(p, c, s) or 0))
+            cfg.allreduce = cb
+            keep.append(cb)
+        if exchange is not None:
+            cb2 = EXCHANGE_FN(lambda a, b, s, u: int(exchange(a, b, s) or 0))
+            cfg.exchange = cb2
+            keep.append(cb2)
+        it, conv, us = c_int32(0), c_int32(0), c_double(0)
+        _check(load().cask_hip_solve_device(self._h, transposed._h if transposed is not None else None, byref(cfg),
+                                            c_void_p(b_t.data_ptr()), c_void_p(x_t.data_ptr()), int(maxiters), float(tol),
+                                            byref(it), byref(conv), byref(us), c_void_p(_stream_ptr(stream))))
+        del keep
+        return it.value, bool(conv.value), us.value
 
     def pcg(self, precond, rhs, x0=None, maxiters=2000, tol=1e-5):
         """Preconditioned CG (pcg<double, Precon>, SparseLinearSolvers.hpp:162-239) with a ``Preconditioner``."""

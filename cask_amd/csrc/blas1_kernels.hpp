@@ -27,34 +27,6 @@ __device__ __forceinline__ double wg_sum(double v, double *red) {
   return s;   // valid in thread 0
 }
 
-// Sum of an L2-resident partials array (the <= 1024 shares of a BLAS-1 reduction, or the per-block
-// shares the product kernel's dot epilogue leaves: a few thousand), computed redundantly by every
-// workgroup in the same order => every workgroup sees the bit-identical value.  This replaces a
-// separate single-workgroup "final" kernel (4.3 us + a launch boundary per dot in the first version).
-// The loads go out eight 16-byte pairs per lane at a time: one L2 round trip for up to 4096 shares with
-// 256 threads, not one per share.  Result in all threads.
-__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int n, double *red) {
-  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(partials);
-  const int n2 = n >> 1, tid = threadIdx.x, wg = blockDim.x;
-  double acc = 0.0;
-  for (int i0 = 0; i0 < n2; i0 += 8 * wg) {
-    dbl2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = p2[min(i0 + u * wg + tid, n2 - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (i0 + u * wg + tid < n2) acc += v[u].x + v[u].y;
-  }
-  if ((n & 1) && tid == 0) acc += partials[n - 1];
-  acc = group_sum<64>(acc);
-  __syncthreads();                                  // red may still be read by a previous use
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  double s = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
-  return s;
-}
-
 __global__ void k_dot_partial(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                               double *__restrict__ partials, const int *done) {
   __shared__ double red[16];
@@ -152,7 +124,7 @@ __global__ void k_cg_update_xr(int64_t n, const double *rsold, const double *__r
                                double *__restrict__ part_rr, const int *done) {
   __shared__ double red[16];
   if (done && *done) return;
-  const double alpha = *rsold / sum_partials(part_pAp, n_part, red);
+  const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
   const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p), *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
   dbl2 *x2 = reinterpret_cast<dbl2 *>(x), *r2 = reinterpret_cast<dbl2 *>(r);
   double acc0 = 0.0, acc1 = 0.0;
@@ -187,7 +159,7 @@ __global__ void k_cg_update_p(int64_t n, const double *__restrict__ part_rr, int
                               double *__restrict__ p, int *done, int *iters) {
   __shared__ double red[16];
   if (*done) return;
-  const double rsnew = sum_partials(part_rr, n_part, red);
+  const double rsnew = partials_or_scalar(part_rr, n_part, red);
   if (rsnew <= tol2) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *done = 1; }
     return;
@@ -215,7 +187,7 @@ __global__ void k_bicg_update(int64_t n, const double *rho, const double *__rest
                               double *__restrict__ part_rr, double *__restrict__ part_rho, const int *done) {
   __shared__ double red[16];
   if (done && *done) return;
-  const double alpha = *rho / sum_partials(part_ptq, n_part, red);
+  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
   const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p), *q2 = reinterpret_cast<const dbl2 *>(q),
              *qt2 = reinterpret_cast<const dbl2 *>(qt);
   dbl2 *x2 = reinterpret_cast<dbl2 *>(x), *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
@@ -260,12 +232,12 @@ __global__ void k_bicg_update_p(int64_t n, const double *__restrict__ part_rr, c
                                 double *__restrict__ p, double *__restrict__ pt, int *done, int *iters) {
   __shared__ double red[16];
   if (*done) return;
-  const double rr = sum_partials(part_rr, n_part, red);
+  const double rr = partials_or_scalar(part_rr, n_part, red);
   if (rr <= tol2) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *done = 1;
     return;
   }
-  const double rho_new = sum_partials(part_rho, n_part, red);
+  const double rho_new = partials_or_scalar(part_rho, n_part, red);
   const double beta = rho_new / *rho;
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt);
@@ -284,6 +256,108 @@ __global__ void k_bicg_update_p(int64_t n, const double *__restrict__ part_rr, c
     pt[n - 1] = fma(beta, pt[n - 1], rt[n - 1]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { *rho_out = rho_new; *iters = iter; }
+}
+// ---- two-launch passes (the product kernel composes the direction: SolverPass, spmv_common.hpp) ------------
+// Vectors that peers read over xGMI (row-sharded solvers) are stored write-through at system scope.
+__device__ __forceinline__ void store_pair(dbl2 *p, dbl2 v, int sys_scope) {
+  if (sys_scope) {
+    double *q = reinterpret_cast<double *>(p);
+    __hip_atomic_store(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    *p = v;
+  }
+}
+__device__ __forceinline__ void store_one(double *p, double v, int sys_scope) {
+  if (sys_scope) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else *p = v;
+}
+
+// CG, second launch of a pass: alpha = rsold / (p.Ap) ; r -= alpha Ap ; shares of r.r
+// (SparseLinearSolvers.hpp:208, 212, 218).  x += alpha p (:210) is applied by the next product launch, which
+// reads p anyway; alpha is left in *alpha_out for it.
+__global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__restrict__ part_pAp, int n_part,
+                              const double *__restrict__ Ap, double *__restrict__ r, double *__restrict__ part_rr,
+                              double *alpha_out, const int *done, int sys_scope) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
+  const dbl2 *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
+  dbl2 *r2 = reinterpret_cast<dbl2 *>(r);
+  double acc0 = 0.0, acc1 = 0.0;
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 av = Ap2[i];
+    dbl2 rv = r2[i];
+    rv.x = fma(-alpha, av.x, rv.x);
+    rv.y = fma(-alpha, av.y, rv.y);
+    store_pair(r2 + i, rv, sys_scope);
+    acc0 = fma(rv.x, rv.x, acc0);
+    acc1 = fma(rv.y, rv.y, acc1);
+  }
+  if (owns_tail(n)) {
+    const double rn = fma(-alpha, Ap[n - 1], r[n - 1]);
+    store_one(r + (n - 1), rn, sys_scope);
+    acc0 = fma(rn, rn, acc0);
+  }
+  __syncthreads();
+  const double s = wg_sum(acc0 + acc1, red);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = s;
+}
+
+// BiCG, last launch of a pass: alpha = rho / (pt.q) ; r -= alpha q ; rt -= alpha qt ; shares of r.r and rt.r
+__global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__restrict__ part_ptq, int n_part,
+                                const double *__restrict__ q, const double *__restrict__ qt,
+                                double *__restrict__ r, double *__restrict__ rt, double *__restrict__ part_rr,
+                                double *__restrict__ part_rho, double *alpha_out, const int *done, int sys_scope) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
+  const dbl2 *q2 = reinterpret_cast<const dbl2 *>(q), *qt2 = reinterpret_cast<const dbl2 *>(qt);
+  dbl2 *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
+  double a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
+  CASK_PAIR_LOOP(n >> 1) {
+    const dbl2 qv = q2[i], qtv = qt2[i];
+    dbl2 rv = r2[i], rtv = rt2[i];
+    rv.x = fma(-alpha, qv.x, rv.x);
+    rv.y = fma(-alpha, qv.y, rv.y);
+    rtv.x = fma(-alpha, qtv.x, rtv.x);
+    rtv.y = fma(-alpha, qtv.y, rtv.y);
+    store_pair(r2 + i, rv, sys_scope);
+    store_pair(rt2 + i, rtv, sys_scope);
+    a_rr0 = fma(rv.x, rv.x, a_rr0);
+    a_rr1 = fma(rv.y, rv.y, a_rr1);
+    a_rho0 = fma(rtv.x, rv.x, a_rho0);
+    a_rho1 = fma(rtv.y, rv.y, a_rho1);
+  }
+  if (owns_tail(n)) {
+    const double rn = fma(-alpha, q[n - 1], r[n - 1]);
+    const double rtn = fma(-alpha, qt[n - 1], rt[n - 1]);
+    store_one(r + (n - 1), rn, sys_scope);
+    store_one(rt + (n - 1), rtn, sys_scope);
+    a_rr0 = fma(rn, rn, a_rr0);
+    a_rho0 = fma(rtn, rn, a_rho0);
+  }
+  __syncthreads();
+  const double s1 = wg_sum(a_rr0 + a_rr1, red);
+  __syncthreads();
+  const double s2 = wg_sum(a_rho0 + a_rho1, red);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = s1; part_rho[blockIdx.x] = s2; }
+}
+
+// Row-sharded solvers: this rank's partial sums -> one scalar each (fixed order), ready for the all-reduce.
+// One workgroup; up to two quantities per launch (BiCG's r.r and rt.r travel in one collective).
+__global__ void k_sum_to_scalars(const double *__restrict__ pa, int na, double *out_a,
+                                 const double *__restrict__ pb, int nb, double *out_b, const int *done) {
+  __shared__ double red[16];
+  if (done && *done) return;
+  const double a = sum_partials(pa, na, red);
+  if (threadIdx.x == 0) *out_a = a;
+  if (pb) {
+    const double b = sum_partials(pb, nb, red);
+    if (threadIdx.x == 0) *out_b = b;
+  }
 }
 #undef CASK_PAIR_LOOP
 

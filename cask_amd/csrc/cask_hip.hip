@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -105,6 +106,7 @@ struct cask_hip_matrix {
   // row-sharded product (cask_hip_p2p.h): columns >= halo_n_own are read from the addresses in halo_addr
   int halo_n_own = std::numeric_limits<int>::max();
   const uint64_t *halo_addr = nullptr;
+  int64_t halo_shift = 0;          // bytes added to every halo address (set per launch by the sharded solvers)
   hipStream_t stream = nullptr;    // for the host-vector entry points and timing
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
   std::unique_ptr<cask_hip_matrix> transpose;
@@ -614,12 +616,16 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
 int dot_lds_bytes(int wg_size) { return 16 * wg_size + 128; }
 
 template <int IPT>
-int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot) {
+int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot,
+                   const SolverPass *pass) {
   const Plan &pl = m.plan;
   MergeLaunch l{};
   l.grid = pl.grid;
   l.wg_size = pl.prm.wg_size;
-  l.lds_bytes = pl.lds_bytes + (dot.w ? dot_lds_bytes(pl.prm.wg_size) : 0);
+  // a solver pass always carries the dot area: its first 16 doubles also serve the sums of the pass scalars
+  l.lds_bytes = pl.lds_bytes + ((dot.w || pass) ? dot_lds_bytes(pl.prm.wg_size) : 0);
+  l.solver_pass = pass != nullptr;
+  if (pass) l.pass = *pass;
   l.xu = pl.xu;
   l.remap = pl.prm.xcd_remap > 0;
   l.n_cols = m.n_cols;
@@ -636,13 +642,16 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.xchunk = pl.xchunk.p;
   l.val = m.d_val;
   l.partials = pl.partials.p;
-  l.halo = XHalo{m.halo_n_own, m.halo_addr};
+  l.halo = XHalo{m.halo_n_own, m.halo_addr, m.halo_shift};
   l.dot = dot;
   launch_merge_blocks<IPT>(l, x, y, s);
   if (pl.n_split_rows > 0) {
-    const DotEpilogue fix{dot.w, dot.w ? dot.dot_part + pl.grid : nullptr};
+    // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
+    // launch stored (b_new), or the plain vector the pass names (wa without wb)
+    const double *fw = pass ? (dot.dot_part ? (pass->wa && !pass->wb ? pass->wa : pass->b_new) : nullptr) : dot.w;
+    const DotEpilogue fix{fw, fw ? dot.dot_part + pl.grid : nullptr};
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
-                       pl.n_split_rows, pl.partials.p, y, fix);
+                       pl.n_split_rows, pl.partials.p, y, fix, pass ? (const int *)pass->done : (const int *)nullptr);
   }
   return CASK_HIP_OK;
 }
@@ -670,7 +679,7 @@ int launch_merge_wave_i(const cask_hip_matrix &m, const double *x, double *y, hi
   }
   if (pl.n_split_rows > 0)
     hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
-                       pl.n_split_rows, pl.partials.p, y, DotEpilogue{nullptr, nullptr});
+                       pl.n_split_rows, pl.partials.p, y, DotEpilogue{nullptr, nullptr}, (const int *)nullptr);
   return CASK_HIP_OK;
 }
 
@@ -681,13 +690,16 @@ bool plan_fuses_dot(const Plan &pl) {
 }
 int dot_part_count(const Plan &pl) { return pl.grid + pl.n_split_rows; }
 
-// y = A x; with w != NULL (MERGE plans only) also plan.dot_part[0 .. dot_part_count) = shares of w.y
-int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const double *w = nullptr) {
+// y = A x; with w != NULL (MERGE plans only) also plan.dot_part[0 .. dot_part_count) = shares of w.y.
+// pass != NULL (MERGE plans with the dot epilogue only): a solver pass -- operand composed on the fly, see
+// SolverPass; `want_dot` then says whether the shares of the dot are wanted.
+int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const double *w = nullptr,
+                const SolverPass *pass = nullptr, bool want_dot = false) {
   Plan &pl = m.plan;
-  if (w) {
+  if (w || pass) {
     if (!plan_fuses_dot(pl)) return fail(CASK_HIP_ERR_INVALID, "this design point has no fused dot epilogue");
   }
-  const DotEpilogue dot{w, w ? pl.dot_part.p : nullptr};
+  const DotEpilogue dot{w, (w || (pass && want_dot)) ? pl.dot_part.p : nullptr};
   if (m.n_rows == 0 || (pl.grid == 0 && pl.n_long_blocks == 0)) return CASK_HIP_OK;
   if (pl.prm.variant == CASK_HIP_VARIANT_MERGE_WAVE) {
     switch (pl.prm.items_per_thread) {
@@ -711,10 +723,10 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
     }
   } else {
     switch (pl.prm.items_per_thread) {
-      case 2:  launch_merge_i<2>(m, x, y, s, dot); break;
-      case 4:  launch_merge_i<4>(m, x, y, s, dot); break;
-      case 8:  launch_merge_i<8>(m, x, y, s, dot); break;
-      default: launch_merge_i<16>(m, x, y, s, dot); break;
+      case 2:  launch_merge_i<2>(m, x, y, s, dot, pass); break;
+      case 4:  launch_merge_i<4>(m, x, y, s, dot, pass); break;
+      case 8:  launch_merge_i<8>(m, x, y, s, dot, pass); break;
+      default: launch_merge_i<16>(m, x, y, s, dot, pass); break;
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1240,33 +1252,159 @@ static int solver_common_checks(cask_hip_matrix *m, const double *rhs, double *x
   return CASK_HIP_OK;
 }
 
-int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
-                int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
-  int rc = solver_common_checks(m, rhs, x, maxiters, tol);
-  if (rc) return rc;
+// ---- CG / BiCG on device vectors, single GPU or one rank of a row-sharded solve -------------------------------
+// Composed mode (MERGE plans): a pass is the product launch(es) -- which compose the direction p = r + beta p_old
+// while staging their x windows, store it for the rows they own, apply the solution update the previous pass owes
+// and leave the shares of p.Ap behind (SolverPass) -- plus ONE update launch (r -= alpha Ap and the shares of
+// r.r): 2 launches per CG pass, 3 per BiCG pass.  Classic mode (any plan; sharded: with an operand-exchange
+// callback): product, x/r update, p update as separate launches.  Row-sharded: the partial sums are added to
+// one scalar per rank and all-reduced through the caller's callback between the launches; those collectives are
+// also what orders a rank's stores to its vector slices against the peers' in-kernel halo loads.
+namespace {
+
+struct SolveSetup {
+  cask_hip_matrix *A = nullptr, *At = nullptr;
+  int kind = CASK_HIP_SOLVER_CG;
+  bool composed = false, sharded = false;
+  cask_hip_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  cask_hip_exchange_fn exchange = nullptr;
+  void *exchange_user = nullptr;
+  int64_t n = 0, S = 0, n_full = 0;
+  int sys_scope = 0;
+};
+
+// vector slots of the (shared or private) allocation, `S` doubles apart
+enum { SLOT_R = 0, SLOT_P0 = 1, SLOT_P1 = 2, SLOT_RT = 3, SLOT_PT0 = 4, SLOT_PT1 = 5 };
+// device scalars
+enum { SC_RS0 = 0, SC_RS1 = 1, SC_ALPHA = 2, SC_DOT = 4, SC_RR = 5, SC_RHO = 6, SC_COUNT = 8 };
+
+int run_allreduce(const SolveSetup &st, double *d, int count, hipStream_t s) {
+  if (!st.allreduce) return CASK_HIP_OK;
+  if (st.allreduce(d, count, s, st.allreduce_user) != 0)
+    return fail(CASK_HIP_ERR_RUNTIME, "the all-reduce callback of the sharded solver failed");
+  return CASK_HIP_OK;
+}
+
+}  // namespace
+
+int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask_hip_solver_config *cfg_in,
+                          const double *d_rhs, double *d_x, int32_t maxiters, double tol, int32_t *iterations,
+                          int32_t *converged, double *usec_per_iteration, void *stream) {
+  if (!m || !d_rhs || !d_x) return fail(CASK_HIP_ERR_INVALID, "NULL argument");
+  if (maxiters < 0 || !(tol >= 0)) return fail(CASK_HIP_ERR_INVALID, "bad maxiters/tol");
+  cask_hip_solver_config cfg{};
+  if (cfg_in) cfg = *cfg_in;
+  if (cfg.kind == 0) cfg.kind = CASK_HIP_SOLVER_CG;
+  if (cfg.kind != CASK_HIP_SOLVER_CG && cfg.kind != CASK_HIP_SOLVER_BICG)
+    return fail(CASK_HIP_ERR_INVALID, "unknown solver kind");
   HIP_TRY(hipSetDevice(m->device));
-  const int64_t n = m->n_rows;
-  hipStream_t s = m->stream;
-  DevBuf<double> dx, db, r, p, Ap, partials, partials_rr, scal;
+  SolveSetup st;
+  st.A = m;
+  st.kind = cfg.kind;
+  st.allreduce = cfg.allreduce;
+  st.allreduce_user = cfg.allreduce_user;
+  st.exchange = cfg.exchange;
+  st.exchange_user = cfg.exchange_user;
+  st.sharded = cfg.allreduce != nullptr;
+  st.n = m->n_rows;
+  const bool bicg = cfg.kind == CASK_HIP_SOLVER_BICG;
+  const bool has_halo = m->halo_addr != nullptr;
+  // the operand of a product: n_rows own entries (+ halo columns behind them, or the gathered vector)
+  if (!has_halo && !st.exchange && m->n_rows != m->n_cols) return fail(CASK_HIP_ERR_INVALID, "solver needs a square matrix");
+  if (has_halo && m->halo_n_own != m->n_rows)
+    return fail(CASK_HIP_ERR_INVALID, "a sharded solver block owns as many columns as rows");
+  if (st.exchange && (cfg.n_full < m->n_cols)) return fail(CASK_HIP_ERR_INVALID, "n_full must cover the block's columns");
+  if (bicg) {
+    if (mt_in) {
+      st.At = mt_in;
+    } else {
+      if (has_halo || st.exchange) return fail(CASK_HIP_ERR_INVALID, "a sharded BiCG needs the row block of A^T");
+      int rc = ensure_transpose(m);
+      if (rc) return rc;
+      st.At = m->transpose.get();
+    }
+    if (st.At->n_rows != m->n_rows) return fail(CASK_HIP_ERR_INVALID, "A and A^T blocks differ in their row count");
+  }
+  const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange;
+  if (cfg.mode == CASK_HIP_SOLVER_COMPOSED && !can_compose)
+    return fail(CASK_HIP_ERR_INVALID, "composed passes need MERGE plans with the dot epilogue (and no exchange callback)");
+  st.composed = cfg.mode == CASK_HIP_SOLVER_CLASSIC ? false : can_compose;
+  const int64_t n = st.n;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_slots = bicg ? 6 : 3;
+  // vectors peers may read live in the caller's shared allocation, `stride` doubles per slot
+  DevBuf<double> own_vec;
+  double *base = cfg.d_shared_base;
+  st.S = cfg.stride;
+  if (!base) {
+    st.S = (n + 31) / 32 * 32;
+    if (st.S == 0) st.S = 32;
+    HIP_TRY(own_vec.alloc((size_t)(st.S * n_slots)));
+    base = own_vec.p;
+  } else {
+    if (st.S < n || (st.S & 1)) return fail(CASK_HIP_ERR_INVALID, "stride must be even and at least the block's row count");
+    if (reinterpret_cast<uintptr_t>(base) & 15) return fail(CASK_HIP_ERR_INVALID, "shared base must be 16-byte aligned");
+    st.sys_scope = 1;
+  }
+  auto slot = [&](int k) { return base + (int64_t)k * st.S; };
+  double *r = slot(SLOT_R), *rt = bicg ? slot(SLOT_RT) : nullptr;
+  DevBuf<double> q, qt, part_a, part_b, part_c, scal, x_full, x_full_t;
   DevBuf<int> flags;
-  HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
-  HIP_TRY(r.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
-  HIP_TRY(partials.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(partials_rr.alloc(BLAS_MAX_PARTIALS));
-  HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(q.alloc(n));
+  if (bicg) HIP_TRY(qt.alloc(n));
+  HIP_TRY(part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_b.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_c.alloc(BLAS_MAX_PARTIALS));
+  HIP_TRY(scal.alloc(SC_COUNT)); HIP_TRY(flags.alloc(2));
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  double *rs[2] = {scal.p, scal.p + 1};
+  HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
+  if (st.exchange) {
+    HIP_TRY(x_full.alloc((size_t)cfg.n_full));
+    if (bicg) HIP_TRY(x_full_t.alloc((size_t)cfg.n_full));
+  }
   int *done = flags.p, *iters = flags.p + 1;
   const int g = blas_grid(n);
   const dim3 bg(g), bw(BLAS_WG);
-  // r = b - A x ; p = r ; rsold = r.r      (SparseLinearSolvers.hpp:189-198)
-  rc = launch_spmv(*m, dx.p, r.p, s);
+  const double tol2 = tol * tol;
+  int rc;
+
+  // the product y = Op * v for a vector v in slot k (or, classic sharded mode, gathered through the callback)
+  auto product = [&](cask_hip_matrix *op, int k, double *y, const double *w, DevBuf<double> &full) -> int {
+    const double *operand = slot(k);
+    if (st.exchange) {
+      if (st.exchange(slot(k), full.p, s, st.exchange_user) != 0)
+        return fail(CASK_HIP_ERR_RUNTIME, "the operand-exchange callback of the sharded solver failed");
+      operand = full.p;
+    }
+    op->halo_shift = (int64_t)k * st.S * 8;
+    const int rc2 = launch_spmv(*op, operand, y, s, w);
+    op->halo_shift = 0;
+    return rc2;
+  };
+
+  // ---- r = b - A x0 ; p = r ; rsold = r.r   (SparseLinearSolvers.hpp:189-198); BiCG: rt = r, rho = rt.r
+  // x0 travels through slot P1 (peers read it there); in composed mode that slot is pass 0's "old direction",
+  // which beta = 0 wipes out, so any finite content does.
+  HIP_TRY(hipMemcpyAsync(slot(SLOT_P1), d_x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (bicg) HIP_TRY(hipMemcpyAsync(slot(SLOT_PT1), d_x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (st.sharded && !st.exchange) {                           // every rank's x0 is in place before anyone's halo loads
+    rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
+    if (rc) return rc;
+  }
+  rc = product(m, SLOT_P1, q.p, nullptr, x_full);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
-                     r.p, (const int *)nullptr);
-  HIP_TRY(hipMemcpyAsync(p.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, r.p, partials.p, (const int *)nullptr);
-  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+  HIP_TRY(hipMemcpyAsync(r, d_rhs, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, -1.0, q.p, 1.0, 1.0, (const double *)nullptr, (const double *)nullptr, r,
+                     (const int *)nullptr);                   // r = -q + r
+  if (bicg) HIP_TRY(hipMemcpyAsync(rt, r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r, r, part_a.p, (const int *)nullptr);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, scal.p + SC_RS0, 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
+  rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r is final before the first pass
+  if (rc) return rc;
+  if (!st.composed) {                                         // classic passes keep p (and pt) materialised in slot P0
+    HIP_TRY(hipMemcpyAsync(slot(SLOT_P0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (bicg) HIP_TRY(hipMemcpyAsync(slot(SLOT_PT0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
 
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -1275,28 +1413,135 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   int h_flags[2] = {0, 0};
   int launched = 0;
   double clean_us = 0.0;
-  const bool fused = plan_fuses_dot(m->plan);
-  SolverLoadPolicy load_policy(m, nullptr, 5);
-  for (int i = 0; i < maxiters; i++) {
-    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
-    // Ap = A p (:206); with a MERGE plan the shares of p.Ap fall out of the same launch
-    const double *pAp_part = partials.p;
-    int n_pAp = g;
-    if (fused) {
-      rc = launch_spmv(*m, p.p, Ap.p, s, p.p);
-      pAp_part = m->plan.dot_part.p;
-      n_pAp = dot_part_count(m->plan);
+  SolverLoadPolicy load_policy(m, bicg ? st.At : nullptr, bicg ? 8 : 5);
+  double *rs[2] = {scal.p + SC_RS0, scal.p + SC_RS1};
+
+  // scalars of the previous pass as the composed product launches consume them
+  auto fill_pass = [&](SolverPass &sp, int iter, int p_slot0, int a_slot) {
+    const int old_slot = p_slot0 + ((iter & 1) ^ 1), new_slot = p_slot0 + (iter & 1);
+    sp = SolverPass{};
+    sp.b_off = (int64_t)(old_slot - a_slot) * st.S;
+    sp.b_new = slot(new_slot);
+    sp.den = rs[(iter + 1) & 1];
+    sp.num_out = rs[iter & 1];
+    sp.alpha_prev = scal.p + SC_ALPHA;
+    sp.done = done;
+    sp.iters = iters;
+    sp.tol2 = tol2;
+    sp.iter = iter;
+    sp.first = iter == 0;
+    sp.sys_scope = st.sys_scope;
+    if (st.sharded) {                                         // all-reduced scalars
+      sp.part_chk = scal.p + SC_RR;
+      sp.n_chk = 0;
+      sp.part_num = bicg ? scal.p + SC_RHO : sp.part_chk;
+      sp.n_num = 0;
     } else {
-      rc = launch_spmv(*m, p.p, Ap.p, s);
-      hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
+      sp.part_chk = part_a.p;
+      sp.n_chk = g;
+      sp.part_num = bicg ? part_b.p : part_a.p;
+      sp.n_num = g;
     }
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rr.p,
-                       (const int *)done);                                              // :208-218
-    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rr.p, g, rsold, rsnew, tol * tol, i, r.p, p.p, done,
-                       iters);                                                          // :220-231
+  };
+  // product launches of pass `iter` (final_only != 0: only the test / the owed solution update)
+  auto composed_products = [&](int iter, int final_only) -> int {
+    SolverPass sp;
+    int rc2;
+    if (bicg) {
+      fill_pass(sp, iter, SLOT_PT0, SLOT_RT);                 // qt = A^T pt ; stores pt_new ; records nothing
+      sp.secondary = 1;
+      sp.final_only = final_only;
+      st.At->halo_shift = (int64_t)SLOT_RT * st.S * 8;
+      rc2 = final_only ? CASK_HIP_OK : launch_spmv(*st.At, rt, qt.p, s, nullptr, &sp, false);
+      st.At->halo_shift = 0;
+      if (rc2) return rc2;
+    }
+    fill_pass(sp, iter, SLOT_P0, SLOT_R);
+    sp.xsol = d_x;
+    sp.final_only = final_only;
+    if (bicg) sp.wa = slot(SLOT_PT0 + (iter & 1));            // pt_new, stored by the launch above
+    return launch_spmv(*m, r, q.p, s, nullptr, &sp, true);
+  };
+
+  for (int i = 0; i < maxiters; i++) {
+    const double *dot_part = part_c.p;
+    int n_dot = g;
+    if (st.composed) {
+      rc = composed_products(i, 0);
+      if (rc) return rc;
+      dot_part = m->plan.dot_part.p;
+      n_dot = dot_part_count(m->plan);
+    } else {
+      // classic: q = A p with the shares of p.q (pt.q) from the same launch when the plan has the epilogue
+      const bool fused = plan_fuses_dot(m->plan);
+      const double *w = bicg ? slot(SLOT_PT0) : slot(SLOT_P0);
+      rc = product(m, SLOT_P0, q.p, fused ? w : nullptr, x_full);
+      if (rc) return rc;
+      if (bicg) {
+        rc = product(st.At, SLOT_PT0, qt.p, nullptr, x_full_t);
+        if (rc) return rc;
+      }
+      if (fused) {
+        dot_part = m->plan.dot_part.p;
+        n_dot = dot_part_count(m->plan);
+      } else {
+        hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, w, q.p, part_c.p, (const int *)done);
+      }
+    }
+    if (st.sharded) {                                         // p.Ap (pt.q): this rank's share -> scalar -> all ranks
+      hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, dot_part, n_dot, scal.p + SC_DOT, (const double *)nullptr, 0,
+                         (double *)nullptr, (const int *)done);
+      rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
+      if (rc) return rc;
+      dot_part = scal.p + SC_DOT;
+      n_dot = 0;
+    }
+    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
+    if (st.composed) {
+      if (bicg)
+        hipLaunchKernelGGL(k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
+                           scal.p + SC_ALPHA, (const int *)done, st.sys_scope);
+      else
+        hipLaunchKernelGGL(k_cg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
+                           (const int *)done, st.sys_scope);
+    } else if (bicg) {
+      hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rsold, dot_part, n_dot, slot(SLOT_P0), q.p, qt.p, d_x, r, rt,
+                         part_a.p, part_b.p, (const int *)done);
+    } else {
+      hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, dot_part, n_dot, slot(SLOT_P0), q.p, d_x, r, part_a.p,
+                         (const int *)done);                                            // :208-218
+    }
+    const double *chk_part = part_a.p, *rho_part = part_b.p;
+    int n_chk = g;
+    if (st.sharded) {                                         // r.r (and rt.r): one collective
+      hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, part_a.p, g, scal.p + SC_RR,
+                         bicg ? (const double *)part_b.p : (const double *)nullptr, g, scal.p + SC_RHO, (const int *)done);
+      rc = run_allreduce(st, scal.p + SC_RR, bicg ? 2 : 1, s);
+      if (rc) return rc;
+      chk_part = scal.p + SC_RR;
+      rho_part = scal.p + SC_RHO;
+      n_chk = 0;
+    }
+    if (!st.composed) {
+      if (bicg)
+        hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, tol2, i, r, rt,
+                           slot(SLOT_P0), slot(SLOT_PT0), done, iters);
+      else
+        hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, tol2, i, r, slot(SLOT_P0), done,
+                           iters);                                                      // :220-231
+    }
+    if (!st.composed && st.sharded && !st.exchange) {
+      // classic passes with in-kernel halos: the p update above must be complete on every rank before any
+      // rank's next product reads it -- no collective sits between the two, so one is spent as a fence
+      rc = run_allreduce(st, scal.p + SC_COUNT - 1, 1, s);
+      if (rc) return rc;
+    }
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      if (st.composed) {                                      // the test of pass i belongs to the next product launch:
+        rc = composed_products(i + 1, i + 1 == maxiters ? 1 : 2);   // run it now, without the product
+        if (rc) return rc;
+      }
       HIP_TRY(hipEventRecord(e1, s));
       load_policy.record(launched, s);
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
@@ -1309,9 +1554,9 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
       clean_us = ms_so_far * 1e3 / launched;
     }
   }
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -1324,96 +1569,31 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
   return CASK_HIP_OK;
 }
 
-int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
-                  int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+static int solve_host(int kind, cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                      int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
   int rc = solver_common_checks(m, rhs, x, maxiters, tol);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(m->device));
-  rc = ensure_transpose(m);
-  if (rc) return rc;
-  cask_hip_matrix &mt = *m->transpose;
   const int64_t n = m->n_rows;
-  hipStream_t s = m->stream;
-  DevBuf<double> dx, db, r, rt, p, pt, q, qt, part_a, part_b, part_c, scal;
-  DevBuf<int> flags;
+  DevBuf<double> dx, db;
   HIP_TRY(dx.upload(x, n)); HIP_TRY(db.upload(rhs, n));
-  HIP_TRY(r.alloc(n)); HIP_TRY(rt.alloc(n)); HIP_TRY(p.alloc(n)); HIP_TRY(pt.alloc(n));
-  HIP_TRY(q.alloc(n)); HIP_TRY(qt.alloc(n));
-  HIP_TRY(part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_b.alloc(BLAS_MAX_PARTIALS));
-  HIP_TRY(part_c.alloc(BLAS_MAX_PARTIALS));
-  HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
-  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  double *rho[2] = {scal.p, scal.p + 1};
-  int *done = flags.p, *iters = flags.p + 1;
-  const int g = blas_grid(n);
-  const dim3 bg(g), bw(BLAS_WG);
-  rc = launch_spmv(*m, dx.p, r.p, s);
+  cask_hip_solver_config cfg{};
+  cfg.kind = kind;
+  if (const char *e = std::getenv("CASK_HIP_SOLVER_MODE")) cfg.mode = std::atoi(e);   // development A/B: 1 composed, 2 classic
+  rc = cask_hip_solve_device(m, nullptr, &cfg, db.p, dx.p, maxiters, tol, iterations, converged, usec_per_iteration, m->stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
-                     r.p, (const int *)nullptr);
-  HIP_TRY(hipMemcpyAsync(rt.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(p.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(pt.p, r.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, rt.p, r.p, part_a.p, (const int *)nullptr);
-  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, rho[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
-  HIP_TRY(hipGetLastError());
-
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, s));
-  const int check_every = 16;
-  int h_flags[2] = {0, 0};
-  int launched = 0;
-  double clean_us = 0.0;
-  const bool fused = plan_fuses_dot(m->plan);
-  SolverLoadPolicy load_policy(m, &mt, 8);
-  for (int i = 0; i < maxiters; i++) {
-    double *rho_old = rho[i & 1], *rho_new = rho[(i + 1) & 1];
-    // q = A p with the shares of pt.q from the same launch (MERGE plans); qt = A^T pt
-    const double *ptq_part = part_c.p;
-    int n_ptq = g;
-    if (fused) {
-      rc = launch_spmv(*m, p.p, q.p, s, pt.p);
-      ptq_part = m->plan.dot_part.p;
-      n_ptq = dot_part_count(m->plan);
-    } else {
-      rc = launch_spmv(*m, p.p, q.p, s);
-    }
-    if (rc) return rc;
-    rc = launch_spmv(mt, pt.p, qt.p, s);
-    if (rc) return rc;
-    if (!fused) hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, pt.p, q.p, part_c.p, (const int *)done);
-    hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rho_old, ptq_part, n_ptq, p.p, q.p, qt.p, dx.p, r.p, rt.p,
-                       part_a.p, part_b.p, (const int *)done);
-    hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, part_a.p, part_b.p, g, rho_old, rho_new, tol * tol, i, r.p,
-                       rt.p, p.p, pt.p, done, iters);
-    launched = i + 1;
-    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
-      HIP_TRY(hipEventRecord(e1, s));
-      load_policy.record(launched, s);
-      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      load_policy.decide(launched);
-      if (h_flags[0]) break;
-      // a checkpoint reached without convergence: every pass so far did real work
-      float ms_so_far = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
-      clean_us = ms_so_far * 1e3 / launched;
-    }
-  }
-  HIP_TRY(hipEventRecord(e1, s));
-  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (iterations) *iterations = h_flags[1];
-  if (converged) *converged = h_flags[0];
-  // passes launched after the converged one are no-ops: prefer the rate measured up to the last
-  // checkpoint that had not converged yet
-  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
+  HIP_TRY(hipMemcpy(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost));
   return CASK_HIP_OK;
+}
+
+int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+  return solve_host(CASK_HIP_SOLVER_CG, m, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+}
+
+int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
+                  int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
+  return solve_host(CASK_HIP_SOLVER_BICG, m, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
 }
 
 // Preconditioned CG, pcg<double, Precon> of the reference (SparseLinearSolvers.hpp:162-239) with the

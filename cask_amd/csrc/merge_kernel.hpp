@@ -20,7 +20,7 @@ namespace caskhip {
 // (power-law blocks: a 500-nonzero row among 3-nonzero rows would otherwise keep one lane busy for
 // microseconds while 255 idle).  The host flags such blocks (KIND_SKEW); others pay one compare.
 
-template <int G, bool EXT>
+template <int G, int EXT>
 __device__ __forceinline__ double reduce_rows_plain(const BlockDesc &d, const double *prod, const int *roff,
                                                     double *__restrict__ y, const double *w) {
   const int tid = threadIdx.x;
@@ -44,7 +44,7 @@ __device__ __forceinline__ double reduce_rows_plain(const BlockDesc &d, const do
   return dsum;
 }
 
-template <int G, bool SKEW, bool EXT>
+template <int G, bool SKEW, int EXT>
 __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *prod, const int *roff,
                                               double *__restrict__ y, const double *w) {
   const bool skew = SKEW && (d.kind_g & KIND_SKEW);           // workgroup-uniform
@@ -128,17 +128,86 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
 // fetches the address-table entries of its window first, issues its stream like any block, then the
 // window loads themselves -- some of them remote: one local and one xGMI round trip, overlapped with
 // the stream.  A separate instantiation, so the code of every other block is exactly the one above.
+// Halo entries live in a peer GPU's memory and change between products of a solver: they are read with
+// system-scope loads (sc0 sc1: served by the owner's memory, never by a line this GPU's L2 kept from the
+// previous product), the owner writes them through at system scope (SolverPass::sys_scope, blas1 kernels) and
+// a collective orders the two -- see DESIGN.md section 7 for the whole argument.
 typedef __attribute__((address_space(1))) const double gdouble;
-__device__ __forceinline__ double load_at(uint64_t addr) { return *reinterpret_cast<gdouble *>(addr); }
+__device__ __forceinline__ double load_at(uint64_t addr) {
+  return __hip_atomic_load(reinterpret_cast<gdouble *>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_own(double *p, double v, int sys_scope) {
+  if (sys_scope) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else *p = v;
+}
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, bool EXT>
+// The SolverPass travels only with the kernels that use it.
+template <int EXT> struct PassArg {};
+template <> struct PassArg<2> { SolverPass sp; };
+template <int EXT> __device__ __forceinline__ SolverPass pass_of(const PassArg<EXT> &) { return SolverPass{}; }
+template <> __device__ __forceinline__ SolverPass pass_of<2>(const PassArg<2> &a) { return a.sp; }
+
+// What a solver pass (EXT == 2) knows once the scalars of the previous pass are summed.
+struct PassScalars {
+  double beta, alpha_prev;
+  bool stop;                 // converged in the previous pass, or a final_only launch: no product
+  bool update_x;             // the solution update of the previous pass is still owed
+};
+
+// Every workgroup derives the same scalars from the same partial sums (fixed order => identical bits), so every
+// workgroup takes the same decision; workgroup 0 records it.  `red` = 16 doubles of LDS.
+__device__ __forceinline__ PassScalars pass_scalars(const SolverPass &sp, int lb, double *red) {
+  PassScalars ps;
+  ps.beta = 0.0;
+  ps.alpha_prev = 0.0;
+  ps.stop = false;
+  ps.update_x = false;
+  if (sp.first) return ps;
+  const double chk = partials_or_scalar(sp.part_chk, sp.n_chk, red);
+  ps.alpha_prev = *sp.alpha_prev;
+  ps.update_x = sp.xsol != nullptr;
+  if (chk <= sp.tol2) {                                       // SparseLinearSolvers.hpp:220-226: nothing after the test
+    if (lb == 0 && threadIdx.x == 0 && !sp.secondary) {
+      if (sp.part_num == sp.part_chk && sp.num_out) *sp.num_out = chk;
+      *sp.done = 1;
+    }
+    ps.stop = true;
+    return ps;
+  }
+  const double num = sp.part_num == sp.part_chk ? chk : partials_or_scalar(sp.part_num, sp.n_num, red);
+  ps.beta = num / *sp.den;
+  if (lb == 0 && threadIdx.x == 0 && !sp.secondary) {
+    if (sp.num_out) *sp.num_out = num;
+    *sp.iters = sp.iter - 1;                                  // :231, the previous pass did not converge
+  }
+  ps.stop = sp.final_only != 0;                               // 1: the solve ends here (the update is still applied);
+  if (sp.final_only == 2) ps.update_x = false;                // 2: a probe at a checkpoint -- the next pass applies it
+  return ps;
+}
+
+// Own-row work of a solver pass for the rows [row0, row0 + n) of a piece that does not go through merge_load
+// (long-row pieces, zero-fill pieces, and every block when the pass stops): the solution update the previous
+// pass owes and, unless the pass stops, the new direction.  Returns nothing; w for long rows is recomputed.
+__device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassScalars &ps, const double *a, int row0,
+                                              int n, bool store_dir) {
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const int row = row0 + r;
+    const double bv = a[row + sp.b_off];
+    if (ps.update_x) sp.xsol[row] = fma(ps.alpha_prev, bv, sp.xsol[row]);
+    if (store_dir && sp.b_new) store_own(sp.b_new + row, fma(ps.beta, bv, a[row]), sp.sys_scope);
+  }
+}
+
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
                                            double *prod, int *roff, double *xs, const XHalo &halo,
-                                           const double *__restrict__ w, double *wl, int lb) {
+                                           const double *__restrict__ w, double *wl, int lb,
+                                           const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
+  constexpr bool COMP = EXT == 2;                             // operand composed on the fly: x[c] + beta * x[c + b_off]
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -157,6 +226,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   // the special case of consecutive chunks; stencil-like matrices (a few narrow bands far apart)
   // fit the same way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
   double xw[XU > 0 ? XU : 1];
+  double xb[(COMP && XU > 0) ? XU : 1];                       // COMP: the same entries of the second operand
   uint64_t xsrc[XU > 0 ? XU : 1];
   if (XU > 0) {
     if (SEAM) {
@@ -182,17 +252,31 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
       const int plim = xlim >> 1;
 #pragma unroll
       for (int u = 0; u < XU / 2; u++) {
-        const dbl2 pr = x2[min((d.cmin >> 1) + u * WG + tid, plim)];
+        const int pi = min((d.cmin >> 1) + u * WG + tid, plim);
+        const dbl2 pr = x2[pi];
         xw[2 * u] = pr.x;
         xw[2 * u + 1] = pr.y;
+        if (COMP) {                                           // b_off is even (16-byte aligned operands)
+          const dbl2 pb = x2[pi + (sp.b_off >> 1)];
+          xb[COMP ? 2 * u : 0] = pb.x;
+          xb[COMP ? 2 * u + 1 : 0] = pb.y;
+        }
       }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
 #pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, xlim)];
+      for (int u = 0; u < XU; u++) {
+        const int c = min(xchunk[u * wpw + wave] + lane, xlim);
+        xw[u] = x[c];
+        if (COMP) xb[COMP ? u : 0] = x[c + sp.b_off];
+      }
     } else {                                                  // one window: no chunk table on the critical path
 #pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, xlim)];
+      for (int u = 0; u < XU; u++) {
+        const int c = min(d.cmin + u * WG + tid, xlim);
+        xw[u] = x[c];
+        if (COMP) xb[COMP ? u : 0] = x[c + sp.b_off];
+      }
     }
   }
   const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
@@ -225,14 +309,43 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   }
   if (XU > 0 && SEAM) {
 #pragma unroll
-    for (int u = 0; u < XU; u++) xw[u] = load_at(xsrc[u]);
+    for (int u = 0; u < XU; u++) {
+      xw[u] = load_at(xsrc[u]);
+      if (COMP) xb[COMP ? u : 0] = load_at(xsrc[u] + 8 * (uint64_t)sp.b_off);
+    }
   }
   // dot epilogue (EXT kernels, launch-uniform test): the block's slice of w, requested behind the stream
   // (youngest loads: nothing waits for them until the products are stored), parked in LDS for the row sums
   double w0 = 0.0, w1 = 0.0;
-  if (EXT && w) {
+  if (EXT == 1 && w) {
     w0 = w[d.row_start + min(tid, d.n_rows - 1)];
     w1 = w[d.row_start + min(tid + WG, d.n_rows - 1)];
+  }
+  // solver pass: the rows this block owns (tid and tid + WG; a block has < 2*WG rows) -- new direction, the
+  // solution update the previous pass owes, and the dot operand
+  const int orow0 = d.row_start + min(tid, d.n_rows - 1), orow1 = d.row_start + min(tid + WG, d.n_rows - 1);
+  if (COMP) {
+    const double a0 = x[orow0], a1 = x[orow1], b0 = x[orow0 + sp.b_off], b1 = x[orow1 + sp.b_off];
+    double s0 = 0.0, s1 = 0.0, wa0 = 0.0, wa1 = 0.0, wb0 = 0.0, wb1 = 0.0;
+    if (ps.update_x) {
+      s0 = sp.xsol[orow0];
+      s1 = sp.xsol[orow1];
+    }
+    if (sp.wa) {                                              // launch-uniform
+      wa0 = sp.wa[orow0]; wa1 = sp.wa[orow1];
+      if (sp.wb) { wb0 = sp.wb[orow0]; wb1 = sp.wb[orow1]; }
+    }
+    const double n0 = fma(ps.beta, b0, a0), n1 = fma(ps.beta, b1, a1);
+    if (sp.b_new) {
+      if (tid < d.n_rows) store_own(sp.b_new + orow0, n0, sp.sys_scope);
+      if (tid + WG < d.n_rows) store_own(sp.b_new + orow1, n1, sp.sys_scope);
+    }
+    if (ps.update_x) {
+      if (tid < d.n_rows) sp.xsol[orow0] = fma(ps.alpha_prev, b0, s0);
+      if (tid + WG < d.n_rows) sp.xsol[orow1] = fma(ps.alpha_prev, b1, s1);
+    }
+    w0 = sp.wa ? (sp.wb ? fma(ps.beta, wb0, wa0) : wa0) : n0;
+    w1 = sp.wa ? (sp.wb ? fma(ps.beta, wb1, wa1) : wa1) : n1;
   }
 
   CASK_STAMP(1);
@@ -241,13 +354,13 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
 #pragma unroll
     for (int u = 0; u < XU / 2; u++) {
       dbl2 pr;
-      pr.x = xw[2 * u];
-      pr.y = xw[2 * u + 1];
+      pr.x = COMP ? fma(ps.beta, xb[COMP ? 2 * u : 0], xw[2 * u]) : xw[2 * u];
+      pr.y = COMP ? fma(ps.beta, xb[COMP ? 2 * u + 1 : 0], xw[2 * u + 1]) : xw[2 * u + 1];
       xs2[u * WG + tid] = pr;
     }
   } else if (XU > 0) {
 #pragma unroll
-    for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
+    for (int u = 0; u < XU; u++) xs[u * WG + tid] = COMP ? fma(ps.beta, xb[COMP ? u : 0], xw[u]) : xw[u];
   }
   roff[tid] = ro0;
   roff[tid + WG] = ro1;
@@ -301,14 +414,36 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
     }
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
-      xv[u].x = load_at(halo_source(x, c[u].x, ex[u], halo));
-      xv[u].y = load_at(halo_source(x, c[u].y, ey[u], halo));
+      ex[u] = halo_source(x, c[u].x, ex[u], halo);
+      ey[u] = halo_source(x, c[u].y, ey[u], halo);
+      xv[u].x = load_at(ex[u]);
+      xv[u].y = load_at(ey[u]);
+    }
+    if (COMP) {
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++) {
+        xv[u].x = fma(ps.beta, load_at(ex[u] + 8 * (uint64_t)sp.b_off), xv[u].x);
+        xv[u].y = fma(ps.beta, load_at(ey[u] + 8 * (uint64_t)sp.b_off), xv[u].y);
+      }
     }
   } else {
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
       xv[u].x = x[c[u].x];
       xv[u].y = x[c[u].y];
+    }
+    if (COMP) {
+      dbl2 xq[IPT / 2];
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++) {
+        xq[u].x = x[c[u].x + sp.b_off];
+        xq[u].y = x[c[u].y + sp.b_off];
+      }
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++) {
+        xv[u].x = fma(ps.beta, xq[u].x, xv[u].x);
+        xv[u].y = fma(ps.beta, xq[u].y, xv[u].y);
+      }
     }
   }
   // every lane stores: lanes past the last pair hold a duplicate of it and land
@@ -320,7 +455,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
 #endif
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
-  if (EXT && w) {
+  if ((EXT == 1 && w) || (COMP && w)) {                       // COMP: w != NULL means "leave the dot shares behind"
     wl[tid] = w0;
     wl[tid + WG] = w1;
   }
@@ -328,28 +463,32 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, bool EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs,
-                                            const XHalo &halo, const DotEpilogue &dot, int lb) {
+                                            const XHalo &halo, const DotEpilogue &dot, int lb,
+                                            const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
   // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
   // slower (8.75 -> 8.88 us per launch in an interleaved A/B) although the occupancy calculator still
   // reports 6 workgroups per CU for 26 896 bytes (tools/lds_granule.hip); the cause was not established.
   double *wl = xs + XU * WG, *dot_red = wl + 2 * WG;
+  // the dot operand: EXT == 1 a vector (dot.w); a solver pass composes it (dot.dot_part != NULL asks for the shares)
+  const bool want_dot = EXT == 2 ? dot.dot_part != nullptr : (EXT == 1 && dot.w != nullptr);   // launch-uniform
+  const double *wsrc = EXT == 2 ? (want_dot ? x : nullptr) : dot.w;
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
     merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                            halo, dot.w, wl, lb);
+                                            halo, wsrc, wl, lb, sp, ps);
   else
     merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                             halo, dot.w, wl, lb);
-  const double *wrow = EXT && dot.w ? wl : nullptr;           // w[row_start + r] sits in wl[r]
+                                             halo, wsrc, wl, lb, sp, ps);
+  const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
 
   double dsum;
   switch (d.kind_g & 0xff) {
@@ -361,7 +500,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
     case 32: dsum = reduce_rows<32, SKEW, EXT>(d, prod, roff, y, wrow); break;
     default: dsum = reduce_rows<64, SKEW, EXT>(d, prod, roff, y, wrow); break;
   }
-  if (EXT && dot.w) {                                         // launch-uniform: the block's share of w.y
+  if (EXT && want_dot) {                                      // launch-uniform: the block's share of w.y
     dsum = group_sum<64>(dsum);
     if ((tid & 63) == 0) dot_red[tid >> 6] = dsum;
     __syncthreads();
@@ -375,15 +514,18 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 
 // SKEW: the plan holds blocks flagged KIND_SKEW (matrices without any run the instantiation that
 // carries no second-pass code at all: 0.13 us per launch on cant).
-// EXT: the launch may carry halo sources and/or a dot epilogue.  Ordinary products run the EXT = false
-// instantiation, which contains none of that code: a kernel this close to the memory system's limits
-// pays for every extra branch, register and byte of LDS (measured while adding them: +1 to +6 %).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, bool EXT>
+// EXT: 0 = the lean kernel of ordinary products; 1 = the launch may carry halo sources and/or a dot epilogue;
+// 2 = a solver pass (SolverPass: composed operand, own-row updates, scalars from partial sums) with or without
+// halo sources.  Ordinary products run EXT = 0, which contains none of that code: a kernel this close to the
+// memory system's limits pays for every extra branch, register and byte of LDS (measured while adding them:
+// +1 to +6 %).
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
-                             double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot) {
+                             double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
+                             PassArg<EXT> pass_arg) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
@@ -396,10 +538,26 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const BlockDesc d = blocks[lb];
   const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
 
+  const SolverPass sp = pass_of(pass_arg);                    // EXT < 2: all zeros, every use folds away
+  PassScalars ps{0.0, 0.0, false, false};
+  if (EXT == 2) {
+    if (*sp.done) return;                                     // a pass after the converged one: nothing happens
+    ps = pass_scalars(sp, lb, prod);                          // LDS not in use yet
+    __syncthreads();
+    if (ps.stop) {                                            // workgroup-uniform (and the same in every workgroup)
+      // converged in the previous pass (or a final_only launch): the solution update that pass owes, nothing else.
+      // A split long row is owned by its first piece.
+      if (ps.update_x && (!(d.kind_g & KIND_LONG) || d.nnz_count == 0 || d.nnz_start == rp[d.row_start]))
+        pass_own_rows(sp, ps, x, d.row_start, d.n_rows, false);
+      return;
+    }
+  }
+
   if (d.kind_g & KIND_LONG) {
     if (d.nnz_count == 0) {                                   // a run of empty rows (planner: zero-fill piece)
       for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = 0.0;
-      if (EXT && dot.w && tid == 0) dot.dot_part[lb] = 0.0;
+      if (EXT == 2) pass_own_rows(sp, ps, x, d.row_start, d.n_rows, true);
+      if (EXT && dot.dot_part && (EXT == 2 || dot.w) && tid == 0) dot.dot_part[lb] = 0.0;
       return;
     }
     // One piece of one long row: the whole workgroup strides over it.
@@ -419,10 +577,21 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 #pragma unroll
         for (int u = 0; u < 4; u++) ent[u] = halo_entry(c[u], halo);
 #pragma unroll
-        for (int u = 0; u < 4; u++) xv[u] = load_at(halo_source(x, c[u], ent[u], halo));
+        for (int u = 0; u < 4; u++) {
+          ent[u] = halo_source(x, c[u], ent[u], halo);
+          xv[u] = load_at(ent[u]);
+        }
+        if (EXT == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) xv[u] = fma(ps.beta, load_at(ent[u] + 8 * (uint64_t)sp.b_off), xv[u]);
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+        if (EXT == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) xv[u] = fma(ps.beta, x[c[u] + sp.b_off], xv[u]);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
@@ -431,15 +600,28 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
     acc = group_sum<64>(acc);
     if ((tid & 63) == 0) prod[tid >> 6] = acc;
     __syncthreads();
+    // solver pass: the row's own entries (its first piece owns them) and its dot operand
+    const bool owner = EXT == 2 && d.nnz_start == rp[d.row_start];
+    double wrow = 0.0;
+    if (EXT == 2 && tid == 0) {
+      const int row = d.row_start;
+      const double bv = x[row + sp.b_off], nv = fma(ps.beta, bv, x[row]);
+      if (owner) {
+        if (ps.update_x) sp.xsol[row] = fma(ps.alpha_prev, bv, sp.xsol[row]);
+        if (sp.b_new) store_own(sp.b_new + row, nv, sp.sys_scope);
+      }
+      wrow = sp.wa ? (sp.wb ? fma(ps.beta, sp.wb[row], sp.wa[row]) : sp.wa[row]) : nv;
+    }
     if (tid == 0) {
       double s = 0.0;
       for (int w = 0; w < (WG >> 6); w++) s += prod[w];
       if (d.kind_g & KIND_PARTIAL) {
         partials[d.aux] = s;
-        if (EXT && dot.w) dot.dot_part[lb] = 0.0;             // the fix-up kernel owns this row's share
+        if (EXT && dot.dot_part && (EXT == 2 || dot.w)) dot.dot_part[lb] = 0.0;   // the fix-up kernel owns this row's share
       } else {
         y[d.row_start] = s;
-        if (EXT && dot.w) dot.dot_part[lb] = dot.w[d.row_start] * s;
+        if (EXT == 2 && dot.dot_part) dot.dot_part[lb] = wrow * s;
+        if (EXT == 1 && dot.w) dot.dot_part[lb] = dot.w[d.row_start] * s;
       }
     }
     return;
@@ -451,10 +633,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
     merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                             xs, halo, dot, lb);
+                                             xs, halo, dot, lb, sp, ps);
   else
     merge_block<IPT, 0, NT, false, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                              xs, halo, dot, lb);
+                                              xs, halo, dot, lb, sp, ps);
   CASK_STAMP(5);
 }
 

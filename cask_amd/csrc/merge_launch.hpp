@@ -23,6 +23,8 @@ struct MergeLaunch {
   double *partials;                // long-row pieces
   XHalo halo;
   DotEpilogue dot;
+  bool solver_pass;                // EXT == 2 launch: `pass` describes the composed operand and the scalars
+  SolverPass pass;
 };
 
 template <int IPT>

@@ -9,16 +9,19 @@ namespace caskhip {
 template <int IPT, int XU>
 static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
   const dim3 grid(l.grid), block(l.wg_size);
-#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT)                                                              \
+#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, PASS)                                                        \
   hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>), grid, block, l.lds_bytes, s, l.blocks, \
                      l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, y,        \
-                     l.partials, l.halo, l.dot)
-  // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one
+                     l.partials, l.halo, l.dot, PASS)
+  // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one, a solver
+  // pass the one that composes its operand
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
-#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                        \
-  do {                                                                 \
-    if (ext) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, true);            \
-    else     CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, false);           \
+  const PassArg<2> pass2{l.pass};
+#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                                       \
+  do {                                                                                \
+    if (l.solver_pass) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, pass2);             \
+    else if (ext)      CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, PassArg<1>{});      \
+    else               CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 0, PassArg<0>{});      \
   } while (0)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = l.nontemporal || l.any_skew;

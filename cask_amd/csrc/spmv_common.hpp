@@ -59,12 +59,14 @@ struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
 struct XHalo {
   int n_own;
   const uint64_t *haddr;
+  int64_t shift;           // bytes added to every halo address: the table points at slot 0 of the peers' shared
+                           //   vector allocations, a product on the vector in slot k reads k*stride*8 further on
 };
 // Two steps so that a lane's loads stay batched: first the table entries of all its columns (entry 0
 // for own columns: harmless, one cached line), then the values from wherever they live.
 __device__ __forceinline__ uint64_t halo_entry(int col, const XHalo &h) { return h.haddr[max(col - h.n_own, 0)]; }
 __device__ __forceinline__ uint64_t halo_source(const double *x, int col, uint64_t entry, const XHalo &h) {
-  return col < h.n_own ? reinterpret_cast<uint64_t>(x + col) : entry;
+  return col < h.n_own ? reinterpret_cast<uint64_t>(x + col) : entry + (uint64_t)h.shift;
 }
 
 // Optional epilogue of the merge kernel: dot_part[block] = sum over the block's rows of
@@ -73,6 +75,39 @@ __device__ __forceinline__ uint64_t halo_source(const double *x, int col, uint64
 struct DotEpilogue {
   const double *w;
   double *dot_part;
+};
+
+// Solver pass (EXT == 2 instantiations of the merge kernel; cask_hip_cg / cask_hip_bicg and their sharded forms).
+// The reference's CG pass is  Ap = A p ; alpha = rsold/(p.Ap) ; x += alpha p ; r -= alpha Ap ; rsnew = r.r ;
+// p = r + (rsnew/rsold) p  (src/runtime/SparseLinearSolvers.hpp:206-229).  Two of those steps need a sum over
+// the whole vector before anything else can proceed (p.Ap and r.r), so a pass is at least two launches -- and it
+// is exactly two when the p update rides on the product: the product kernel composes its operand on the fly,
+//     x[c] = a[c] + beta * b[c]              (CG: a = r, b = p_old: the value IS p_new[c], same fma everywhere)
+// while staging its x window, stores b_new[row] = a[row] + beta*b[row] for the rows it owns (the next pass's
+// p_old; ping-pong buffers, so nobody's window sees a half-updated vector), applies the solution update the
+// previous pass still owes, xsol[row] += alpha_prev * b[row], and leaves the shares of w.y behind.  beta, the
+// convergence test and `iterations` come from the partial sums (or all-reduced scalars) the previous update
+// kernel left: every workgroup adds them in the same order and takes the same decision.
+struct SolverPass {
+  int64_t b_off;             // doubles from an entry of a (the kernel's x argument) to the same entry of b
+  double *b_new;             // own rows: b_new[row] = a[row] + beta*b[row]; NULL = not stored
+  double *xsol;              // own rows: xsol[row] += alpha_prev * b[row]; NULL = none
+  const double *wa, *wb;     // dot operand of own rows: wa[row] + beta*wb[row]; wa == NULL: the composed operand
+  const double *part_chk;    // convergence quantity (r.r): n_chk partial sums, or one scalar if n_chk == 0
+  const double *part_num;    // beta numerator: n_num partials / one scalar; may equal part_chk (CG)
+  const double *den;         // beta denominator (rsold / rho_old), one scalar
+  const double *alpha_prev;  // step length of the previous pass, one scalar
+  double *num_out;           // workgroup 0 records the numerator here (the next pass's denominator)
+  int *done, *iters;         // convergence flag / the reference's `iterations` (workgroup 0 writes)
+  double tol2;
+  int n_chk, n_num;
+  int iter;                  // index of this pass
+  int first;                 // pass 0: no test, beta = 0, no solution update
+  int final_only;            // no product.  1: end of the solve -- test, `iterations`, the owed solution update;
+                             //   2: probe at a host checkpoint -- the same, but the update only if converged
+  int sys_scope;             // b_new lives in a slice peers read: store it write-through at system scope
+  int secondary;             // second product of the same pass (BiCG's A^T): same scalars, records nothing, and
+                             //   leaves the convergence flag to the primary launch that follows it
 };
 
 // ---------------------------------------------------------------- cross-lane
@@ -108,6 +143,40 @@ __device__ __forceinline__ double group_sum(double v) {
   if (L >= 32) v += swap16_f64(v);       // ds_swizzle SWAP,16
   if (L >= 64) v = sum_halves_f64(v);    // v_permlane32_swap
   return v;
+}
+
+// Sum of an L2-resident partials array (the <= 1024 shares of a BLAS-1 reduction, or the per-block
+// shares the product kernel's dot epilogue leaves: a few thousand), computed redundantly by every
+// workgroup in the same order => every workgroup sees the bit-identical value.  This replaces a
+// separate single-workgroup "final" kernel (4.3 us + a launch boundary per dot in the first version).
+// The loads go out eight 16-byte pairs per lane at a time: one L2 round trip for up to 4096 shares with
+// 256 threads, not one per share.  Result in all threads.
+__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int n, double *red) {
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(partials);
+  const int n2 = n >> 1, tid = threadIdx.x, wg = blockDim.x;
+  double acc = 0.0;
+  for (int i0 = 0; i0 < n2; i0 += 8 * wg) {
+    dbl2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p2[min(i0 + u * wg + tid, n2 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u * wg + tid < n2) acc += v[u].x + v[u].y;
+  }
+  if ((n & 1) && tid == 0) acc += partials[n - 1];
+  acc = group_sum<64>(acc);
+  __syncthreads();                                  // red may still be read by a previous use
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+  return s;
+}
+
+// A reduced quantity arrives either as n > 0 partial sums (single GPU: every workgroup adds them itself) or,
+// n == 0, as one scalar (row-sharded solvers: the partials were summed and all-reduced between the launches).
+__device__ __forceinline__ double partials_or_scalar(const double *__restrict__ p, int n, double *red) {
+  return n > 0 ? sum_partials(p, n, red) : *p;
 }
 
 // Contiguous row blocks per XCD: hardware deals workgroups round-robin over the

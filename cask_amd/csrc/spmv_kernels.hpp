@@ -303,9 +303,10 @@ __global__ void k_spmv_long(const BlockDesc *__restrict__ blocks, int n_blocks,
 // Sums the pieces of rows that were split over several workgroups, in piece
 // order (deterministic; no float atomics anywhere in the engine).
 __global__ void k_spmv_fixup(const SplitRow *__restrict__ rows, int n, const double *__restrict__ partials,
-                             double *__restrict__ y, DotEpilogue dot) {
+                             double *__restrict__ y, DotEpilogue dot, const int *done) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (done && *done) return;                                  // solver pass after convergence: the product did not run
   const SplitRow r = rows[i];
   double s = 0.0;
   for (int k = 0; k < r.n_slots; k++) s += partials[r.first_slot + k];

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 2
+#define CASK_HIP_ABI_VERSION 3
 
 /* status codes */
 #define CASK_HIP_OK               0
@@ -198,6 +198,46 @@ int cask_hip_cg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxite
 /* Classical BiCG with A and A^T (BASELINE config 5). */
 int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxiters, double tol,
                   int32_t *iterations, int32_t *converged, double *usec_per_iteration);
+
+/* ---- CG / BiCG on device vectors; one rank of a row-sharded solve -------------------------------------
+ * The same recurrences as cask_hip_cg / cask_hip_bicg (pcg<double, IdentityPreconditioner>,
+ * SparseLinearSolvers.hpp:162-239; BiCG: the declared-only DfeBiCgSolver, :56-61) with device vectors on
+ * `stream`, plus what a rank of a row-sharded solve (BASELINE configs 3 and 5 on several GPUs) needs:
+ *   allreduce  sums `count` doubles at d_values over all ranks, in place, ordered on `stream` (RCCL
+ *              all-reduce of the dot products).  NULL = single rank.
+ *   exchange   classic mode only: gathers the operand slices of all ranks into d_full (RCCL all-gather
+ *              of x), for blocks stored with GLOBAL column indices.  NULL = the block reads its halo
+ *              itself (cask_hip_csr_set_halo_sources) or has none.
+ *   d_shared_base / stride   sharded, in-kernel halo: the vectors peers read (r, p, rt, pt) live in this
+ *              rank's shared allocation (cask_hip_shared_alloc), slot k at base + k*stride doubles; 3
+ *              slots for CG, 6 for BiCG; the halo tables of A and A^T point at slot 0 of the peers'
+ *              allocations (same stride on every rank).  NULL = private vectors.
+ * mode: composed = the product launch composes p = r + beta*p on the fly (2 launches per CG pass, 3 per
+ * BiCG pass; needs MERGE plans), classic = product, x/r update and p update are separate launches.
+ * d_x holds the initial guess and receives the solution (n_rows entries of this rank).  Every rank takes
+ * the same decisions from the same all-reduced scalars. */
+#define CASK_HIP_SOLVER_CG        1
+#define CASK_HIP_SOLVER_BICG      2
+#define CASK_HIP_SOLVER_AUTO      0
+#define CASK_HIP_SOLVER_COMPOSED  1
+#define CASK_HIP_SOLVER_CLASSIC   2
+typedef int (*cask_hip_allreduce_fn)(double *d_values, int32_t count, void *stream, void *user);
+typedef int (*cask_hip_exchange_fn)(const double *d_local, double *d_full, void *stream, void *user);
+typedef struct cask_hip_solver_config {
+  int32_t kind;                  /* CASK_HIP_SOLVER_CG (0 = CG) / _BICG */
+  int32_t mode;                  /* CASK_HIP_SOLVER_AUTO / _COMPOSED / _CLASSIC */
+  double *d_shared_base;
+  int64_t stride;
+  cask_hip_allreduce_fn allreduce;
+  void *allreduce_user;
+  cask_hip_exchange_fn exchange;
+  void *exchange_user;
+  int64_t n_full;                /* exchange: entries of the gathered operand */
+} cask_hip_solver_config;
+/* mt: the row block of A^T for a sharded BiCG; NULL = built from m (single rank). */
+int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt, const cask_hip_solver_config *cfg,
+                          const double *d_rhs, double *d_x, int32_t maxiters, double tol,
+                          int32_t *iterations, int32_t *converged, double *usec_per_iteration, void *stream);
 
 /* ---- preconditioning -------------------------------------------------------------
  * The reference's preconditioned CG, pcg<T, Precon> (src/runtime/SparseLinearSolvers.hpp:162-239),
