@@ -83,3 +83,8 @@ clean:
 build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip
+
+# ablation builds of the solver pass (development only): build/libcask_hip_abl<N>.so
+build/libcask_hip_abl%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DCASK_ABL=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip

@@ -57,7 +57,7 @@ class CsrInfo(Structure):
     _fields_ = [("n_rows", c_int32), ("n_cols", c_int32), ("nnz", c_int64), ("grid", c_int32),
                 ("lds_bytes", c_int32), ("n_long_rows", c_int32), ("n_split_rows", c_int32),
                 ("max_row_nnz", c_int32), ("empty_rows", c_int32), ("mean_row_nnz", c_double),
-                ("algorithmic_bytes", c_int64)]
+                ("algorithmic_bytes", c_int64), ("fuses_dot", c_int32), ("reserved", c_int32)]
 
 
 class DeviceProps(Structure):

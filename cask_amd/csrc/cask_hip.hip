@@ -978,6 +978,7 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out) {
   out->empty_rows = m->empty_rows;
   out->mean_row_nnz = m->n_rows ? (double)m->nnz / m->n_rows : 0.0;
   out->algorithmic_bytes = 12 * m->nnz + 4 * ((int64_t)m->n_rows + 1) + 8 * (int64_t)m->n_cols + 8 * (int64_t)m->n_rows;
+  out->fuses_dot = plan_fuses_dot(m->plan) ? 1 : 0;
   return CASK_HIP_OK;
 }
 
@@ -1329,7 +1330,18 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange;
   if (cfg.mode == CASK_HIP_SOLVER_COMPOSED && !can_compose)
     return fail(CASK_HIP_ERR_INVALID, "composed passes need MERGE plans with the dot epilogue (and no exchange callback)");
-  st.composed = cfg.mode == CASK_HIP_SOLVER_CLASSIC ? false : can_compose;
+  // AUTO: measured on one GPU (profiles/r02_solver_modes.txt) the composed pass LOSES to the classic one --
+  // G3_circuit-like CG 51.5 vs 46.7 us, atmosmodd-like BiCG 120 vs 80 us per pass: the bytes of the p update do
+  // not go away, they move into the product launch (own-row reads and writes +4.8 us, the second x window
+  // +2.2 us) and every workgroup pays for summing the previous launch's partials first (+4.6 us), which is more
+  // than the launch boundary saved.  A row-sharded solve with in-kernel halos is where it pays: the scalars
+  // arrive all-reduced (no sums), and the two all-reduces of a pass are the only cross-rank ordering it needs,
+  // whereas a classic pass needs a third collective as a fence behind its p update.
+  st.composed = cfg.mode == CASK_HIP_SOLVER_COMPOSED   ? true
+                : cfg.mode == CASK_HIP_SOLVER_CLASSIC ? false
+                                                      : (can_compose && st.sharded && cfg.d_shared_base != nullptr);
+  // (the ranks of a sharded solve must all take the same form: the caller agrees on `mode` collectively when
+  // their plans may differ -- cask_amd/dist.py does)
   const int64_t n = st.n;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_slots = bicg ? 6 : 3;
@@ -1399,12 +1411,12 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r, r, part_a.p, (const int *)nullptr);
   hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, scal.p + SC_RS0, 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
-  rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r is final before the first pass
-  if (rc) return rc;
   if (!st.composed) {                                         // classic passes keep p (and pt) materialised in slot P0
     HIP_TRY(hipMemcpyAsync(slot(SLOT_P0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (bicg) HIP_TRY(hipMemcpyAsync(slot(SLOT_PT0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
+  rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r (and p) is final before the first pass
+  if (rc) return rc;
 
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

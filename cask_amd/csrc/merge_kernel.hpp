@@ -163,6 +163,10 @@ __device__ __forceinline__ PassScalars pass_scalars(const SolverPass &sp, int lb
   ps.stop = false;
   ps.update_x = false;
   if (sp.first) return ps;
+#if defined(CASK_ABL) && (CASK_ABL & 1)                       // diagnostic build: what do the partial sums cost?
+  ps.beta = 0.5; ps.alpha_prev = 0.0; ps.update_x = sp.xsol != nullptr;
+  return ps;
+#endif
   const double chk = partials_or_scalar(sp.part_chk, sp.n_chk, red);
   ps.alpha_prev = *sp.alpha_prev;
   ps.update_x = sp.xsol != nullptr;
@@ -207,7 +211,16 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
                                            const double *__restrict__ w, double *wl, int lb,
                                            const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
+#if defined(CASK_ABL) && (CASK_ABL & 2)                       // diagnostic build: what does the second window cost?
+  constexpr bool COMP = false;
+#else
   constexpr bool COMP = EXT == 2;                             // operand composed on the fly: x[c] + beta * x[c + b_off]
+#endif
+#if defined(CASK_ABL) && (CASK_ABL & 4)                       // diagnostic build: what do the own-row updates cost?
+  constexpr bool OWN = false;
+#else
+  constexpr bool OWN = EXT == 2;
+#endif
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -324,7 +337,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   // solver pass: the rows this block owns (tid and tid + WG; a block has < 2*WG rows) -- new direction, the
   // solution update the previous pass owes, and the dot operand
   const int orow0 = d.row_start + min(tid, d.n_rows - 1), orow1 = d.row_start + min(tid + WG, d.n_rows - 1);
-  if (COMP) {
+  if (OWN) {
     const double a0 = x[orow0], a1 = x[orow1], b0 = x[orow0 + sp.b_off], b1 = x[orow1 + sp.b_off];
     double s0 = 0.0, s1 = 0.0, wa0 = 0.0, wa1 = 0.0, wb0 = 0.0, wb1 = 0.0;
     if (ps.update_x) {
@@ -455,7 +468,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
 #endif
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
-  if ((EXT == 1 && w) || (COMP && w)) {                       // COMP: w != NULL means "leave the dot shares behind"
+  if ((EXT == 1 && w) || (EXT == 2 && w)) {                   // solver pass: w != NULL means "leave the dot shares behind"
     wl[tid] = w0;
     wl[tid + WG] = w1;
   }

@@ -80,18 +80,26 @@ class ShardedSpmv:
 
     @classmethod
     def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None,
-                    exchange="all_gather", fence=None, fused_halo=False):
+                    exchange="all_gather", fence=None, fused_halo=False, solver_slots=1, share_with=None,
+                    bounds=None):
         """Build this rank's block of a globally known CSR matrix on the current GPU.
 
         exchange="all_gather": block with global columns, x all-gathered per product.
         exchange="p2p": block with extended columns [own | halo], halo pulled from the peers' shared
         slices per product (collective construction; raises on every rank if any rank cannot map a peer).
         ``fence`` orders device work across ranks for the p2p path (default: a 1-element all-reduce).
-        ``fused_halo`` (p2p only): no pull step -- the product kernel loads the halo from the peers."""
+        ``fused_halo`` (p2p only): no pull step -- the product kernel loads the halo from the peers.
+        ``solver_slots`` (p2p + fused_halo): 3 (CG) or 6 (BiCG) vector slots in the shared allocation, the
+        layout ``cask_hip_solve_device`` runs its passes on.  ``share_with``: another p2p operator whose
+        shared vectors this one reads too (the A^T block of a sharded BiCG; same row partition).
+        ``bounds``: use this row partition instead of computing one."""
         import torch
         from . import capi
         n = len(row_ptr) - 1
-        bounds = partition_rows_by_nnz(row_ptr, world) if balance == "nnz" else partition_rows_even(n, world)
+        if share_with is not None:
+            bounds = share_with.bounds
+        if bounds is None:
+            bounds = partition_rows_by_nnz(row_ptr, world) if balance == "nnz" else partition_rows_even(n, world)
         if n != n_cols:
             raise ValueError("row sharding of x needs a square matrix")
         rp, ci, va = slice_rows(row_ptr, col_ind, values, bounds[rank], bounds[rank + 1])
@@ -112,13 +120,24 @@ class ShardedSpmv:
 
                 def fence():
                     dist.all_reduce(token, group=group)
-            ex = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects, fence)
-            mat = capi.CsrMatrix.from_host(n_local, n_local + ex.n_halo, rp, ci_ext, va, params)
+            n_halo = int(len(halo_owner))
+            if share_with is not None:
+                ex = share_with.exchange         # same vectors, own halo list
+                addr = ex.address_table(halo_owner, halo_index)
+            else:
+                ex = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects, fence,
+                                      n_slots=solver_slots)
+                addr = ex.addr
+            mat = capi.CsrMatrix.from_host(n_local, n_local + n_halo, rp, ci_ext, va, params)
             obj = cls(bounds, rank, world, lambda xe, yl: mat.spmv_device(xe, yl), dev, group, exchange=ex)
             obj.fused_halo = False
+            obj.n_halo = n_halo
             if fused_halo and mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2:
-                ex.attach(mat)                  # the product kernel reads the halo from the peers itself
+                if n_halo:
+                    mat.set_halo_sources(n_local, addr)   # the product kernel reads the halo from the peers itself
                 obj.fused_halo = True
+            elif ex.n_slots != 1 or share_with is not None:
+                raise capi.CaskHipError("solver slots / shared vectors need the in-kernel halo (MERGE variant)")
         elif exchange == "all_gather":
             mat = capi.CsrMatrix.from_host(n_local, n_cols, rp, ci, va, params)
             obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
@@ -128,21 +147,22 @@ class ShardedSpmv:
         return obj
 
     # -- exchange ---------------------------------------------------------------
-    def gather_x(self, x_local):
-        """all-gather of the x slices into self.x_full (uneven slices are padded to the longest)."""
+    def gather_x(self, x_local, out=None):
+        """all-gather of the x slices into ``out`` (default: self.x_full); uneven slices are padded to the longest."""
         import torch.distributed as dist
+        out = self.x_full if out is None else out
         if self.world == 1:
-            self.x_full.copy_(x_local)
-            return self.x_full
+            out.copy_(x_local)
+            return out
         if self.even:
-            dist.all_gather_into_tensor(self.x_full, x_local.contiguous(), group=self.group)
-            return self.x_full
+            dist.all_gather_into_tensor(out, x_local.contiguous(), group=self.group)
+            return out
         self._pad_in[: self.n_local].copy_(x_local)
         dist.all_gather_into_tensor(self._pad_out, self._pad_in, group=self.group)
         for g in range(self.world):
-            self.x_full[self.bounds[g]: self.bounds[g + 1]].copy_(
+            out[self.bounds[g]: self.bounds[g + 1]].copy_(
                 self._pad_out[g * self.max_local: g * self.max_local + self.sizes[g]])
-        return self.x_full
+        return out
 
     def spmv(self, x_local, y_local=None, fence_before=True, fence_after=True):
         """y_local = A_g x.  With a peer-to-peer exchange two orderings across ranks are needed: every slice
@@ -183,66 +203,124 @@ class ShardedSpmv:
             ex.close()
 
     def dot(self, a_local, b_local):
-        """Global dot product as a 1-element tensor on the device (no host sync)."""
+        """Global dot product as a 1-element tensor on the device (no host sync): the engine's two-stage
+        reduction on GPUs (``cask_hip_ddot_device``), then a one-element all-reduce."""
         import torch.distributed as dist
-        s = (a_local * b_local).sum().reshape(1)
+        if a_local.is_cuda:
+            from . import capi
+            s = self.torch.empty(1, dtype=self.torch.float64, device=a_local.device)
+            capi.ddot_device(a_local, b_local, s)
+        else:                                   # CPU tests of the collective plumbing (no engine without a GPU)
+            s = (a_local * b_local).sum().reshape(1)
         if self.world > 1:
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s
 
-    def cg(self, b_local, x_local=None, maxiters=2000, tol=1e-5):
-        """Distributed un-preconditioned CG with the recurrence, stopping rule and
-        `iterations` convention of pcg (src/runtime/SparseLinearSolvers.hpp:162-239).
-        Every rank sees the same all-reduced scalars, so all ranks stop in the same
-        pass.  Returns (x_local, iterations, converged)."""
-        torch = self.torch
-        x = torch.zeros_like(b_local) if x_local is None else x_local.clone()
-        r = b_local - self.spmv(x)                               # :189-190
-        p = r.clone()
-        rsold = self.dot(r, r)                                   # :198
-        iterations, tol2 = 0, tol * tol
-        for i in range(maxiters):
-            Ap = self.spmv(p, fence_after=False)                 # :206 (the all-reduce of p.Ap orders the ranks)
-            alpha = rsold / self.dot(p, Ap)                      # :208
-            x = x + alpha * p                                    # :210
-            r = r - alpha * Ap                                   # :212
-            rsnew = self.dot(r, r)                               # :218
-            if float(rsnew) <= tol2:                             # :220
-                return x, iterations, True
-            p = r + (rsnew / rsold) * p                          # :229
-            rsold = rsnew
-            iterations = i                                       # :231
-        return x, iterations, False
+    # -- solvers: the engine's own kernels and recurrences (cask_hip_solve_device) ----------------------
+    def _allreduce_callback(self):
+        """``allreduce(ptr, count, stream) -> 0`` for cask_hip_solve_device: sums ``count`` doubles at a device
+        address over the ranks of ``self.group``, ordered on torch's current stream (the one the solver runs
+        on).  RCCL (backend "nccl") is stream-ordered by itself; host-staged backends (gloo: dry runs with
+        several ranks on one GPU) are bracketed by device synchronisation."""
+        import torch.distributed as dist
+        torch, device, group = self.torch, self.device, self.group
+        stream_ordered = dist.get_backend(group) == "nccl"
+        views = {}
 
-    def bicg(self, transposed: "ShardedSpmv", b_local, x_local=None, maxiters=2000, tol=1e-5):
-        """Distributed classical BiCG (BASELINE config 5): products with A (this operator) and A^T
-        (``transposed``: the row-sharded transpose, see ``transpose_csr``), all-reduced dot products.
-        Same recurrence, stopping rule (r.r <= tol^2) and `iterations` convention as the single-GPU
-        ``cask_hip_bicg`` and the oracle; the reference only declares this solver
-        (DfeBiCgSolver, src/runtime/SparseLinearSolvers.hpp:56-61).  Returns (x_local, iterations, converged)."""
+        def allreduce(ptr, count, stream):
+            t = views.get((ptr, count))
+            if t is None:
+                t = views[(ptr, count)] = tensor_from_ptr(ptr, count, device)
+            if not stream_ordered and device.type == "cuda":
+                torch.cuda.synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if not stream_ordered and device.type == "cuda":
+                torch.cuda.synchronize()
+            return 0
+        return allreduce
+
+    def _exchange_callback(self):
+        """``exchange(local_ptr, full_ptr, stream) -> 0``: the all-gather of an operand (classic passes on blocks
+        with global column indices)."""
+        import torch.distributed as dist
+        stream_ordered = self.world == 1 or dist.get_backend(self.group) == "nccl"
+        views = {}
+
+        def exchange(local_ptr, full_ptr, stream):
+            key = (local_ptr, full_ptr)
+            if key not in views:
+                views[key] = (tensor_from_ptr(local_ptr, self.n_local, self.device),
+                              tensor_from_ptr(full_ptr, self.n, self.device))
+            src, dst = views[key]
+            if not stream_ordered and self.device.type == "cuda":
+                self.torch.cuda.synchronize()
+            self.gather_x(src, out=dst)
+            if not stream_ordered and self.device.type == "cuda":
+                self.torch.cuda.synchronize()
+            return 0
+        return exchange
+
+    def _solve(self, kind, transposed, b_local, x_local, maxiters, tol, mode):
+        from . import capi
         torch = self.torch
+        if getattr(self, "matrix", None) is None:
+            raise RuntimeError("the sharded solvers run on the HIP engine: build the operator with from_global()")
         x = torch.zeros_like(b_local) if x_local is None else x_local.clone()
-        r = b_local - self.spmv(x)
-        rt, p, pt = r.clone(), r.clone(), r.clone()
-        rho = self.dot(rt, r)
-        iterations, tol2 = 0, tol * tol
-        for i in range(maxiters):
-            q = self.spmv(p, fence_after=False)                  # each product publishes its operand and fences
-            qt = transposed.spmv(pt, fence_after=False)          # before reading; the all-reduce of pt.q orders
-            alpha = rho / self.dot(pt, q)                        # the reads against the updates below
-            x.add_(alpha * p)
-            r.sub_(alpha * q)
-            rt.sub_(alpha * qt)
-            rr = self.dot(r, r)
-            if float(rr) <= tol2:
-                return x, iterations, True
-            rho_new = self.dot(rt, r)
-            beta = rho_new / rho
-            p = r + beta * p
-            pt = rt + beta * pt
-            rho = rho_new
-            iterations = i
-        return x, iterations, False
+        kw = {}
+        if self.world > 1:
+            import torch.distributed as dist
+            kw["allreduce"] = self._allreduce_callback()
+            if mode == capi.SOLVER_AUTO:
+                # every rank must run the same form of pass (same collectives): composed only if every rank's
+                # design points have the fused dot epilogue (a block with < 2 nonzeros runs the VECTOR kernel)
+                ok = bool(self.matrix.info.fuses_dot) and (transposed is None or bool(transposed.matrix.info.fuses_dot))
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                mode = capi.SOLVER_COMPOSED if (float(flag[0]) > 0.5 and self.exchange is not None) else capi.SOLVER_CLASSIC
+        ex = self.exchange
+        if ex is not None:
+            if not getattr(self, "fused_halo", False) or ex.n_slots < (6 if kind == "bicg" else 3):
+                raise RuntimeError("a peer-to-peer solver needs fused halos and solver slots "
+                                   "(from_global(..., exchange='p2p', fused_halo=True, solver_slots=3 or 6))")
+            if transposed is not None and transposed.exchange is not ex:
+                raise RuntimeError("A and A^T must share one PeerExchange (from_global(..., share_with=...))")
+            kw.update(shared_base=ex.shared.ptr, stride=ex.stride)
+        elif self.world > 1:
+            kw.update(exchange=self._exchange_callback(), n_full=self.n)
+        it, conv, us = self.matrix.solve_device(b_local.contiguous(), x, kind=kind,
+                                                transposed=transposed.matrix if transposed is not None else None,
+                                                mode=mode, maxiters=maxiters, tol=tol, **kw)
+        self.last_usec_per_iteration = us
+        return x, it, conv
+
+    def cg(self, b_local, x_local=None, maxiters=2000, tol=1e-5, mode=0):
+        """Distributed un-preconditioned CG: recurrence, stopping rule and `iterations` convention of pcg
+        (src/runtime/SparseLinearSolvers.hpp:162-239), run by the engine (``cask_hip_solve_device``): fused
+        product + p.Ap, update kernels, device-resident scalars, convergence flag polled every 16 passes; the
+        dot products are all-reduced in-stream.  Every rank sees the same scalars, so all ranks stop in the same
+        pass.  Returns (x_local, iterations, converged)."""
+        return self._solve("cg", None, b_local, x_local, maxiters, tol, mode)
+
+    def bicg(self, transposed: "ShardedSpmv", b_local, x_local=None, maxiters=2000, tol=1e-5, mode=0):
+        """Distributed classical BiCG (BASELINE config 5): products with A (this operator) and A^T
+        (``transposed``: the row-sharded transpose, see ``transpose_csr``), all-reduced dot products; same
+        recurrence, stopping rule (r.r <= tol^2) and `iterations` convention as the single-GPU ``cask_hip_bicg``
+        and the oracle (the reference only declares this solver: DfeBiCgSolver,
+        src/runtime/SparseLinearSolvers.hpp:56-61).  Returns (x_local, iterations, converged)."""
+        return self._solve("bicg", transposed, b_local, x_local, maxiters, tol, mode)
+
+
+def tensor_from_ptr(ptr: int, n: int, device):
+    """Zero-copy float64 view of ``n`` doubles at a raw address (host memory for a cpu device)."""
+    import ctypes
+    import torch
+    if device.type == "cpu":
+        return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr)))
+    from . import p2p
+    t = torch.as_tensor(p2p._RawDeviceArray(ptr, n), device=device)
+    if t.data_ptr() != ptr:
+        raise RuntimeError("torch copied the buffer instead of viewing it")
+    return t
 
 
 def transpose_csr(n_rows, n_cols, row_ptr, col_ind, values):

@@ -170,7 +170,13 @@ class PeerExchange:
     Raises on every rank or on none (the outcome is agreed through ``exchange_objects``).
     """
 
-    def __init__(self, bounds, rank, world, halo_owner, halo_index, device, exchange_objects, fence_fn=None):
+    def __init__(self, bounds, rank, world, halo_owner, halo_index, device, exchange_objects, fence_fn=None,
+                 n_slots=1):
+        """``n_slots`` > 1 (row-sharded solvers, ``cask_hip_solve_device``): the allocation holds that many
+        vectors, slot k at ``k * stride`` doubles, with the SAME stride on every rank (the longest slice,
+        rounded up to 32 doubles); the address table points at slot 0 and a product on the vector in slot
+        k adds ``k * stride * 8`` bytes.  The private halo copy behind the slots exists only for
+        ``n_slots == 1`` (the pull mode needs [own | halo] contiguous)."""
         import torch
         self.rank, self.world, self.device = rank, world, device
         self.n_local = int(bounds[rank + 1] - bounds[rank])
@@ -178,23 +184,23 @@ class PeerExchange:
         self.fence_fn = fence_fn
         self.peers = {}
         self.shared = None
+        self.n_slots = int(n_slots)
+        longest = max(int(bounds[g + 1] - bounds[g]) for g in range(world))
+        self.stride = self.n_local if self.n_slots == 1 else max(32, -(-longest // 32) * 32)
         err = None
         try:
-            self.shared = SharedVector(self.n_local + self.n_halo)
+            self.shared = SharedVector(self.n_local + self.n_halo if self.n_slots == 1
+                                       else self.n_slots * self.stride)
             # signature in element 0 so that a peer can tell a good mapping from a stale one
             self.shared.write([rank + 0.5])
         except Exception as e:  # noqa: BLE001 - reported to every rank below
             err = repr(e)
         infos = exchange_objects({"handle": self.shared.handle if self.shared else None, "error": err})
+        self._handles = [i["handle"] for i in infos]
         err = next((f"rank {g}: {i['error']}" for g, i in enumerate(infos) if i["error"]), None)
         if err is None:
             try:
-                for g in sorted(set(int(o) for o in np.unique(halo_owner))):
-                    if g == rank:
-                        raise ValueError("halo column owned by this rank")
-                    self.peers[g] = open_peer(infos[g]["handle"])
-                    if peek(self.peers[g]) != g + 0.5:
-                        raise capi.CaskHipError(f"mapping of rank {g}'s slice does not show its signature")
+                self._open_owners(halo_owner, check_signature=True)
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
         oks = exchange_objects(err)                      # also: nobody clears its signature before all have looked
@@ -203,15 +209,40 @@ class PeerExchange:
             self.close()
             raise capi.CaskHipError("peer-to-peer setup failed (" + "; ".join(bad) + ")")
         self.shared.write([0.0])
-        bases = [self.peers.get(g, 0) for g in range(world)]
-        addr = halo_addresses(halo_owner, halo_index, bases) if self.n_halo else np.zeros(0, dtype=np.int64)
-        self.addr = torch.from_numpy(addr).to(device)
+        self.addr = self.address_table(halo_owner, halo_index)
         self.x_ext = self.shared.tensor(device)
         self.x_local = self.x_ext[: self.n_local]
         self._halo_ptr = self.shared.ptr + 8 * self.n_local
 
+    def _open_owners(self, halo_owner, check_signature=False):
+        for g in sorted(set(int(o) for o in np.unique(halo_owner))):
+            if g == self.rank:
+                raise ValueError("halo column owned by this rank")
+            if g in self.peers:
+                continue
+            self.peers[g] = open_peer(self._handles[g])
+            if check_signature and peek(self.peers[g]) != g + 0.5:
+                raise capi.CaskHipError(f"mapping of rank {g}'s slice does not show its signature")
+
+    def address_table(self, halo_owner, halo_index):
+        """Device table of the absolute addresses (slot 0 of the owners' allocations) of a halo list; maps
+        owners that are not mapped yet.  A second operator over the same vectors (the A^T block of a sharded
+        BiCG) gets its table here -- not collective: the handles were exchanged at construction."""
+        import torch
+        self._open_owners(halo_owner)
+        bases = [self.peers.get(g, 0) for g in range(self.world)]
+        addr = halo_addresses(halo_owner, halo_index, bases) if len(halo_owner) else np.zeros(0, dtype=np.int64)
+        return torch.from_numpy(addr).to(self.device)
+
+    def slot(self, k):
+        """torch view of the vector in slot k (n_local entries)."""
+        full = self.shared.tensor(self.device)
+        return full[k * self.stride: k * self.stride + self.n_local]
+
     def pull(self, stream=None):
         """Refresh the halo from the owners' slices (asynchronous on ``stream``)."""
+        if self.n_slots != 1:
+            raise capi.CaskHipError("the halo pull needs the [own | halo] layout (n_slots == 1)")
         if self.n_halo:
             capi._check(_lib().cask_hip_halo_pull_device(self.n_halo, c_void_p(self.addr.data_ptr()),
                                                          c_void_p(self._halo_ptr), c_void_p(capi._stream_ptr(stream))))

@@ -69,6 +69,8 @@ typedef struct cask_hip_csr_info {
   int32_t empty_rows;
   double  mean_row_nnz;
   int64_t algorithmic_bytes;/* 12*nnz + 4*(n_rows+1) + 8*n_cols + 8*n_rows */
+  int32_t fuses_dot;        /* 1: the design point has the fused dot epilogue (composed solver passes possible) */
+  int32_t reserved;
 } cask_hip_csr_info;
 
 typedef struct cask_hip_device_props {

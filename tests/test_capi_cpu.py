@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
     # sizes implied by include/cask_hip.h (all int32/int64/double, natural alignment)
     import ctypes
     assert ctypes.sizeof(capi.Params) == 32
-    assert ctypes.sizeof(capi.CsrInfo) == 56
+    assert ctypes.sizeof(capi.CsrInfo) == 64
     assert ctypes.sizeof(capi.DeviceProps) == 128
     assert ctypes.sizeof(capi.TunePoint) == 64
 

@@ -1,5 +1,5 @@
 """The N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise the row partitioning, the
-all-gather of x (even and uneven slices), the all-reduced dots and the distributed CG of
+all-gather of x (even and uneven slices), the all-reduced dots and the solver callbacks of
 cask_amd/dist.py.  The local block product is injected (the CPU oracle -- tests may use it); on GPUs
 it is the HIP engine."""
 import os
@@ -38,20 +38,43 @@ def _worker(rank, world, port, case, out):
         y = sh.spmv(x)
         res = {"y": y.numpy().copy(), "dot": float(sh.dot(x, x))}
         if case.get("cg"):
-            b = torch.from_numpy(case["b"][bounds[rank]:bounds[rank + 1]].copy())
-            xs, it, conv = sh.cg(b, maxiters=case.get("maxiters", 2000))
-            res.update({"cg_x": xs.numpy().copy(), "cg_it": it, "cg_conv": conv})
-        if case.get("bicg"):
-            trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
-            tl = cdist.slice_rows(trp, tci, tva, bounds[rank], bounds[rank + 1])
+            # The engine's sharded CG (cask_hip_solve_device, classic form) restated on numpy in THIS test and
+            # driven through the product code's real callbacks: the operand all-gather (uneven slices) and the
+            # in-place all-reduce of scalars at a raw address.  Checks the collective protocol on CPU; the
+            # arithmetic of the engine itself is tested on the GPU (tests/test_p2p_gpu.py).
+            import ctypes
+            allreduce, exchange = sh._allreduce_callback(), sh._exchange_callback()
+            nl = bounds[rank + 1] - bounds[rank]
+            b = case["b"][bounds[rank]:bounds[rank + 1]].copy()
+            ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p).value          # noqa: E731
+            full, scal = np.zeros(n), np.zeros(4)
 
-            def local_product_t(x_full, y_local):
-                y_local.copy_(torch.from_numpy(oracle.csr_spmv(tl[0], tl[1], tl[2], x_full.numpy())))
+            def product(v):
+                assert exchange(ptr(v), ptr(full), 0) == 0
+                return oracle.csr_spmv(lrp, lci, lva, full)
 
-            sht = cdist.ShardedSpmv(bounds, rank, world, local_product_t, torch.device("cpu"))
-            b = torch.from_numpy(case["b"][bounds[rank]:bounds[rank + 1]].copy())
-            xs, it, conv = sh.bicg(sht, b, tol=case.get("tol", 1e-5))
-            res.update({"bicg_x": xs.numpy().copy(), "bicg_it": it, "bicg_conv": conv})
+            def allsum(v):
+                scal[0] = v
+                assert allreduce(ptr(scal), 1, 0) == 0
+                return scal[0]
+
+            xs = np.zeros(nl)
+            r = b - product(xs)
+            p = r.copy()
+            rsold = allsum(r @ r)
+            it, conv = 0, False
+            for i in range(case.get("maxiters", 2000)):
+                Ap = product(p)
+                alpha = rsold / allsum(p @ Ap)
+                xs += alpha * p
+                r -= alpha * Ap
+                rsnew = allsum(r @ r)
+                if rsnew <= 1e-10:
+                    conv = True
+                    break
+                p = r + (rsnew / rsold) * p
+                rsold, it = rsnew, i
+            res.update({"cg_x": xs, "cg_it": it, "cg_conv": conv})
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -105,7 +128,9 @@ def test_sharded_spmv_even_slices_weak_scaling_blocks():
     assert np.array_equal(np.concatenate([r["y"] for r in res]), oracle.csr_spmv(rp, ci, va, x))
 
 
-def test_distributed_cg_matches_oracle():
+def test_solver_callbacks_carry_a_distributed_cg():
+    """The all-reduce and operand-exchange callbacks the sharded solvers hand to cask_hip_solve_device,
+    exercised by a numpy restatement of its classic pass (the engine itself needs a GPU)."""
     n, rp, ci, va = synth.small("cant", factor=64)
     x0 = np.arange(n) * 0.25 / n
     b = oracle.csr_spmv(rp, ci, va, x0)
@@ -124,20 +149,3 @@ def test_transpose_csr_matches_oracle():
     x = np.random.default_rng(1).standard_normal(n)
     assert np.array_equal(oracle.csr_spmv(trp, tci, tva, x), oracle.csr_spmv_t(n, rp, ci, va, x))
     assert all(np.all(np.diff(tci[trp[r]:trp[r + 1]]) > 0) for r in range(0, n, max(1, n // 50)))
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_bicg_matches_oracle(world):
-    """BASELINE config 5 in small: nonsymmetric atmosmodd-like system, A and A^T products row-sharded."""
-    n, rp, ci, va = synth.small("atmosmodd", factor=64)
-    x0 = np.random.default_rng(2).uniform(-1, 1, n)
-    b = oracle.csr_spmv(rp, ci, va, x0)
-    want, want_it, want_conv = oracle.bicg(rp, ci, va, b, tol=1e-9)
-    bounds = cdist.partition_rows_by_nnz(rp, world)
-    res = run_world(world, {"matrix": (n, rp, ci, va), "bounds": bounds, "x": x0, "b": b, "bicg": True, "tol": 1e-9})
-    got = np.concatenate([r["bicg_x"] for r in res])
-    assert want_conv and all(r["bicg_conv"] for r in res)
-    assert all(abs(r["bicg_it"] - want_it) <= 1 for r in res), ([r["bicg_it"] for r in res], want_it)
-    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(got, x0, rtol=1e-6, atol=1e-8)
-

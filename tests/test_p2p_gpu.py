@@ -70,16 +70,21 @@ def _worker(rank, world, port, case, out):
         res["y_graph"] = y.cpu().numpy()
         fence()
         if case.get("bicg") is not None:
-            # BASELINE config 5 in small: BiCG with A and A^T row-sharded, both read their halos in-kernel
+            # BASELINE config 5 in small: BiCG with A and A^T row-sharded over the same shared vectors (6 slots),
+            # both read their halos in-kernel; the passes run in the engine (cask_hip_solve_device)
             trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
-            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, balance=case.get("balance", "nnz"),
-                                                exchange="p2p", fence=fence, fused_halo=case.get("fused", False))
+            sh.close()
+            sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, balance=case.get("balance", "nnz"),
+                                               exchange="p2p", fence=fence, fused_halo=True, solver_slots=6)
+            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, exchange="p2p", fence=fence,
+                                                fused_halo=True, share_with=sh)
             bl = torch.from_numpy(case["bicg"][b0:b1].copy()).cuda()
-            xs, it, conv = sh.bicg(sht, bl, tol=1e-9)
-            torch.cuda.synchronize()
-            res.update({"bicg_x": xs.cpu().numpy(), "bicg_it": it, "bicg_conv": conv})
-            fence()
-            sht.close()
+            for mode in case.get("modes", (0,)):
+                xs, it, conv = sh.bicg(sht, bl, tol=1e-9, mode=mode)
+                torch.cuda.synchronize()
+                res[f"bicg_x{mode}"], res[f"bicg_it{mode}"], res[f"bicg_conv{mode}"] = xs.cpu().numpy(), it, conv
+                fence()
+            sht.exchange = None                    # the vectors belong to sh
         sh.close()
         out[rank] = res
     finally:
@@ -139,16 +144,18 @@ def test_two_ranks_block_diagonal_needs_no_halo():
 
 def test_two_ranks_bicg_with_in_kernel_halos():
     """A and A^T products of a nonsymmetric stencil system sharded over two processes (balance by rows so
-    that both operators use the same slices), dots all-reduced: same answer as the oracle's BiCG."""
+    that both operators use the same slices), dots all-reduced: same answer as the oracle's BiCG, in the composed
+    form (the product launches compose p and pt; the two all-reduces of a pass are its only ordering) and in the
+    classic form (separate p update + a fence collective)."""
     matrix = synth.small("atmosmodd", factor=32)
     n, rp, ci, va = matrix
     x0 = np.random.default_rng(3).uniform(-1, 1, n)
     b = oracle.csr_spmv(rp, ci, va, x0)
     want, want_it, want_conv = oracle.bicg(rp, ci, va, b, tol=1e-9)
     xs = [np.arange(n, dtype=np.float64) * 0.25]
-    res = run_world(2, {"matrix": matrix, "xs": xs, "balance": "even", "fused": True, "bicg": b})
-    got = np.concatenate([r["bicg_x"] for r in res])
-    assert want_conv and all(r["bicg_conv"] for r in res)
-    assert all(abs(r["bicg_it"] - want_it) <= 1 for r in res)
-    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
-
+    res = run_world(2, {"matrix": matrix, "xs": xs, "balance": "even", "fused": True, "bicg": b, "modes": (0, 1, 2)})
+    for mode in (0, 1, 2):
+        got = np.concatenate([r[f"bicg_x{mode}"] for r in res])
+        assert want_conv and all(r[f"bicg_conv{mode}"] for r in res)
+        assert all(abs(r[f"bicg_it{mode}"] - want_it) <= 1 for r in res), mode
+        np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
