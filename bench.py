@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: fp64 CSR SpMV on the cant-like matrix (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload W] [--solver S]
 
-A "step" is one pass of the hot path: y = A x over the whole matrix resident in
-HBM.  For N > 1 (weak scaling: every rank owns one cant-sized row block of a
-block-banded global matrix, and the slice of x that goes with it) a step is still
-ONE launch per rank: the x slices live in shared allocations and the product
-kernel's seam workgroups load the halo entries they need straight from the
-neighbours' slices over xGMI (cask_hip_csr_set_halo_sources, cask_amd/p2p.py) --
-no collective, no copy and no exchange kernel on the data path.  That mode is
-verified bit-for-bit against the halo-pull mode (a small kernel in front of the
-product) before it is timed; if the slices cannot be mapped the step falls back
-to the pull, then to an RCCL all-gather of x.  To make the number an HBM number
-and not an Infinity-Cache number the steps rotate through enough device copies of
-the matrix to exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one
-copy is reported next to it.  The K timed steps are captured once into a HIP
-graph (one kernel node per step) so the host's launch rate is not what is
-measured.
+A "step" is one pass of the hot path over data resident in HBM:
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline      -- algorithmic bytes per launch / mean launch time (HIP events on
-                   the launch stream) against the 8 TB/s HBM peak
-  cpu_baseline  -- the CPU oracle (1 core, "port") and MKL's dcsrgemv on all host
-                   cores, both on the same matrix, bounded to ~10 s each.
+* default (``--workload cant``): y = A x over the whole matrix.  N > 1 is WEAK scaling: every rank owns one
+  cant-sized row block of a block-banded global matrix and the slice of x that goes with it; a step is ONE launch
+  per rank -- the seam workgroups of the product kernel load the halo entries they need straight from the
+  neighbours' shared x slices over xGMI (cask_hip_csr_set_halo_sources), no collective on the data path.
+* ``--workload webbase-1M`` (BASELINE configs[3]), ``G3_circuit``, ``atmosmodd``: ONE global matrix, rows dealt to the
+  ranks in nnz-balanced contiguous blocks (STRONG scaling).  The exchange is chosen per matrix from the halo
+  fraction: where a block references most of x (webbase-like: 30 % uniformly random columns) a step is an RCCL
+  all-gather of x + the local product; banded / stencil matrices read their halos in-kernel.
+  ``CASK_BENCH_EXCHANGE=all_gather|p2p`` forces one.
+* ``--solver cg|bicg`` (configs[2] and [4]: ``--workload G3_circuit --solver cg``, ``--workload atmosmodd --solver
+  bicg``): a step is one solver pass run by the engine (cask_hip_solve_device: fused product + dot, update kernels,
+  device-resident scalars); row-sharded for N > 1 with the dot products all-reduced over RCCL.  The timed solve
+  runs exactly K passes (tol = 0); a separate solve to tol 1e-5 is checked against the oracle.
+
+To make the SpMV number an HBM number and not an Infinity-Cache number the steps rotate through enough device
+copies of the matrix to exceed 2x the 256 MiB cache ("cold"); the cache-warm rate of one copy is reported next to
+it.  The K timed steps are captured once into a HIP graph where the step has no collective.
+
+ONE clock: `value`, `ms_per_step` and `roofline.*` all come from the HIP-event time of the K timed steps (events on
+the launch stream, between the two barrier + synchronize brackets; the MAX over ranks).  The host wall time of the
+same region is reported as `host_wall_ms_per_step`.
+
+Prints ONE JSON line on rank 0 with
+  roofline      -- algorithmic bytes per launch / mean launch time against the 8 TB/s HBM peak
+  cpu_baseline  -- MKL's dcsrgemv (the CPU library the reference calls) on pinned host threads, and the 1-core
+                   C restatement (oracle) as the secondary figure; both on the same matrix, bounded to seconds.
 """
 import argparse
 import ctypes
@@ -40,6 +47,9 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
+HALO_FRACTION_FOR_ALLGATHER = 0.10   # a block that references more than this share of x gets the all-gather:
+#   per-element remote loads pay a fabric packet per 8 useful bytes, the all-gather moves whole slices (webbase-like
+#   blocks reference 16 % of x scattered over every peer; stencil / banded blocks 0.1-2 % from their neighbours)
 
 
 def parse_args():
@@ -47,7 +57,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="cant", choices=["cant", "G3_circuit", "webbase-1M", "atmosmodd"])
+    ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "atmosmodd"])
+    ap.add_argument("--solver", default=None, choices=["cg", "bicg"], help="time solver passes instead of products")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
     ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -61,35 +72,39 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
-    """Time the CPU oracle (sequential C restatement) and MKL on the same matrix."""
-    import oracle
-    out = {}
-    n = rp.size - 1
-    nnz = int(ci.size)
-    y = oracle.csr_spmv(rp, ci, va, x)                  # warm-up + the checker
-    bad, first = oracle.mismatches(y_gpu, y)
-    t0 = time.perf_counter()
-    calls = 0
-    while True:
-        oracle.csr_spmv(rp, ci, va, x)
-        calls += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or calls >= 5000:
-            break
-    out.update({"value": round(2.0 * nnz * calls / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
-                "sample": f"{calls} sequential CSR SpMVs of the same {n}x{n} matrix in {el:.1f} s (oracle/cask_oracle.c)",
-                "parity_gpu_vs_cpu_mismatches": bad})
-    # MKL, the CPU library the reference calls (fpgaNaiveCpuCode.cpp:33, SparseLinearSolvers.hpp:189)
-    mkl = None
+# ------------------------------------------------------------------------------------------- CPU baselines
+def load_mkl():
     for cand in (os.environ.get("MKLROOT", "/nonexistent") + "/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.1",
                  "/opt/conda/lib/libmkl_rt.so.2"):
         if os.path.exists(cand):
             try:
-                mkl = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-                break
+                return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
             except OSError:
                 pass
+    return None
+
+
+def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
+    """MKL mkl_cspblas_dcsrgemv on pinned threads (primary: the reference's CPU library) and the 1-core oracle."""
+    import oracle
+    n = rp.size - 1
+    nnz = int(ci.size)
+    y = oracle.csr_spmv(rp, ci, va, x)                  # warm-up + the checker
+    bad, _ = oracle.mismatches(y_gpu, y) if y_gpu is not None else (None, None)
+    t0 = time.perf_counter()
+    calls = 0
+    budget = min(seconds, 5.0)
+    while True:
+        oracle.csr_spmv(rp, ci, va, x)
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= budget or calls >= 5000:
+            break
+    port = {"value": round(2.0 * nnz * calls / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"{calls} sequential CSR SpMVs of the same {n}x{x.size} matrix in {el:.1f} s (oracle/cask_oracle.c)"}
+    out = dict(port)
+    out["parity_gpu_vs_cpu_mismatches"] = bad
+    mkl = load_mkl()
     if mkl is not None and x.size == n:
         try:
             mkl.MKL_Get_Max_Threads.restype = ctypes.c_int
@@ -99,8 +114,8 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
             ym = np.zeros(n)
             args = (ctypes.byref(tr), ctypes.byref(nn), p(va), p(rp), p(ci), p(x), p(ym))
             # the host is shared and a 62 K-row product does not feed 128 threads: time a few team sizes for
-            # a slice of the budget each and report the best one (its thread count is `threads`)
-            counts = sorted({t for t in (8, 16, 32, 64, max_threads) if 0 < t <= max_threads})
+            # a slice of the budget each and report the best one (threads pinned: OMP_PROC_BIND/OMP_PLACES below)
+            counts = sorted({t for t in (8, 16, 32, 64) if 0 < t <= max_threads} | {min(max_threads, 16)})
             by_threads, best = {}, None
             for t in counts:
                 mkl.MKL_Set_Num_Threads(ctypes.c_int(t))
@@ -119,17 +134,36 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
                 if best is None or rate > best[0]:
                     best = (rate, t, calls, el)
             mbad, _ = oracle.mismatches(ym, y)
-            out["mkl"] = {"value": round(best[0], 4), "unit": "GFLOP/s", "threads": best[1],
-                          "host_cores": os.cpu_count(), "routine": "mkl_cspblas_dcsrgemv",
-                          "sample": f"{best[2]} calls in {best[3]:.1f} s", "gflops_by_threads": by_threads,
-                          "mismatches_vs_oracle": mbad}
+            out = {"value": round(best[0], 4), "unit": "GFLOP/s", "cores": best[1], "kind": "mkl",
+                   "routine": "mkl_cspblas_dcsrgemv (oneMKL, GNU threading layer, OMP_PROC_BIND=close OMP_PLACES=cores)",
+                   "host_cores": os.cpu_count(), "sample": f"{best[2]} calls with {best[1]} threads in {best[3]:.1f} s",
+                   "gflops_by_threads": by_threads, "mismatches_vs_oracle": mbad,
+                   "parity_gpu_vs_cpu_mismatches": bad, "port": port}
         except Exception as e:  # pragma: no cover - diagnostic only
-            out["mkl"] = {"error": repr(e)}
-    else:
-        out["mkl"] = None
+            out["mkl_error"] = repr(e)
     return out
 
 
+def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
+    """The oracle's CG / BiCG (1 core) for a bounded number of passes; GFLOP/s on the same flop count as `value`."""
+    import oracle
+    n, nnz = rp.size - 1, int(ci.size)
+    passes = 10
+    fn = oracle.cg_full if kind == "cg" else oracle.bicg
+    t0 = time.perf_counter()
+    fn(rp, ci, va, b, maxiters=passes, tol=0.0)
+    el = time.perf_counter() - t0
+    if el < seconds / 4:                                    # scale the sample up to a few seconds
+        passes = int(min(200, passes * seconds / 2 / max(el, 1e-3)))
+        t0 = time.perf_counter()
+        fn(rp, ci, va, b, maxiters=passes, tol=0.0)
+        el = time.perf_counter() - t0
+    flops = (2 * nnz + 12 * n) if kind == "cg" else (4 * nnz + 20 * n)
+    return {"value": round(flops * passes / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} {kind} passes of the same {n}-row system in {el:.1f} s (oracle/cask_oracle.c)"}
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -139,10 +173,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     # CASK_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all_gather, all_reduce) with a single
-    # rank: a dry run of the N>1 plumbing on a 1-GPU box.
+    # rank: the RCCL path on a 1-GPU box.
     use_dist = world > 1 or bool(os.environ.get("CASK_BENCH_FORCE_DIST"))
     os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
-    os.environ.setdefault("OMP_PROC_BIND", "true")
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
     import torch
     import torch.distributed as dist
@@ -162,7 +197,14 @@ def main():
             dist.init_process_group(backend)
     ctl_dev = dev if backend == "nccl" else torch.device("cpu")
 
+    class Ctx:
+        pass
+    cx = Ctx()
+    cx.args, cx.rank, cx.world, cx.dev, cx.use_dist, cx.backend, cx.ctl_dev = args, rank, world, dev, use_dist, backend, ctl_dev
+
     def all_reduce_scalar(v, op):
+        if not use_dist:
+            return float(v)
         t = torch.tensor([float(v)], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=op)
         return float(t[0])
@@ -171,30 +213,98 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
+    cx.all_reduce_scalar, cx.host_barrier = all_reduce_scalar, host_barrier
+
+    if args.solver:
+        rec = run_solver(cx)
+    elif args.workload in ("cant", "cant3"):
+        rec = run_spmv(cx, weak=True)
+    else:
+        rec = run_spmv(cx, weak=False)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if use_dist:
+        host_barrier()
+        dist.destroy_process_group()
+
+
+def timed_region(cx, run_steps):
+    """The K timed steps between the two barrier + synchronize brackets; returns (device ms: max over ranks,
+    host wall seconds: max over ranks)."""
+    import torch
+    import torch.distributed as dist
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cx.host_barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    run_steps()
+    e1.record()
+    cx.host_barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if cx.use_dist:
+        dev_ms = cx.all_reduce_scalar(dev_ms, dist.ReduceOp.MAX)
+        wall = cx.all_reduce_scalar(wall, dist.ReduceOp.MAX)
+    return dev_ms, wall
+
+
+def traffic_record(workload):
+    """Counter-measured HBM bytes per launch of an earlier profiled run of the same workload (not measured here)."""
+    tfile = REPO / "profiles" / f"traffic_{workload}.json"
+    if tfile.exists():
+        try:
+            t = json.loads(tfile.read_text())
+            return t.get("hbm_bytes_per_launch"), f"profiles/{tfile.name} (rocprofv3 PMC passes of round {t.get('round', '?')}, " \
+                                                  "FETCH_SIZE x calibration + WRITE_SIZE; not measured in this run)"
+        except Exception:
+            pass
+    return None, None
+
+
+def run_spmv(cx, weak):
+    import torch
+    import torch.distributed as dist
+    from cask_amd import capi, synth
+    from cask_amd import dist as cdist
+    args, rank, world, dev, use_dist = cx.args, cx.rank, cx.world, cx.dev, cx.use_dist
 
     # ---- workload -----------------------------------------------------------
-    if args.workload == "cant":
-        n_local, n_global, rp, ci, va = synth.cant_like_shard(rank, world)
-        source = "synthetic"
+    t_gen = time.perf_counter()
+    if weak:
+        gen = synth.cant_like_shard if args.workload == "cant" else synth.cant3_like_shard
+        if world == 1 and os.environ.get("CASK_MATRIX_DIR") and (Path(os.environ["CASK_MATRIX_DIR"]) / "cant.mtx").exists():
+            n_local, rp, ci, va, source = synth.load_or_make("cant")
+            n_global = n_local
+        else:
+            n_local, n_global, rp, ci, va = gen(rank, world)
+            source = "synthetic"
+        bounds = [g * n_local for g in range(world + 1)]
+        nnz_global = None
     else:
-        if use_dist:
-            raise SystemExit("multi-GPU bench is defined for the cant workload")
-        n_local, rp, ci, va, source = synth.load_or_make(args.workload)
-        n_global = n_local
+        n_global, grp, gci, gva, source = synth.load_or_make(args.workload)
+        bounds = cdist.partition_rows_by_nnz(grp, world)
+        rp, ci, va = cdist.slice_rows(grp, gci, gva, bounds[rank], bounds[rank + 1])
+        n_local = bounds[rank + 1] - bounds[rank]
+        nnz_global = int(gci.size)
     nnz_local = int(ci.size)
     x_host = np.arange(n_global, dtype=np.float64) * 0.25 / n_global        # test_spmv.cpp operand, scaled
-    x_slice = x_host[rank * n_local:(rank + 1) * n_local].copy()
+    x_slice = x_host[bounds[rank]:bounds[rank + 1]].copy()
 
-    # ---- exchange (N > 1): peer-to-peer halo pull, else RCCL all-gather ------------
-    exchange, peer, p2p_error = "none", None, None
+    # ---- exchange (N > 1): in-kernel halo / halo pull over shared slices, or RCCL all-gather ------------
+    exchange, peer, p2p_error, halo_frac = "none", None, None, 0.0
     ci_dev, n_cols_dev = ci, n_global
     if use_dist:
+        from cask_amd import p2p
+        ci_ext, halo_cols, halo_owner, halo_index = p2p.plan_halo(ci, bounds, rank)
+        halo_frac = cx.all_reduce_scalar(halo_cols.size / max(n_global, 1), dist.ReduceOp.MAX)
+        want = os.environ.get("CASK_BENCH_EXCHANGE", "auto")
+        if os.environ.get("CASK_BENCH_NO_P2P"):
+            want = "all_gather"
+        if want == "auto":
+            want = "all_gather" if halo_frac > HALO_FRACTION_FOR_ALLGATHER else "p2p"
         exchange = "all_gather"
-        if not os.environ.get("CASK_BENCH_NO_P2P"):
-            from cask_amd import p2p
-            bounds = [g * n_local for g in range(world + 1)]
-            ci_ext, halo_cols, halo_owner, halo_index = p2p.plan_halo(ci, bounds, rank)
-
+        if want == "p2p":
             def gather_objects(obj):
                 out = [None] * world
                 dist.all_gather_object(out, obj)
@@ -203,15 +313,15 @@ def main():
             try:
                 peer = p2p.PeerExchange(bounds, rank, world, halo_owner, halo_index, dev, gather_objects)
                 peer.x_local.copy_(torch.from_numpy(x_slice).to(dev))
-                host_barrier()                                   # every slice is in place before anyone pulls
+                cx.host_barrier()                                   # every slice is in place before anyone pulls
                 peer.pull()
                 torch.cuda.synchronize()
                 # self-check against a halo computed from the formula for x (no collective involved)
-                want = torch.from_numpy(x_host[halo_cols]).to(dev)
-                ok = bool(torch.equal(peer.x_ext[n_local:], want))
+                wanted = torch.from_numpy(x_host[halo_cols]).to(dev)
+                ok = bool(torch.equal(peer.x_ext[n_local:], wanted))
             except Exception as e:  # noqa: BLE001 - setup is collective: it fails on every rank or none
                 ok, p2p_error = False, repr(e)
-            ok = all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            ok = cx.all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
             if ok:
                 exchange, ci_dev, n_cols_dev = "p2p", ci_ext, n_local + peer.n_halo
             else:
@@ -221,19 +331,30 @@ def main():
                 if peer is not None:
                     peer.close()
                     peer = None
+    gen_seconds = time.perf_counter() - t_gen
     # bytes the local kernel must move: x entries = the columns this block can reference
     alg_bytes = synth.algorithmic_bytes(n_local, n_cols_dev, nnz_local)
     matrix_bytes = 12 * nnz_local + 4 * (n_local + 1)
-    copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // matrix_bytes) + 1)
+    copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // max(matrix_bytes, 1)) + 1)
 
     forced = capi.make_params(variant=args.variant or 0, lanes_per_row=args.lanes, tile_width=args.tile,
                               items_per_thread=args.items, wg_size=args.wg,
                               index16=int(os.environ.get("CASK_BENCH_INDEX16", "0")))   # development A/B only
     mats = []
+    torch.cuda.synchronize()
+    t_up = time.perf_counter()
     rp_t = torch.from_numpy(rp).to(dev)
-    for _ in range(copies):
+    ci_t0, va_t0 = torch.from_numpy(ci_dev).to(dev), torch.from_numpy(va).to(dev)
+    torch.cuda.synchronize()
+    upload_seconds = time.perf_counter() - t_up                  # one copy of the CSR arrays, host -> HBM
+    t_plan = time.perf_counter()
+    mats.append(capi.CsrMatrix.from_device(n_local, n_cols_dev, rp_t, ci_t0, va_t0, forced))
+    torch.cuda.synchronize()
+    plan_seconds = time.perf_counter() - t_plan                  # launch plan of one handle (merge-path cuts, x tiles, slots)
+    for _ in range(copies - 1):
         ci_t, va_t = torch.from_numpy(ci_dev).to(dev), torch.from_numpy(va).to(dev)
         mats.append(capi.CsrMatrix.from_device(n_local, n_cols_dev, rp_t, ci_t, va_t, forced))
+    x_local = None
     if exchange == "p2p":
         x_in = peer.x_ext                                        # [own slice | halo]
         if not os.environ.get("CASK_BENCH_NO_FUSED_HALO") and peer.n_halo:
@@ -254,7 +375,7 @@ def main():
                 fused_ok = bool(torch.equal(y_try, y_ref))
             except Exception as e:  # noqa: BLE001
                 fused_ok, p2p_error = False, repr(e)
-            fused_ok = all_reduce_scalar(1.0 if fused_ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            fused_ok = cx.all_reduce_scalar(1.0 if fused_ok else 0.0, dist.ReduceOp.MIN) > 0.5
             if fused_ok:
                 exchange = "p2p_fused"
             else:
@@ -264,9 +385,10 @@ def main():
                     m.set_halo_sources(n_local, None)
                 peer.pull()
     elif exchange == "all_gather":
+        gather = cdist.ShardedSpmv(bounds, rank, world, None, dev)
         x_local = torch.from_numpy(x_slice).to(dev)
-        x_in = torch.zeros(n_global, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(x_in, x_local)
+        x_in = gather.x_full
+        gather.gather_x(x_local)
     else:
         x_in = torch.from_numpy(x_host).to(dev)
     y = torch.zeros(n_local, dtype=torch.float64, device=dev)
@@ -291,7 +413,7 @@ def main():
         if exchange == "p2p":
             peer.pull()                                          # remote loads over xGMI, on the launch stream
         elif exchange == "all_gather":
-            dist.all_gather_into_tensor(x_in, x_local)
+            gather.gather_x(x_local)                             # RCCL all_gather_into_tensor (uneven slices padded)
         mats[i % copies].spmv_device(x_in, y)
 
     # ---- warm-up (eager) -------------------------------------------------------
@@ -331,40 +453,33 @@ def main():
             graph, launch_mode = None, "eager"
     if use_dist:
         # ranks must agree on the launch mode only for reporting; the timed region has no collective in p2p mode
-        launch_mode = "graph" if all_reduce_scalar(1.0 if graph is not None else 0.0, dist.ReduceOp.MIN) > 0.5 \
+        launch_mode = "graph" if cx.all_reduce_scalar(1.0 if graph is not None else 0.0, dist.ReduceOp.MIN) > 0.5 \
             else "eager"
         if launch_mode == "eager":
             graph = None
 
     # ---- timed region: exactly K steps -------------------------------------------
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if graph is not None:
         for _ in range(preroll):
             graph.replay()
-    host_barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(args.steps):
-            step(i)
-    e1.record()
-    host_barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
+
+    def run_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i)
+    dev_ms, wall = timed_region(cx, run_steps)
     y_gpu = y.cpu().numpy()
+    rows_wrong = None
     if use_dist:
-        elapsed = all_reduce_scalar(elapsed, dist.ReduceOp.MAX)
-        nnz_total = all_reduce_scalar(nnz_local, dist.ReduceOp.SUM)
+        nnz_total = cx.all_reduce_scalar(nnz_local, dist.ReduceOp.SUM)
         # every rank checks its whole block against the CPU oracle (the global x is a formula, nothing to gather)
         import oracle
         bad, _ = oracle.mismatches(y_gpu, oracle.csr_spmv(rp, ci, va, x_host))
-        rows_wrong = int(all_reduce_scalar(bad, dist.ReduceOp.SUM))
+        rows_wrong = int(cx.all_reduce_scalar(bad, dist.ReduceOp.SUM))
     else:
         nnz_total = float(nnz_local)
-        rows_wrong = None
 
     # ---- cache-warm rate of ONE copy (what a CG iteration on this matrix sees) ------
     warm_med, warm_min = mats[0].time(x_in, y, warmup=10, iters=200)        # eager launches, one event pair each
@@ -387,26 +502,23 @@ def main():
         except Exception:  # pragma: no cover - reporting only
             warm_graph = None
 
+    rec = None
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        gflops = 2.0 * nnz_total * args.steps / elapsed / 1e9
-        launch_us = dev_ms * 1e3 / args.steps              # HIP events on the launch stream, whole timed region
-        achieved = alg_bytes / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tfile = REPO / "profiles" / f"traffic_{args.workload}.json"
-        if tfile.exists():
-            try:
-                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        step_us = dev_ms * 1e3 / args.steps                # ONE clock: HIP events on the launch stream, max over ranks
+        gflops = 2.0 * nnz_total / step_us * 1e-3
+        achieved = alg_bytes / (step_us * 1e-6) / 1e9      # this rank's launch: its algorithmic bytes / the step time
+        traffic, traffic_source = traffic_record(args.workload) if world == 1 else (None, None)
+        like = {"cant": "cant-like", "cant3": "cant-like (3x3 node blocks, non-uniform band)"}.get(args.workload, args.workload + "-like")
         rec = {
-            "metric": "SpMV GFLOP/s (fp64 CSR, 2*nnz/t), SuiteSparse cant-like", "value": round(gflops, 2),
+            "metric": f"SpMV GFLOP/s (fp64 CSR, 2*nnz/t), SuiteSparse {like}", "value": round(gflops, 2),
             "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_us * 1e-3, 6), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if source == "synthetic" else source,
-            "config": {"workload": f"{args.workload}-like CSR SpMV, {n_local} rows x {n_global} cols per GPU, "
-                                   f"{nnz_local} nnz per GPU, x_i = 0.25 i / n",
-                       "rows": n_local * world, "nnz": int(nnz_total), "parallelism": f"row-blocks x{world}",
+            "host_wall_ms_per_step": round(wall * 1e3 / args.steps, 6),
+            "config": {"workload": f"{like} CSR SpMV, {n_local} rows x {n_global} cols on rank 0, "
+                                   f"{nnz_local} nnz on rank 0, x_i = 0.25 i / n",
+                       "rows": n_global, "nnz": int(nnz_total),
+                       "parallelism": f"row-blocks x{world}" + ("" if weak else " (nnz-balanced, one global matrix)"),
                        "exchange": {"none": "none",
                                     "p2p_fused": f"inside the product kernel: its seam workgroups load {peer.n_halo if peer else 0} "
                                                  "halo entries over xGMI from the neighbours' shared x slices "
@@ -414,15 +526,18 @@ def main():
                                     "p2p": f"per step: pull of {peer.n_halo if peer else 0} halo entries over xGMI from the "
                                            "neighbours' shared x slices (one kernel, no collective)",
                                     "all_gather": "per step: RCCL all_gather(x)"}[exchange],
+                       "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
                        "matrix_copies_rotated": copies, "launch": launch_mode, "untimed_preroll_replays": preroll, "design_point": design,
-                       "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info},
+                       "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info,
+                       "upload_seconds": round(upload_seconds, 4), "plan_seconds": round(plan_seconds, 4),
+                       "generate_seconds": round(gen_seconds, 2)},
             "hbm_gbs_algorithmic": round(achieved * world, 1),
             "hbm_pct_of_peak": round(100.0 * achieved / HBM_PEAK_GBS, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_spmv_" + design["variant"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "launch_usec": round(launch_us, 3)},
+                         "launch_usec": round(step_us, 3)},
             "warm_cache": {"usec_graph": round(warm_graph, 3) if warm_graph else None,
                            "gflops_graph": round(2.0 * nnz_local / warm_graph * 1e-3, 2) if warm_graph else None,
                            "usec_eager_median": round(warm_med, 3), "usec_eager_min": round(warm_min, 3),
@@ -431,19 +546,136 @@ def main():
                                    "launches), usec_eager_* are single launches between their own event pairs"},
         }
         if not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(rp, ci, va, x_host, y_gpu, args.cpu_seconds)
+            if weak or world == 1:
+                rec["cpu_baseline"] = cpu_baseline(rp, ci, va, x_host, y_gpu if world == 1 else None, args.cpu_seconds)
+            else:
+                rec["cpu_baseline"] = cpu_baseline(grp, gci, gva, x_host, None, args.cpu_seconds)
         else:
             rec["cpu_baseline"] = None
-        print(json.dumps(rec), flush=True)
     if use_dist:
-        host_barrier()
+        cx.host_barrier()
         if peer is not None:
+            from cask_amd import p2p
             for ptr in peer.peers.values():
                 p2p.close_peer(ptr)
             peer.peers = {}
-            host_barrier()                                       # owners free only after every peer has unmapped
+            cx.host_barrier()                                       # owners free only after every peer has unmapped
             peer.close()
-        dist.destroy_process_group()
+    return rec
+
+
+def run_solver(cx):
+    """CG / BiCG passes (BASELINE configs[2], [4]); row-sharded for N > 1."""
+    import torch
+    import torch.distributed as dist
+    from cask_amd import capi, synth
+    from cask_amd import dist as cdist
+    args, rank, world, dev, use_dist = cx.args, cx.rank, cx.world, cx.dev, cx.use_dist
+    kind = args.solver
+    name = args.workload
+    n, rp, ci, va, source = synth.load_or_make(name)
+    nnz = int(ci.size)
+    x_true = np.random.default_rng(5).uniform(-1, 1, n)          # b = A x_true: the reference harness (test_utils.hpp:61-70)
+    import oracle
+    b = oracle.csr_spmv(rp, ci, va, x_true)
+
+    forced = capi.make_params(variant=args.variant or 0, tile_width=args.tile, items_per_thread=args.items, wg_size=args.wg)
+    bounds = cdist.partition_rows_by_nnz(rp, world)
+    halo_frac, exchange = 0.0, "none"
+    sh = sht = None
+    trp = tci = tva = None
+    if kind == "bicg":
+        trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
+    if world > 1:
+        from cask_amd import p2p
+        lci = cdist.slice_rows(rp, ci, va, bounds[rank], bounds[rank + 1])[1]
+        _, halo_cols, _, _ = p2p.plan_halo(lci, bounds, rank)
+        halo_frac = cx.all_reduce_scalar(halo_cols.size / n, dist.ReduceOp.MAX)
+        want = os.environ.get("CASK_BENCH_EXCHANGE", "auto")
+        if want == "auto":
+            want = "all_gather" if halo_frac > HALO_FRACTION_FOR_ALLGATHER else "p2p"
+        exchange = "all_gather"
+        if want == "p2p":
+            fence = None
+            if cx.backend != "nccl":                                 # host-staged control plane: fence on the host
+                def fence():
+                    torch.cuda.synchronize()
+                    dist.barrier()
+            try:
+                sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, params=forced, exchange="p2p", fence=fence,
+                                                   fused_halo=True, solver_slots=6 if kind == "bicg" else 3, bounds=bounds)
+                if kind == "bicg":
+                    sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, params=forced, exchange="p2p",
+                                                        fence=fence, fused_halo=True, share_with=sh)
+                exchange = "p2p_fused"
+            except Exception as e:  # noqa: BLE001 - collective: raised on every rank or none
+                if rank == 0:
+                    print(f"[bench] in-kernel halos unavailable ({e!r}); all-gathering the operands", file=sys.stderr)
+                sh = sht = None
+    if sh is None:
+        sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, params=forced, bounds=bounds)
+        if kind == "bicg":
+            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, params=forced, bounds=bounds)
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    bl = torch.from_numpy(b[b0:b1].copy()).to(dev)
+
+    def solve(maxiters, tol):
+        if kind == "bicg":
+            return sh.bicg(sht, bl, maxiters=maxiters, tol=tol)
+        return sh.cg(bl, maxiters=maxiters, tol=tol)
+
+    # ---- the real solve, checked against the oracle ---------------------------------
+    xs, it, conv = solve(2000, 1e-5)
+    torch.cuda.synchronize()
+    x_all = xs.cpu().numpy()
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, x_all)
+        x_all = np.concatenate(parts)
+    check = None
+    if rank == 0:
+        res = float(np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, x_all)))
+        want_x, want_it, want_conv = (oracle.cg_full if kind == "cg" else oracle.bicg)(rp, ci, va, b)
+        check = {"iterations": it, "converged": conv, "oracle_iterations": want_it, "oracle_converged": want_conv,
+                 "residual_2norm_by_oracle_product": res, "max_abs_diff_vs_oracle_solution": float(np.abs(x_all - want_x).max())}
+    # ---- warm-up + timed region: exactly K passes (tol = 0 never converges) -----------
+    if args.warmup:
+        solve(args.warmup, 0.0)
+    dev_ms, wall = timed_region(cx, lambda: solve(args.steps, 0.0))
+    rec = None
+    if rank == 0:
+        step_us = dev_ms * 1e3 / args.steps
+        b_spmv = synth.algorithmic_bytes(n, n, nnz)
+        b_it = b_spmv + 96 * n if kind == "cg" else 2 * b_spmv + 152 * n      # SURVEY 8(d), unfused algorithmic bytes
+        f_it = 2 * nnz + 12 * n if kind == "cg" else 4 * nnz + 20 * n
+        achieved = b_it / world / (step_us * 1e-6) / 1e9                       # per GPU
+        rec = {
+            "metric": f"{kind.upper()} pass GFLOP/s (fp64, {'2 nnz + 12 n' if kind == 'cg' else '4 nnz + 20 n'} flop per pass), "
+                      f"SuiteSparse {name}-like",
+            "value": round(f_it / step_us * 1e-3, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_us * 1e-3, 6), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if source == "synthetic" else source,
+            "host_wall_ms_per_step": round(wall * 1e3 / args.steps, 6),
+            "config": {"workload": f"{kind} on the {name}-like system, {n} rows, {nnz} nnz, b = A x0, one step = one pass",
+                       "rows": n, "nnz": nnz, "parallelism": f"row-blocks x{world} (nnz-balanced)",
+                       "exchange": {"none": "none", "p2p_fused": "halos read inside the product kernels over xGMI; dot products: "
+                                    "RCCL all_reduce of device scalars (2 collectives per pass)",
+                                    "all_gather": "per product: RCCL all_gather of the operand; dot products: RCCL all_reduce"}[exchange],
+                       "halo_fraction_max": round(halo_frac, 4) if world > 1 else None,
+                       "solve_check": check, "design_point": sh.matrix.params.as_dict(),
+                       "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                         "kernel": f"{kind} pass (k_spmv_merge + update kernels)",
+                         "algorithmic_bytes_per_launch": b_it // world, "launch_usec": round(step_us, 3)},
+        }
+        rec["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_solver(kind, rp, ci, va, b, args.cpu_seconds)
+    if world > 1:
+        cx.host_barrier()
+        if sht is not None and sht.exchange is sh.exchange:
+            sht.exchange = None
+        sh.close()
+    return rec
 
 
 if __name__ == "__main__":

@@ -88,6 +88,16 @@ struct Plan {
   DevBuf<int2v> xspan;
 };
 
+// Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
+// over a few passes -- must not pay a dozen allocations per call).
+struct SolverWorkspace {
+  int64_t n = -1, S = 0, n_full = 0;
+  int n_slots = 0;
+  bool shared_vec = false;
+  DevBuf<double> own_vec, q, qt, part_a, part_b, part_c, scal, x_full, x_full_t;
+  DevBuf<int> flags;
+};
+
 }  // namespace
 
 struct cask_hip_matrix {
@@ -110,6 +120,7 @@ struct cask_hip_matrix {
   hipStream_t stream = nullptr;    // for the host-vector entry points and timing
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
   std::unique_ptr<cask_hip_matrix> transpose;
+  std::unique_ptr<SolverWorkspace> solver_ws;
   ~cask_hip_matrix() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1346,33 +1357,45 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_slots = bicg ? 6 : 3;
   // vectors peers may read live in the caller's shared allocation, `stride` doubles per slot
-  DevBuf<double> own_vec;
   double *base = cfg.d_shared_base;
   st.S = cfg.stride;
   if (!base) {
     st.S = (n + 31) / 32 * 32;
     if (st.S == 0) st.S = 32;
-    HIP_TRY(own_vec.alloc((size_t)(st.S * n_slots)));
-    base = own_vec.p;
   } else {
     if (st.S < n || (st.S & 1)) return fail(CASK_HIP_ERR_INVALID, "stride must be even and at least the block's row count");
     if (reinterpret_cast<uintptr_t>(base) & 15) return fail(CASK_HIP_ERR_INVALID, "shared base must be 16-byte aligned");
     st.sys_scope = 1;
   }
+  if (!m->solver_ws) m->solver_ws.reset(new SolverWorkspace);
+  SolverWorkspace &ws = *m->solver_ws;
+  const int64_t want_full = st.exchange ? cfg.n_full : 0;
+  if (ws.n != n || ws.S != st.S || ws.n_slots != n_slots || ws.shared_vec != (cfg.d_shared_base != nullptr) ||
+      ws.n_full != want_full) {
+    ws.n = -1;                                                // (re)build; a failed allocation leaves it invalid
+    if (!cfg.d_shared_base) HIP_TRY(ws.own_vec.alloc((size_t)(st.S * n_slots))); else ws.own_vec.release();
+    HIP_TRY(ws.q.alloc(n));
+    if (bicg) HIP_TRY(ws.qt.alloc(n)); else ws.qt.release();
+    HIP_TRY(ws.part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(ws.part_b.alloc(BLAS_MAX_PARTIALS));
+    HIP_TRY(ws.part_c.alloc(BLAS_MAX_PARTIALS));
+    HIP_TRY(ws.scal.alloc(SC_COUNT)); HIP_TRY(ws.flags.alloc(2));
+    if (want_full) {
+      HIP_TRY(ws.x_full.alloc((size_t)want_full));
+      if (bicg) HIP_TRY(ws.x_full_t.alloc((size_t)want_full)); else ws.x_full_t.release();
+    } else {
+      ws.x_full.release();
+      ws.x_full_t.release();
+    }
+    ws.n = n; ws.S = st.S; ws.n_slots = n_slots; ws.shared_vec = cfg.d_shared_base != nullptr; ws.n_full = want_full;
+  }
+  if (!base) base = ws.own_vec.p;
   auto slot = [&](int k) { return base + (int64_t)k * st.S; };
   double *r = slot(SLOT_R), *rt = bicg ? slot(SLOT_RT) : nullptr;
-  DevBuf<double> q, qt, part_a, part_b, part_c, scal, x_full, x_full_t;
-  DevBuf<int> flags;
-  HIP_TRY(q.alloc(n));
-  if (bicg) HIP_TRY(qt.alloc(n));
-  HIP_TRY(part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_b.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(part_c.alloc(BLAS_MAX_PARTIALS));
-  HIP_TRY(scal.alloc(SC_COUNT)); HIP_TRY(flags.alloc(2));
+  DevBuf<double> &q = ws.q, &qt = ws.qt, &part_a = ws.part_a, &part_b = ws.part_b, &part_c = ws.part_c, &scal = ws.scal,
+                 &x_full = ws.x_full, &x_full_t = ws.x_full_t;
+  DevBuf<int> &flags = ws.flags;
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
-  if (st.exchange) {
-    HIP_TRY(x_full.alloc((size_t)cfg.n_full));
-    if (bicg) HIP_TRY(x_full_t.alloc((size_t)cfg.n_full));
-  }
   int *done = flags.p, *iters = flags.p + 1;
   const int g = blas_grid(n);
   const dim3 bg(g), bw(BLAS_WG);

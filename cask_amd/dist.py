@@ -151,7 +151,7 @@ class ShardedSpmv:
         """all-gather of the x slices into ``out`` (default: self.x_full); uneven slices are padded to the longest."""
         import torch.distributed as dist
         out = self.x_full if out is None else out
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             out.copy_(x_local)
             return out
         if self.even:
@@ -243,7 +243,7 @@ class ShardedSpmv:
         """``exchange(local_ptr, full_ptr, stream) -> 0``: the all-gather of an operand (classic passes on blocks
         with global column indices)."""
         import torch.distributed as dist
-        stream_ordered = self.world == 1 or dist.get_backend(self.group) == "nccl"
+        stream_ordered = dist.get_backend(self.group) == "nccl"
         views = {}
 
         def exchange(local_ptr, full_ptr, stream):
@@ -267,8 +267,12 @@ class ShardedSpmv:
             raise RuntimeError("the sharded solvers run on the HIP engine: build the operator with from_global()")
         x = torch.zeros_like(b_local) if x_local is None else x_local.clone()
         kw = {}
-        if self.world > 1:
-            import torch.distributed as dist
+        import os
+        import torch.distributed as dist
+        # CASK_FORCE_COLLECTIVES: take the row-sharded path (callbacks, RCCL collectives) with a single rank -- how the
+        # nccl backend is exercised on a 1-GPU box
+        collective = self.world > 1 or (bool(os.environ.get("CASK_FORCE_COLLECTIVES")) and dist.is_initialized())
+        if collective:
             kw["allreduce"] = self._allreduce_callback()
             if mode == capi.SOLVER_AUTO:
                 # every rank must run the same form of pass (same collectives): composed only if every rank's
@@ -285,7 +289,7 @@ class ShardedSpmv:
             if transposed is not None and transposed.exchange is not ex:
                 raise RuntimeError("A and A^T must share one PeerExchange (from_global(..., share_with=...))")
             kw.update(shared_base=ex.shared.ptr, stride=ex.stride)
-        elif self.world > 1:
+        elif collective:
             kw.update(exchange=self._exchange_callback(), n_full=self.n)
         it, conv, us = self.matrix.solve_device(b_local.contiguous(), x, kind=kind,
                                                 transposed=transposed.matrix if transposed is not None else None,

@@ -131,6 +131,68 @@ def atmosmodd_like(n=1_270_432, nx=108, ny=108, seed=4):
     return n, rp, ci, va
 
 
+def cant3_like(nx=9, ny=9, nz=257, order="z_fastest", seed=6):
+    """A second cant look-alike, closer to the real FEM matrix: a 9 x 9 x 257 hexahedral mesh of a
+    cantilever beam (20 817 nodes x 3 dof = 62 451 rows, the real dimension), 27-point node stencil, every node
+    pair coupled by a DENSE 3 x 3 block (~69 nnz per row, 4.3 M nnz; the real cant: 64 and 4.0 M), symmetric
+    positive definite (random symmetric blocks + diagonal dominance).  ``order="z_fastest"`` numbers the nodes
+    along the beam first: the band is then wide and non-uniform (node offsets +-1, +-257 and +-2313 in
+    clusters: three bands 7.7 K columns apart) -- not the one +-400 window of ``cant_like``;
+    ``"x_fastest"`` gives the narrow band (+-273 columns)."""
+    rng = np.random.default_rng(seed)
+    n_nodes = nx * ny * nz
+    X, Y, Z = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    X, Y, Z = X.ravel(), Y.ravel(), Z.ravel()
+
+    def node_id(x, y, z):
+        return (x * ny + y) * nz + z if order == "z_fastest" else x + nx * (y + ny * z)
+
+    me = node_id(X, Y, Z)
+    pa, pb = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if (dx, dy, dz) <= (0, 0, 0):
+                    continue                                   # each undirected pair once
+                ok = (X + dx >= 0) & (X + dx < nx) & (Y + dy >= 0) & (Y + dy < ny) & (Z + dz >= 0) & (Z + dz < nz)
+                pa.append(me[ok])
+                pb.append(node_id(X[ok] + dx, Y[ok] + dy, Z[ok] + dz))
+    pa, pb = np.concatenate(pa), np.concatenate(pb)
+    # off-diagonal node pairs: a dense 3x3 block B at (a, b) and B^T at (b, a)
+    blk = rng.standard_normal((pa.size, 3, 3))
+    i3, j3 = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
+    rows_ab = (3 * pa[:, None, None] + i3).ravel()
+    cols_ab = (3 * pb[:, None, None] + j3).ravel()
+    vals_ab = blk.ravel()
+    # diagonal node blocks: symmetric, strictly dominant
+    n = 3 * n_nodes
+    absum = np.zeros(n)
+    np.add.at(absum, rows_ab, np.abs(vals_ab))
+    np.add.at(absum, cols_ab, np.abs(vals_ab))
+    dblk = rng.standard_normal((n_nodes, 3, 3))
+    dblk = 0.5 * (dblk + dblk.transpose(0, 2, 1))
+    nodes = np.arange(n_nodes)
+    rows_d = (3 * nodes[:, None, None] + i3).ravel()
+    cols_d = (3 * nodes[:, None, None] + j3).ravel()
+    vals_d = dblk.ravel().copy()
+    offd = np.abs(dblk).sum(axis=2) - np.abs(dblk[:, [0, 1, 2], [0, 1, 2]])
+    on_diag = rows_d == cols_d
+    vals_d[on_diag] = 1.0 + absum + offd.ravel()
+    R = np.concatenate([rows_ab, cols_ab, rows_d])
+    C = np.concatenate([cols_ab, rows_ab, cols_d])
+    V = np.concatenate([vals_ab, vals_ab, vals_d])
+    rp, ci, va = _coo_to_csr(n, R, C, V)
+    return n, rp, ci, va
+
+
+def cant3_like_shard(rank, world):
+    """cant3_like as a bench workload: one GPU only (the weak-scaling seam construction exists for cant_like)."""
+    if world != 1:
+        raise ValueError("the cant3 workload is defined for one GPU")
+    n, rp, ci, va = cant3_like()
+    return n, n, rp, ci, va
+
+
 GENERATORS = {"cant": cant_like, "G3_circuit": g3_like, "webbase-1M": webbase_like, "atmosmodd": atmosmodd_like}
 
 

@@ -29,29 +29,89 @@ def last_json_line(text):
     return json.loads(lines[-1])
 
 
+def run_bench(extra, env=None, world=1, timeout=900):
+    cmd = [sys.executable]
+    if world > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(free_port())]
+    cmd += [str(REPO / "bench.py"), "--gpus", str(world)] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr[-3000:]
+    return last_json_line(out.stdout)
+
+
+SHARE = {"CASK_BENCH_SHARE_DEVICE": "1", "CASK_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"}
+
+
 def test_single_rank_line():
-    out = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "20", "--warmup", "4", "--no-tune",
-                          "--copies", "3", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rec = last_json_line(out.stdout)
+    rec = run_bench(["--steps", "20", "--warmup", "4", "--no-tune", "--copies", "3", "--cpu-seconds", "0.5"])
     assert CONTRACT_KEYS <= set(rec)
     assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["dtype"] == "f64" and rec["value"] > 100
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["parity_gpu_vs_cpu_mismatches"] == 0
+    # ONE clock: value, ms_per_step and the roofline all derive from the same device-event time
+    assert abs(rec["ms_per_step"] * 1e3 - roof["launch_usec"]) < 1e-2
+    assert abs(rec["value"] - 2.0 * rec["config"]["nnz"] / roof["launch_usec"] * 1e-3) <= 0.01 * rec["value"]
+    assert roof["traffic"] is None or "profiles/" in roof["traffic_source"]
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] in ("mkl", "port") and cpu["parity_gpu_vs_cpu_mismatches"] == 0 and cpu["cores"] >= 1
+    if cpu["kind"] == "mkl":
+        assert cpu["mismatches_vs_oracle"] == 0 and cpu["port"]["kind"] == "port" and cpu["port"]["cores"] == 1
+    assert rec["config"]["plan_seconds"] > 0 and rec["config"]["upload_seconds"] > 0
     assert "workload" in rec["config"] and "model" not in rec["config"]
 
 
 def test_two_rank_dry_run_reads_halos_in_kernel():
-    env = dict(os.environ, CASK_BENCH_SHARE_DEVICE="1", CASK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", "20",
-           "--warmup", "4", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    rec = last_json_line(out.stdout)
+    rec = run_bench(["--steps", "20", "--warmup", "4", "--no-tune", "--copies", "2", "--no-cpu-baseline"], SHARE, world=2)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["exchange"].startswith("inside the product kernel"), rec["config"]["exchange"]
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     assert rec["config"]["rows"] == 2 * 62451
+
+
+def test_rccl_collectives_run_at_world_one():
+    """the nccl (= RCCL) backend itself -- init_process_group("nccl"), all_gather_into_tensor of x
+    and all_reduce of scalars on the device -- with the one rank a 1-GPU box allows: the config-4 step (all-gather +
+    product) and the config-5 solver pass (operand all-gather + all-reduced dots through the engine's callbacks)."""
+    env = {"CASK_BENCH_FORCE_DIST": "1", "CASK_BENCH_EXCHANGE": "all_gather", "CASK_FORCE_COLLECTIVES": "1",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
+                     "--no-cpu-baseline"], env)
+    assert rec["config"]["exchange"] == "per step: RCCL all_gather(x)" and rec["config"]["launch"] == "eager"
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    env["MASTER_PORT"] = str(free_port())
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
+    chk = rec["config"]["solve_check"]
+    assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
+    assert chk["residual_2norm_by_oracle_product"] <= 2e-5
+
+
+def test_config4_webbase_row_partitioned_dry_run():
+    """BASELINE configs[3] as bench.py runs it on N GPUs, here 4 ranks sharing the GPU (gloo): one global matrix,
+    nnz-balanced row blocks, the all-gather exchange its halo fraction selects, every rank's rows against the oracle."""
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
+                     "--no-cpu-baseline"], SHARE, world=4)
+    assert rec["n_gpus"] == 4 and rec["scaling"] == "strong" and rec["config"]["rows"] == 1_000_005
+    assert rec["config"]["exchange"] == "per step: RCCL all_gather(x)"
+    assert rec["config"]["halo_fraction_max"] > 0.10
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+
+
+def test_config5_atmosmodd_bicg_sharded_dry_run():
+    """BASELINE configs[4]: BiCG on the full atmosmodd-like system, A and A^T row-sharded over 4 ranks sharing the GPU,
+    halos read in-kernel, dots all-reduced; iteration count and true residual against the oracle."""
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
+                    SHARE, world=4)
+    assert rec["n_gpus"] == 4 and rec["config"]["exchange"].startswith("halos read inside the product kernels")
+    chk = rec["config"]["solve_check"]
+    assert chk["converged"] and chk["oracle_converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
+    assert chk["residual_2norm_by_oracle_product"] <= 5e-5 and chk["max_abs_diff_vs_oracle_solution"] <= 1e-5
+
+
+def test_config3_cg_full_size_single_gpu_line():
+    rec = run_bench(["--steps", "32", "--warmup", "2", "--workload", "G3_circuit", "--solver", "cg", "--cpu-seconds", "1"])
+    chk = rec["config"]["solve_check"]
+    assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
+    assert chk["residual_2norm_by_oracle_product"] <= 2e-5
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["value"] > 100
