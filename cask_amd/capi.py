@@ -45,7 +45,7 @@ PRECOND_JACOBI, PRECOND_ILU0, PRECOND_ILU0_UNIT = 1, 2, 3
 class Params(Structure):
     _fields_ = [("variant", c_int32), ("lanes_per_row", c_int32), ("tile_width", c_int32),
                 ("wg_size", c_int32), ("items_per_thread", c_int32), ("xcd_remap", c_int32),
-                ("nontemporal", c_int32), ("index16", c_int32)]
+                ("nontemporal", c_int32), ("index16", c_int32), ("far_columns", c_int32)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -167,10 +167,11 @@ def device_props(device: int = 0) -> dict:
 
 
 def make_params(variant=0, lanes_per_row=0, tile_width=0, wg_size=0, items_per_thread=0,
-                xcd_remap=0, nontemporal=0, index16=0) -> Params:
+                xcd_remap=0, nontemporal=0, index16=0, far_columns=0) -> Params:
     if isinstance(variant, str):
         variant = {v: k for k, v in VARIANT_NAMES.items()}[variant]
-    return Params(variant, lanes_per_row, tile_width, wg_size, items_per_thread, xcd_remap, nontemporal, index16)
+    return Params(variant, lanes_per_row, tile_width, wg_size, items_per_thread, xcd_remap, nontemporal, index16,
+                  far_columns)
 
 
 def _np(a, dtype):

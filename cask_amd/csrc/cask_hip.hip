@@ -84,6 +84,12 @@ struct Plan {
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
   DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y
+  // far columns (MERGE with slot indices): x values of the nonzeros outside their block's tile, pre-gathered
+  // column panel by column panel (k_far_gather) into farx, block-major
+  int n_far = 0, far_grid = 0;
+  FarPanels far_panels{};
+  DevBuf<int> far_col, far_dst;
+  DevBuf<double> farx;
   // VECTOR
   DevBuf<int2v> xspan;
 };
@@ -163,6 +169,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.index16 == 0) out.index16 = 1;
   if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
+  if (out.far_columns < -1 || out.far_columns > 1) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0 or 1");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
@@ -260,44 +267,93 @@ int ensure_host_col_ind(cask_hip_matrix &m) {
   return CASK_HIP_OK;
 }
 
+// With `far` the tile of a block keeps only the chunks several of its nonzeros share; the nonzeros of the other
+// chunks ("far": the scattered columns of a power-law block, the long-range edges of a circuit matrix) get
+// slots of their own behind the chunks, one per nonzero, and their x values arrive through the pre-gather launch.
+// A chunk with r references costs 64 slots and 512 bytes of window loads; r far slots cost r slots and ~30 bytes
+// each -- so chunks with r <= FAR_REFS are always far, and the least referenced ones follow until the block fits.
+// far_of[b] lists the block's far nonzeros in (column panel, nonzero) order; d.cmin = their number.
+constexpr int FAR_REFS = 2;
 void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks, int max_chunks,
-                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16) {
+                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16,
+                       bool far, std::vector<std::vector<int>> *far_of) {
   constexpr int GAP = 32;
   const int *ci = m.h_ci.data();
   ci16.assign((size_t)m.nnz + 8, 0);
   chunk_starts.assign(blocks.size(), {});
+  if (far_of) far_of->assign(blocks.size(), {});
+  const int panel_width = std::max(1, (m.n_cols + FAR_PANELS - 1) / FAR_PANELS);
   auto work = [&](size_t b0, size_t b1) {
-    std::vector<int> uniq, starts;
+    std::vector<int> uniq, starts, refs, order;
+    std::vector<char> keep;
     for (size_t b = b0; b < b1; b++) {
       BlockDesc &d = blocks[b];
       d.cwidth = 0;
       if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
       const int k0 = d.nnz_start, k1 = d.nnz_start + d.nnz_count;
       uniq.assign(ci + k0, ci + k1);
-      std::sort(uniq.begin(), uniq.end());
-      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+      std::sort(uniq.begin(), uniq.end());                   // with duplicates: references per chunk are counted below
       starts.clear();
-      bool fits = true;
+      refs.clear();
       size_t i = 0;
-      while (i < uniq.size() && fits) {
+      while (i < uniq.size()) {
         size_t j = i;
         while (j + 1 < uniq.size() && uniq[j + 1] - uniq[j] <= GAP) j++;
-        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) {     // even starts: the kernel loads the tile in 16-byte pairs
-          if ((int)starts.size() == max_chunks) { fits = false; break; }
-          starts.push_back(c);
+        size_t e = i;                                         // even starts: the kernel loads the tile in 16-byte pairs
+        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) {
+          int r = 0;
+          while (e <= j && uniq[e] < c + 64) { r++; e++; }
+          if (r > 0 || !far) { starts.push_back(c); refs.push_back(r); }
         }
         i = j + 1;
       }
-      if (!fits) continue;
-      d.cmin = starts.front();
-      d.cwidth = (int)starts.size() * 64;
-      bool contiguous = true;
+      int n_far = 0;
+      keep.assign(starts.size(), 1);
+      if (far) {
+        size_t kept = starts.size();
+        for (size_t c = 0; c < starts.size(); c++)
+          if (refs[c] <= FAR_REFS) { keep[c] = 0; kept--; n_far += refs[c]; }
+        if ((long)kept * 64 + n_far > (long)max_chunks * 64) {
+          order.resize(starts.size());
+          for (size_t c = 0; c < starts.size(); c++) order[c] = (int)c;
+          std::sort(order.begin(), order.end(), [&](int a, int bb) { return refs[a] != refs[bb] ? refs[a] < refs[bb] : a < bb; });
+          for (int c : order) {
+            if ((long)kept * 64 + n_far <= (long)max_chunks * 64) break;
+            if (!keep[c]) continue;
+            keep[c] = 0; kept--; n_far += refs[c];
+          }
+        }
+        if ((long)kept * 64 + n_far > (long)max_chunks * 64) continue;     // does not fit even so: gathers from L2
+        size_t w = 0;
+        for (size_t c = 0; c < starts.size(); c++)
+          if (keep[c]) starts[w++] = starts[c];
+        starts.resize(w);
+      } else if ((int)starts.size() > max_chunks) {
+        continue;
+      }
+      const int tile_slots = (int)starts.size() * 64;
+      d.cmin = starts.empty() ? 0 : starts.front();
+      d.cwidth = tile_slots + n_far;
+      bool contiguous = !starts.empty();
       for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
-      if (contiguous) d.kind_g |= KIND_CONTIG;
+      if (contiguous && n_far == 0) d.kind_g |= KIND_CONTIG;
+      std::vector<int> *fl = far_of ? &(*far_of)[b] : nullptr;
       for (int k = k0; k < k1; k++) {
         const int c = ci[k];
         const int idx = (int)(std::upper_bound(starts.begin(), starts.end(), c) - starts.begin()) - 1;
-        ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
+        if (idx >= 0 && c < starts[idx] + 64) ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
+        else fl->push_back(k);                                // far (only reachable with `far`)
+      }
+      // chunks of neighbouring ranges may overlap: a nonzero of a dropped chunk that a kept chunk also covers
+      // is served by the tile after all, so the far count is what the lookup above found (never more than planned)
+      n_far = fl ? (int)fl->size() : 0;
+      d.cwidth = tile_slots + n_far;
+      if (n_far > 0) {
+        // (column panel, nonzero) order: the order the pre-gather launch produces them in within a block
+        std::stable_sort(fl->begin(), fl->end(), [&](int a, int bb) { return ci[a] / panel_width < ci[bb] / panel_width; });
+        for (int j = 0; j < n_far; j++) ci16[(*fl)[j]] = (unsigned short)(tile_slots + j);
+        d.kind_g |= KIND_FAR;
+        d.cmin = n_far;                                       // the chunked window path does not use cmin
       }
       chunk_starts[b] = starts;
     }
@@ -447,6 +503,10 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.dot_part.release();
   pl.xspan.release();
   pl.n_long_rows = pl.n_split_rows = 0;
+  pl.n_far = pl.far_grid = 0;
+  pl.far_col.release();
+  pl.far_dst.release();
+  pl.farx.release();
   pl.grid = 0;
   pl.lds_bytes = 0;
   pl.ldsx = false;
@@ -510,15 +570,63 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       int xu_cap = 8;
       while (xu_cap > 0 && base_lds + 8 * xu_cap * prm.wg_size > MAX_LDS_BYTES) xu_cap /= 2;
       const int max_slots = std::min(tile, xu_cap * prm.wg_size);
-      std::vector<std::vector<int>> chunk_starts;
+      std::vector<std::vector<int>> chunk_starts, far_of;
       std::vector<unsigned short> ci16;
-      build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16);
+      // far columns: never with halo sources (their x values live on peers).  Opt-in (far_columns = 1): measured
+      // on every BASELINE family (profiles/r02_far_columns.txt) the pre-gather launch costs more than it saves --
+      // webbase-1M-like: product 24.4 -> 19.5-21.3 us, but the gather launch is two dependent memory round trips
+      // with little parallelism (9.4 us for 23 MB), 29-31 us in all; G3_circuit-like 22.1 -> 27.3 us.  It does cut
+      // the fabric traffic, which is what the column panels are for; it does not cut the time.
+      bool far = prm.far_columns == 1 && !m.halo_addr && max_slots <= 65536;
+      long n_far = 0;
+      if (far) {
+        std::vector<BlockDesc> trial = blocks;
+        build_chunk_tiles(m, trial, max_slots / 64, chunk_starts, ci16, true, &far_of);
+        for (const auto &f : far_of) n_far += (long)f.size();
+        if (n_far == 0 || (prm.far_columns == 0 && n_far * 20 < m.nnz)) {
+          far = false;
+          n_far = 0;
+        } else {
+          blocks = trial;
+        }
+      }
+      if (!far) build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16, false, nullptr);
+      pl.prm.far_columns = far ? 1 : -1;
+      if (far) {
+        // farx is block-major (one coalesced run per block); the pre-gather walks the far nonzeros sorted by column
+        // panel, then block, then nonzero -- the order far_of already has inside a block
+        const int panel_width = std::max(1, (m.n_cols + FAR_PANELS - 1) / FAR_PANELS);
+        std::vector<int> base(blocks.size() + 1, 0);
+        for (size_t b = 0; b < blocks.size(); b++) base[b + 1] = base[b] + (int)far_of[b].size();
+        std::vector<int> count(FAR_PANELS + 1, 0);
+        for (const auto &f : far_of)
+          for (int k : f) count[m.h_ci[k] / panel_width + 1]++;
+        for (int p = 0; p < FAR_PANELS; p++) count[p + 1] += count[p];
+        std::vector<int> fill(count.begin(), count.end() - 1), fcol((size_t)n_far), fdst((size_t)n_far);
+        for (size_t b = 0; b < blocks.size(); b++) {
+          for (size_t j = 0; j < far_of[b].size(); j++) {
+            const int k = far_of[b][j], p = m.h_ci[k] / panel_width, at = fill[p]++;
+            fcol[at] = m.h_ci[k];
+            fdst[at] = base[b] + (int)j;
+          }
+          if (!far_of[b].empty()) blocks[b].aux = base[b];
+        }
+        int per_panel = 0;
+        for (int p = 0; p <= FAR_PANELS; p++) pl.far_panels.start[p] = count[p];
+        for (int p = 0; p < FAR_PANELS; p++) per_panel = std::max(per_panel, (count[p + 1] - count[p] + FAR_CHUNK - 1) / FAR_CHUNK);
+        pl.n_far = (int)n_far;
+        pl.far_grid = per_panel * FAR_PANELS;
+        HIP_TRY(pl.far_col.upload(fcol));
+        HIP_TRY(pl.far_dst.upload(fdst));
+        HIP_TRY(pl.farx.alloc((size_t)n_far));
+      }
       if (m.halo_addr) place_seam_blocks(m, blocks, chunk_starts, prm.xcd_remap > 0);
-      int max_chunks = 0;
-      for (const auto &c : chunk_starts) max_chunks = std::max(max_chunks, (int)c.size());
-      if (max_chunks > 0) {
+      int max_used = 0;                                       // slots of the fullest tile (chunks + far slots)
+      for (const BlockDesc &d : blocks)
+        if (!(d.kind_g & KIND_LONG)) max_used = std::max(max_used, d.cwidth);
+      if (max_used > 0) {
         int xu = 1;
-        while (xu * prm.wg_size < max_chunks * 64) xu *= 2;
+        while (xu * prm.wg_size < max_used) xu *= 2;
         pl.xu = xu;
         pl.maxch = xu * prm.wg_size / 64;
         pl.prm.tile_width = xu * prm.wg_size;
@@ -637,6 +745,12 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.lds_bytes = pl.lds_bytes + ((dot.w || pass) ? dot_lds_bytes(pl.prm.wg_size) : 0);
   l.solver_pass = pass != nullptr;
   if (pass) l.pass = *pass;
+  l.farx = nullptr;
+  if (pl.n_far > 0) {                                         // x values of the far nonzeros, panel by panel
+    hipLaunchKernelGGL(k_far_gather, dim3(pl.far_grid), dim3(256), 0, s, pl.far_panels, pl.far_col.p, pl.far_dst.p, x,
+                       pl.farx.p);
+    l.farx = pl.farx.p;
+  }
   l.xu = pl.xu;
   l.remap = pl.prm.xcd_remap > 0;
   l.n_cols = m.n_cols;
@@ -989,7 +1103,7 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out) {
   out->empty_rows = m->empty_rows;
   out->mean_row_nnz = m->n_rows ? (double)m->nnz / m->n_rows : 0.0;
   out->algorithmic_bytes = 12 * m->nnz + 4 * ((int64_t)m->n_rows + 1) + 8 * (int64_t)m->n_cols + 8 * (int64_t)m->n_rows;
-  out->fuses_dot = plan_fuses_dot(m->plan) ? 1 : 0;
+  out->fuses_dot = plan_fuses_dot(m->plan) && m->plan.n_far == 0 ? 1 : 0;
   return CASK_HIP_OK;
 }
 
@@ -1338,7 +1452,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     }
     if (st.At->n_rows != m->n_rows) return fail(CASK_HIP_ERR_INVALID, "A and A^T blocks differ in their row count");
   }
-  const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange;
+  const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange &&
+                           m->plan.n_far == 0 && (!bicg || st.At->plan.n_far == 0);   // far slots carry a plain operand
   if (cfg.mode == CASK_HIP_SOLVER_COMPOSED && !can_compose)
     return fail(CASK_HIP_ERR_INVALID, "composed passes need MERGE plans with the dot epilogue (and no exchange callback)");
   // AUTO: measured on one GPU (profiles/r02_solver_modes.txt) the composed pass LOSES to the classic one --

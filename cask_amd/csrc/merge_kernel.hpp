@@ -202,14 +202,15 @@ __device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassSc
   }
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool FAR>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
                                            double *prod, int *roff, double *xs, const XHalo &halo,
                                            const double *__restrict__ w, double *wl, int lb,
-                                           const SolverPass &sp, const PassScalars &ps) {
+                                           const SolverPass &sp, const PassScalars &ps,
+                                           const double *__restrict__ farx) {
   const int WG = blockDim.x, tid = threadIdx.x;
 #if defined(CASK_ABL) && (CASK_ABL & 2)                       // diagnostic build: what does the second window cost?
   constexpr bool COMP = false;
@@ -274,6 +275,17 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
           xb[COMP ? 2 * u : 0] = pb.x;
           xb[COMP ? 2 * u + 1 : 0] = pb.y;
         }
+      }
+    } else if (FAR && (d.kind_g & KIND_FAR)) {                // workgroup-uniform
+      // far slots: behind the block's chunks sit the x values of its far columns, gathered column panel by column
+      // panel by k_far_gather into farx[d.aux ...] just before this launch (d.cmin of them)
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+      const int tile_slots = d.cwidth - d.cmin, last_far = max(d.cmin - 1, 0);
+#pragma unroll
+      for (int u = 0; u < XU; u++) {
+        const int cidx = u * wpw + wave;                      // wave-uniform chunk index; slot = 64*cidx + lane
+        if (cidx * 64 < tile_slots) xw[u] = x[min(xchunk[cidx] + lane, xlim)];
+        else                        xw[u] = farx[d.aux + min(cidx * 64 + lane - tile_slots, last_far)];
       }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
@@ -476,14 +488,15 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs,
                                             const XHalo &halo, const DotEpilogue &dot, int lb,
-                                            const SolverPass &sp, const PassScalars &ps) {
+                                            const SolverPass &sp, const PassScalars &ps,
+                                            const double *__restrict__ farx) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
   // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
@@ -496,11 +509,11 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                            halo, wsrc, wl, lb, sp, ps);
+    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                            halo, wsrc, wl, lb, sp, ps, farx);
   else
-    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                             halo, wsrc, wl, lb, sp, ps);
+    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                             halo, wsrc, wl, lb, sp, ps, farx);
   const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
 
   double dsum;
@@ -532,13 +545,14 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 // halo sources.  Ordinary products run EXT = 0, which contains none of that code: a kernel this close to the
 // memory system's limits pays for every extra branch, register and byte of LDS (measured while adding them:
 // +1 to +6 %).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
+// FAR: the plan has blocks with far slots (KIND_FAR; plans without any run the instantiation without that code).
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
-                             PassArg<EXT> pass_arg) {
+                             PassArg<EXT> pass_arg, const double *__restrict__ farx) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
@@ -645,11 +659,11 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                             xs, halo, dot, lb, sp, ps);
+    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                             xs, halo, dot, lb, sp, ps, farx);
   else
-    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                              xs, halo, dot, lb, sp, ps);
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                              xs, halo, dot, lb, sp, ps, farx);
   CASK_STAMP(5);
 }
 

@@ -25,6 +25,7 @@ struct MergeLaunch {
   DotEpilogue dot;
   bool solver_pass;                // EXT == 2 launch: `pass` describes the composed operand and the scalars
   SolverPass pass;
+  const double *farx;              // plans with far slots: the x values k_far_gather left for them; else NULL
 };
 
 template <int IPT>

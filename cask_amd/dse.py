@@ -117,7 +117,7 @@ def explore(mats, x_t, y_t, points=None, steps=60, reps=3):
             best = row
     if best is not None:
         keys = ("variant", "lanes_per_row", "tile_width", "wg_size", "items_per_thread", "xcd_remap",
-                "nontemporal", "index16")
+                "nontemporal", "index16", "far_columns")
         prm = capi.make_params(**{k: best[k] for k in keys})
         for m in mats:
             m.set_params(prm)
@@ -138,7 +138,7 @@ def write_dse_out(path, entries, took):
             "measured_gbs_algorithmic": b["gbs_algorithmic"],
             "pct_hbm_peak": b["pct_hbm_peak"],
             "architecture_params": {k: b[k] for k in ("variant", "lanes_per_row", "tile_width", "wg_size",
-                                                      "items_per_thread", "xcd_remap", "nontemporal", "index16")},
+                                                      "items_per_thread", "xcd_remap", "nontemporal", "index16", "far_columns")},
             "launch": {"grid": b["grid"], "lds_bytes": b["lds_bytes"]},
             "matrices": [e["matrix"]],
             "points_evaluated": e["points"],

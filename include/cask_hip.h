@@ -56,6 +56,11 @@ typedef struct cask_hip_params {
   int32_t index16;          /* MERGE with an x tile: 1 = stream tile-relative slot indices instead of 32-bit columns
                              * (12 bits each, packed per thread, where the kernel has that layout; else 16 bits),
                              * 2 = 16-bit slots only, -1 = off */
+  int32_t far_columns;      /* MERGE with slot indices: nonzeros whose columns lie outside a block's tile ("far") are
+                             * served from a side buffer that a pre-gather launch fills column panel by column panel
+                             * (one panel of x per XCD's L2) -- the reference's column blocking (SparseMatrix.hpp:459-482)
+                             * applied to the scattered part only.  1 = on, 0 / -1 = off (measured: the extra launch
+                             * costs more than the saved line fills on every BASELINE family) */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {

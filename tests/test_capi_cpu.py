@@ -56,10 +56,10 @@ def test_code_object_is_gfx950_only():
 def test_struct_layouts_match_header():
     # sizes implied by include/cask_hip.h (all int32/int64/double, natural alignment)
     import ctypes
-    assert ctypes.sizeof(capi.Params) == 32
+    assert ctypes.sizeof(capi.Params) == 36
     assert ctypes.sizeof(capi.CsrInfo) == 64
     assert ctypes.sizeof(capi.DeviceProps) == 128
-    assert ctypes.sizeof(capi.TunePoint) == 64
+    assert ctypes.sizeof(capi.TunePoint) == 72
 
 
 def test_argument_validation_happens_before_any_device_work():

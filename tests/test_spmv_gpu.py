@@ -29,6 +29,9 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, index16=-1),
     dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096, index16=2),       # 16-bit slots, not packed
     dict(variant="merge", items_per_thread=8, wg_size=128, tile_width=1024, index16=1, nontemporal=-1),   # 12-bit packed
+    dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096, far_columns=1),    # far slots, 16-bit indices
+    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=2048, far_columns=1),    # far slots, 12-bit packed
+    dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=128, far_columns=1, nontemporal=-1),
     dict(variant="merge_wave", items_per_thread=2, wg_size=64),
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
@@ -321,3 +324,22 @@ def test_create_device_rejects_out_of_range_columns():
         for dp in (dict(variant="vector"), dict(variant="merge", tile_width=-1), dict()):
             with pytest.raises(ValueError, match="column index out of range"):
                 capi.CsrMatrix.from_device(2, 3, rp, ci, va, capi.make_params(**dp))
+
+
+def test_far_columns_path_is_taken_and_exact():
+    """The far-column path (pre-gather by column panel + far slots behind the tile) on the power-law family:
+    bit-identical to the same design point without it (same products, same summation order), and reproducible."""
+    n, rp, ci, va = synth.webbase_like()
+    x = np.random.default_rng(21).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    base = dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096)
+    ys = {}
+    for far in (-1, 0, 1):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(far_columns=far, **base))
+        got = m.params.as_dict()["far_columns"]
+        ys[far] = (m.spmv(x), m.spmv(x), got)
+        m.close()
+        oracle.assert_almost_equal(ys[far][0], want, what=f"far={far}")
+        assert np.array_equal(ys[far][0], ys[far][1])
+    assert ys[-1][2] == -1 and ys[1][2] == 1 and ys[0][2] == -1         # opt-in: the default plan is unchanged
+    assert np.array_equal(ys[1][0], ys[-1][0]) and np.array_equal(ys[0][0], ys[-1][0])
