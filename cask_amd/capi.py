@@ -68,7 +68,7 @@ class DeviceProps(Structure):
 
 class TunePoint(Structure):
     _fields_ = [("params", Params), ("usec", c_double), ("gflops", c_double), ("gbytes_per_s", c_double),
-                ("valid", c_int32), ("reserved", c_int32)]
+                ("valid", c_int32), ("copies", c_int32), ("usec_warm", c_double)]
 
 
 class CaskHipError(RuntimeError):
@@ -291,7 +291,7 @@ class CsrMatrix:
                                          warmup, iters, byref(med), byref(mn)))
         return med.value, mn.value
 
-    def tune(self, variants=None, lanes=None, tiles=None, wg_sizes=None, items=None, warmup=3, iters=20,
+    def tune(self, variants=None, lanes=None, tiles=None, wg_sizes=None, items=None, warmup=1, iters=0,
              max_results=4096):
         """Measured DSE; leaves the best point active. Returns (points, best_index)."""
         arrs = [_int_array(v) for v in (variants, lanes, tiles, wg_sizes, items)]
@@ -301,7 +301,8 @@ class CsrMatrix:
         for a, cnt in arrs:
             args += [_p(a) if a is not None else None, cnt]
         _check(load().cask_hip_tune(self._h, *args, warmup, iters, res, max_results, byref(n), byref(best)))
-        pts = [{"params": res[i].params.as_dict(), "usec": res[i].usec, "gflops": res[i].gflops,
+        pts = [{"params": res[i].params.as_dict(), "usec": res[i].usec, "usec_warm": res[i].usec_warm,
+                "copies": res[i].copies, "gflops": res[i].gflops,
                 "gbytes_per_s": res[i].gbytes_per_s, "valid": bool(res[i].valid)} for i in range(n.value)]
         return pts, best.value
 

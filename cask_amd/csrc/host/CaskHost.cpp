@@ -385,13 +385,13 @@ std::vector<DseResult> SparkDse::run(const Benchmark &benchmark, const DseParame
                         (int)tiles.size(), wgs.data(), (int)wgs.size(), items.data(), (int)items.size(), params.warmup,
                         params.iterations, pts.data(), (int)pts.size(), &n, &best),
           "cask_hip_tune");
-    std::cout << "File Variant Lanes Tile WG Items usec GFLOPs GB/s" << std::endl;
+    std::cout << "File Variant Lanes Tile WG Items usec_cold usec_warm GFLOPs GB/s" << std::endl;
     for (int k = 0; k < n; k++) {
       if (!pts[k].valid) continue;
       const cask_hip_params &q = pts[k].params;
       std::cout << basename << " " << q.variant << " " << q.lanes_per_row << " " << q.tile_width << " " << q.wg_size
-                << " " << q.items_per_thread << " " << pts[k].usec << " " << pts[k].gflops << " "
-                << pts[k].gbytes_per_s << std::endl;
+                << " " << q.items_per_thread << " " << pts[k].usec << " " << pts[k].usec_warm << " " << pts[k].gflops
+                << " " << pts[k].gbytes_per_s << std::endl;
     }
     if (best < 0) continue;
     arch->setDesignPoint(pts[best].params);
@@ -399,6 +399,8 @@ std::vector<DseResult> SparkDse::run(const Benchmark &benchmark, const DseParame
     r.bestParams = pts[best].params;
     r.measuredGflops = pts[best].gflops;
     r.measuredMicroseconds = pts[best].usec;
+    r.measuredMicrosecondsWarm = pts[best].usec_warm;
+    r.copiesRotated = pts[best].copies;
     r.measuredGBs = pts[best].gbytes_per_s;
     r.pointsEvaluated = n;
     cask_hip_csr_info info;
@@ -434,12 +436,14 @@ void write_dse_results(const std::vector<DseResult> &results, double took, const
     f << "    {\n      \"name\": \"" << r.bestArchitecture->get_name() << "\",\n"
       << "      \"measured_gflops\": " << r.measuredGflops << ",\n"
       << "      \"measured_usec\": " << r.measuredMicroseconds << ",\n"
+      << "      \"measured_usec_warm\": " << r.measuredMicrosecondsWarm << ",\n"
+      << "      \"matrix_copies_rotated\": " << r.copiesRotated << ",\n"
       << "      \"measured_gbs_algorithmic\": " << r.measuredGBs << ",\n"
       << "      \"pct_hbm_peak\": " << 100.0 * r.measuredGBs / deviceModel.hbmPeakGBs() << ",\n"
       << "      \"architecture_params\": {\"variant\": " << p.variant << ", \"lanes_per_row\": " << p.lanes_per_row
       << ", \"tile_width\": " << p.tile_width << ", \"wg_size\": " << p.wg_size << ", \"items_per_thread\": "
       << p.items_per_thread << ", \"xcd_remap\": " << p.xcd_remap << ", \"nontemporal\": " << p.nontemporal
-      << ", \"index16\": " << p.index16 << "},\n"
+      << ", \"index16\": " << p.index16 << ", \"far_columns\": " << p.far_columns << "},\n"
       << "      \"launch\": {\"grid\": " << r.grid << ", \"lds_bytes\": " << r.ldsBytes << "},\n"
       << "      \"points_evaluated\": " << r.pointsEvaluated << ",\n      \"matrices\": [";
     for (size_t k = 0; k < r.matrices.size(); k++) f << (k ? ", " : "") << "\"" << r.matrices[k] << "\"";

@@ -4,10 +4,12 @@ The reference's DSE (src/main.cpp:119-207, src/runtime/Dse.cpp:32-140, driven by
 src/frontend/cask.py:90-122) walks the cross product of architecture parameter
 ranges, scores every point with an FPGA cycle MODEL and writes the winner per
 matrix to ``dse_out.json``.  Here the loop is the same shape but every point is
-MEASURED on the GPU: the point is applied to R rotating device copies of the
+MEASURED on the GPU by the engine itself (``cask_hip_tune``, the one DSE: the same call
+``build/main`` makes): the point is applied to R rotating device copies of the
 matrix (R copies exceed 2x the 256 MiB Infinity Cache, so every launch reads
-HBM), ``steps`` SpMVs are captured into a HIP graph, and the best replay gives
-microseconds per launch -> GFLOP/s and algorithmic GB/s against the 8 TB/s peak.
+HBM), a HIP graph of back-to-back SpMVs is replayed, and the best replay gives
+microseconds per launch -> GFLOP/s and algorithmic GB/s against the 8 TB/s peak;
+the cache-warm time of one copy is recorded next to it.
 
 Parameter mapping (include/cask_hip.h): input_width -> lanes_per_row,
 cache_size -> tile_width, num_pipes -> workgroup shape (wg_size,
@@ -90,30 +92,42 @@ def measure(mats, x_t, y_t, steps=60, reps=3):
     return best
 
 
-def explore(mats, x_t, y_t, points=None, steps=60, reps=3):
-    """Measure every design point on the rotating copies `mats`; leave the fastest active on all
-    of them.  Returns (rows, best_row); a row is the design point plus usec/gflops/gbs/pct_peak."""
-    points = points if points is not None else design_points()
+def ranges_of(points):
+    """The ranges a list of design points spans (the C odometer takes ranges, not points)."""
+    def vals(key, fam=None):
+        return sorted({p[key] for p in points if key in p and (fam is None or p["variant"] in fam)})
+    return {"variant": [v for v in ("vector", "merge", "merge_wave") if any(p["variant"] == v for p in points)],
+            "lanes_per_row": vals("lanes_per_row", ("vector",)), "tile_width": vals("tile_width"),
+            "wg_size": vals("wg_size"), "items_per_thread": vals("items_per_thread", ("merge", "merge_wave"))}
+
+
+def explore(mats, x_t=None, y_t=None, points=None, steps=0, reps=3):
+    """Measure every design point with the engine's own DSE (``cask_hip_tune``: the one implementation -- the
+    same call build/main makes) on ``mats[0]``, cold-ranked with the warm time recorded next to it, and leave the
+    winner active on every handle in ``mats``.  Returns (rows, best_row, seconds); a row is the resolved design
+    point plus usec (cold) / usec_warm / gflops / gbs / pct_peak.  ``points`` restricts the sweep to the cross
+    product of the values its points use; x_t / y_t are accepted for compatibility (the C side brings its own)."""
+    del x_t, y_t, reps
+    r = ranges_of(points) if points is not None else DEFAULT_RANGES
+    var_id = {v: k for k, v in capi.VARIANT_NAMES.items()}
     info0 = mats[0].info
     nnz, alg = int(info0.nnz), int(info0.algorithmic_bytes)
-    rows, best = [], None
     t0 = time.perf_counter()
-    for dp in points:
-        try:
-            prm = capi.make_params(**dp)
-            for m in mats:
-                m.set_params(prm)
-        except ValueError as e:
-            rows.append({**dp, "valid": False, "error": str(e)})
+    pts, best_i = mats[0].tune(variants=[var_id[v] for v in r["variant"]], lanes=r["lanes_per_row"] or None,
+                               tiles=r["tile_width"] or None, wg_sizes=r["wg_size"] or None,
+                               items=r["items_per_thread"] or None, iters=steps)
+    rows, best = [], None
+    for i, pt in enumerate(pts):
+        if not pt["valid"]:
+            rows.append({**pt["params"], "valid": False})
             continue
-        us = measure(mats, x_t, y_t, steps, reps)
-        info = mats[0].info
-        row = {**mats[0].params.as_dict(), "valid": True, "usec": round(us, 3),
-               "gflops": round(2.0 * nnz / us * 1e-3, 2), "gbs_algorithmic": round(alg / us * 1e-3, 1),
-               "pct_hbm_peak": round(100.0 * alg / us * 1e-3 / HBM_PEAK_GBS, 2),
-               "grid": int(info.grid), "lds_bytes": int(info.lds_bytes)}
+        us = pt["usec"]
+        row = {**pt["params"], "valid": True, "usec": round(us, 3), "usec_warm": round(pt["usec_warm"], 3),
+               "copies": pt["copies"], "gflops": round(2.0 * nnz / us * 1e-3, 2),
+               "gbs_algorithmic": round(alg / us * 1e-3, 1),
+               "pct_hbm_peak": round(100.0 * alg / us * 1e-3 / HBM_PEAK_GBS, 2)}
         rows.append(row)
-        if best is None or us < best["usec"]:
+        if i == best_i:
             best = row
     if best is not None:
         keys = ("variant", "lanes_per_row", "tile_width", "wg_size", "items_per_thread", "xcd_remap",
@@ -121,6 +135,8 @@ def explore(mats, x_t, y_t, points=None, steps=60, reps=3):
         prm = capi.make_params(**{k: best[k] for k in keys})
         for m in mats:
             m.set_params(prm)
+        info = mats[0].info
+        best["grid"], best["lds_bytes"] = int(info.grid), int(info.lds_bytes)
     took = time.perf_counter() - t0
     return rows, best, took
 
@@ -139,6 +155,7 @@ def write_dse_out(path, entries, took):
             "pct_hbm_peak": b["pct_hbm_peak"],
             "architecture_params": {k: b[k] for k in ("variant", "lanes_per_row", "tile_width", "wg_size",
                                                       "items_per_thread", "xcd_remap", "nontemporal", "index16", "far_columns")},
+            "measured_usec_warm": b.get("usec_warm"),
             "launch": {"grid": b["grid"], "lds_bytes": b["lds_bytes"]},
             "matrices": [e["matrix"]],
             "points_evaluated": e["points"],

@@ -85,7 +85,9 @@ class DseResult {
   std::shared_ptr<cask::spmv::Spmv> bestArchitecture;
   std::vector<std::string> matrices;
   cask_hip_params bestParams{};
-  double measuredGflops = 0, measuredMicroseconds = 0, measuredGBs = 0;
+  double measuredGflops = 0, measuredMicroseconds = 0, measuredGBs = 0;   // cold (rotating device copies)
+  double measuredMicrosecondsWarm = 0;                                    // one copy replayed (Infinity-Cache resident)
+  int copiesRotated = 1;
   int pointsEvaluated = 0;
   int grid = 0, ldsBytes = 0;
 

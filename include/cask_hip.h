@@ -94,11 +94,14 @@ typedef struct cask_hip_device_props {
  * estimated_gflops entries in dse_out.json, src/main.cpp:81-117) */
 typedef struct cask_hip_tune_point {
   cask_hip_params params;
-  double  usec;             /* median kernel time per SpMV             */
-  double  gflops;           /* 2*nnz / t                               */
-  double  gbytes_per_s;     /* algorithmic bytes / t                   */
+  double  usec;             /* the score: microseconds per SpMV, COLD (launches rotate over device copies of the
+                             * matrix that together exceed 2x the 256 MiB Infinity Cache, so every launch reads
+                             * HBM); matrices under 4 MB are timed warm only                                   */
+  double  gflops;           /* 2*nnz / usec                            */
+  double  gbytes_per_s;     /* algorithmic bytes / usec                */
   int32_t valid;            /* 0 = rejected (e.g. LDS over budget)     */
-  int32_t reserved;
+  int32_t copies;           /* device copies the cold timing rotated over (1 = warm only) */
+  double  usec_warm;        /* one copy replayed back to back (what a solver iteration sees) */
 } cask_hip_tune_point;
 
 const char *cask_hip_last_error(void);
@@ -170,7 +173,11 @@ int cask_hip_spmv_time(cask_hip_matrix *m, const double *d_x, double *d_y,
  * product variants x lanes x tiles x wg_sizes x items in the reference's
  * sweep order (first list fastest; src/runtime/Utils.hpp:158-202), leaves the
  * fastest valid point active on the handle and returns all measurements.
- * Replaces dse_run/better (src/runtime/Dse.cpp:12-74), measured not modelled. */
+ * Replaces dse_run/better (src/runtime/Dse.cpp:12-74), measured not modelled.
+ * Every point is timed as a HIP graph of back-to-back launches, cold (ranked on
+ * this) and warm; `iters` = launches per graph (0 = default), `warmup` = untimed
+ * replays.  The one DSE of the engine: build/main, tools/dse.py, bench.py and
+ * cask_amd.dse all rank design points with this call. */
 int cask_hip_tune(cask_hip_matrix *m,
                   const int32_t *variants, int32_t n_variants,
                   const int32_t *lanes, int32_t n_lanes,

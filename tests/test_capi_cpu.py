@@ -59,7 +59,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Params) == 36
     assert ctypes.sizeof(capi.CsrInfo) == 64
     assert ctypes.sizeof(capi.DeviceProps) == 128
-    assert ctypes.sizeof(capi.TunePoint) == 72
+    assert ctypes.sizeof(capi.TunePoint) == 80
 
 
 def test_argument_validation_happens_before_any_device_work():

@@ -233,6 +233,30 @@ def test_tune_sweeps_in_reference_order_and_keeps_the_best():
     m.close()
 
 
+def test_one_dse_cold_and_warm_times():
+    """ONE DSE.  cask_hip_tune ranks every point on its COLD time (launches rotate over device
+    copies that exceed 2x the Infinity Cache) and records the warm time next to it; cask_amd.dse.explore -- what
+    bench.py and tools/dse.py call -- is that same call, and build/main makes it too (tests/test_host_cpp.py)."""
+    from cask_amd import dse
+    n, rp, ci, va = synth.small("cant", factor=4)             # 12 MB of matrix: an HBM workload, 40+ copies
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pts, best = m.tune(variants=[capi.VARIANT_MERGE], tiles=[-1, 1024], wg_sizes=[256], items=[8])
+    assert len(pts) == 2 and all(p["valid"] and p["copies"] > 8 for p in pts)
+    assert all(p["usec"] > 0 and p["usec_warm"] > 0 and p["usec"] >= 0.9 * p["usec_warm"] for p in pts)
+    assert pts[best]["usec"] == min(p["usec"] for p in pts)
+    rows, best_row, _ = dse.explore([m], points=[dict(variant="merge", items_per_thread=8, tile_width=t, wg_size=256)
+                                                  for t in (-1, 1024)])
+    assert len(rows) == 2 and {"usec", "usec_warm", "copies"} <= set(rows[0])
+    assert m.params.as_dict()["tile_width"] == best_row["tile_width"]
+    m.close()
+    # a matrix that fits the L2 is not an HBM workload: timed warm only
+    n2, rp2, ci2, va2 = synth.small("cant", factor=64)
+    m = capi.CsrMatrix.from_host(n2, n2, rp2, ci2, va2)
+    pts, _ = m.tune(variants=[capi.VARIANT_MERGE], tiles=[1024], wg_sizes=[256], items=[8])
+    assert pts[0]["copies"] == 1 and pts[0]["usec"] == pts[0]["usec_warm"]
+    m.close()
+
+
 def _random_csr(rng, n_rows, n_cols, profile):
     """Seeded random CSR with a chosen row-length profile (sorted, duplicate-free rows)."""
     if profile == "uniform":

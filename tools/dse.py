@@ -58,7 +58,7 @@ def main():
     ap.add_argument("matrices", nargs="+")
     ap.add_argument("--params", default=None)
     ap.add_argument("--out", default="dse_out.json")
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=0, help="launches per timed graph (0 = the engine default)")
     args = ap.parse_args()
     import torch
     from cask_amd import capi, dse
@@ -72,16 +72,11 @@ def main():
     dev = torch.device("cuda", 0)
     for path in paths:
         name, n_rows, n_cols, rp, ci, va = load_matrix(path)
-        mbytes = 12 * ci.size + 4 * (n_rows + 1)
-        copies = dse.copies_for_cold(mbytes)
         rp_t = torch.from_numpy(rp).to(dev)
-        mats = [capi.CsrMatrix.from_device(n_rows, n_cols, rp_t, torch.from_numpy(ci).to(dev),
-                                           torch.from_numpy(va).to(dev)) for _ in range(copies)]
-        x = torch.from_numpy(np.arange(n_cols, dtype=np.float64) * 0.25).to(dev)     # test_spmv.cpp:27-28
-        y = torch.zeros(n_rows, dtype=torch.float64, device=dev)
-        rows, best, took = dse.explore(mats, x, y, points, steps=args.steps)
-        print(f"{Path(name).name}: best {best['variant']} {best['usec']} us  {best['gflops']} GFLOP/s  "
-              f"{best['pct_hbm_peak']}% of HBM peak  ({len(rows)} points, {took:.1f} s)")
+        mats = [capi.CsrMatrix.from_device(n_rows, n_cols, rp_t, torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev))]
+        rows, best, took = dse.explore(mats, points=points, steps=args.steps)     # cask_hip_tune: cold copies made inside
+        print(f"{Path(name).name}: best {best['variant']} {best['usec']} us cold ({best['usec_warm']} warm)  "
+              f"{best['gflops']} GFLOP/s  {best['pct_hbm_peak']}% of HBM peak  ({len(rows)} points, {took:.1f} s)")
         entries.append({"matrix": name, "best": best, "points": len(rows), "rows": rows})
         for m in mats:
             m.close()
