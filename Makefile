@@ -88,3 +88,8 @@ build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 build/libcask_hip_abl%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DCASK_ABL=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip
+
+# row f3: MatrixMarket ingest timing (host only)
+build/ingest_time: tools/ingest_time.cpp $(HOSTHDR)
+	mkdir -p build
+	$(CXX) $(CXXFLAGS) -O2 -o $@ $<

@@ -108,3 +108,75 @@ def test_bicg_reference_harness_bfwb62():
     m.close()
     assert conv
     np.testing.assert_allclose(got, x0, rtol=1e-6, atol=1e-8)
+
+
+def test_config3_cg_on_full_g3_circuit_like():
+    """BASELINE configs[2] at FULL size: CG on the 1.585 M-row G3_circuit-like SPD system, both
+    pass forms: iterations within +-2 of the oracle's pcg restatement, true residual (oracle product) <= 2e-5."""
+    import os
+    n, rp, ci, va = synth.GENERATORS["G3_circuit"]()
+    x0 = np.random.default_rng(5).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b)
+    assert want_conv
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    try:
+        for mode in ("2", "1"):                                # classic (3 launches per pass), composed (2 launches)
+            os.environ["CASK_HIP_SOLVER_MODE"] = mode
+            got, it, conv, us = m.cg(b)
+            assert conv and abs(it - want_it) <= 2, (mode, it, want_it)
+            assert np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, got)) <= 2e-5
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+    finally:
+        os.environ.pop("CASK_HIP_SOLVER_MODE", None)
+        m.close()
+
+
+def test_config5_bicg_on_full_atmosmodd_like():
+    """BASELINE configs[4] at FULL size on one GPU: BiCG with A and A^T on the 1.27 M-row nonsymmetric stencil system."""
+    import os
+    n, rp, ci, va = synth.GENERATORS["atmosmodd"]()
+    x0 = np.random.default_rng(5).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b)
+    assert want_conv
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    try:
+        for mode in ("2", "1"):
+            os.environ["CASK_HIP_SOLVER_MODE"] = mode
+            got, it, conv, us = m.bicg(b)
+            assert conv and abs(it - want_it) <= 2, (mode, it, want_it)
+            assert np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, got)) <= 2e-5
+            np.testing.assert_allclose(got, x0, rtol=1e-5, atol=1e-6)
+    finally:
+        os.environ.pop("CASK_HIP_SOLVER_MODE", None)
+        m.close()
+
+
+def test_composed_and_classic_passes_agree_bit_for_bit():
+    """The two-launch pass composes p = r + beta*p with the same fma the classic p update uses, sums the same
+    partials in the same order and applies the same x update one launch later: identical iterates, not just close."""
+    import os
+    for name, solver in (("cant", "cg"), ("G3_circuit", "cg"), ("webbase-1M", "bicg"), ("atmosmodd", "bicg")):
+        n, rp, ci, va = synth.small(name, factor=32)
+        if solver == "bicg" and name == "webbase-1M":           # make it diagonally dominant so that BiCG converges
+            rows = np.repeat(np.arange(n), np.diff(rp))
+            va = va.copy()
+            absum = np.zeros(n)
+            np.add.at(absum, rows, np.abs(va))
+            diag = rows == ci
+            if not diag.any():
+                continue
+            va[diag] = absum[rows[diag]] + 1.0
+        b = np.random.default_rng(9).standard_normal(n)
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+        out = {}
+        try:
+            for mode in ("1", "2"):
+                os.environ["CASK_HIP_SOLVER_MODE"] = mode
+                out[mode] = (m.cg if solver == "cg" else m.bicg)(b, maxiters=40, tol=1e-12)[:3]
+        finally:
+            os.environ.pop("CASK_HIP_SOLVER_MODE", None)
+            m.close()
+        assert out["1"][1:] == out["2"][1:], (name, out["1"][1:], out["2"][1:])
+        assert np.array_equal(out["1"][0], out["2"][0]), name

@@ -367,3 +367,32 @@ def test_far_columns_path_is_taken_and_exact():
         assert np.array_equal(ys[far][0], ys[far][1])
     assert ys[-1][2] == -1 and ys[1][2] == 1 and ys[0][2] == -1         # opt-in: the default plan is unchanged
     assert np.array_equal(ys[1][0], ys[-1][0]) and np.array_equal(ys[0][0], ys[-1][0])
+
+
+def test_cant3_fem_blocks_wide_band():
+    """the second cant look-alike -- 3x3 dense node blocks on a 9 x 9 x 257 beam mesh numbered so
+    that the band is wide and non-uniform (three bands 7.7 K columns apart): parity under the design points of the
+    headline kernel, and what its plan looks like (12-bit packed slots still apply; the tile is no longer ONE window)."""
+    n, rp, ci, va = synth.cant3_like()
+    assert n == 62_451 and 4_200_000 < ci.size < 4_450_000
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    colsum = oracle.csr_spmv_t(n, rp, ci, va, np.ones(n))
+    for dp in (dict(), dict(variant="merge", tile_width=1024), dict(variant="merge", tile_width=4096, wg_size=512),
+               dict(variant="merge", tile_width=-1), dict(variant="vector", lanes_per_row=16), dict(variant="merge_wave")):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
+        y, again = m.spmv(x), m.spmv(x)
+        prm = m.params.as_dict()
+        m.close()
+        oracle.assert_almost_equal(y, want, what=f"cant3 {dp}")
+        assert np.array_equal(y, again)
+        np.testing.assert_allclose(y.sum(), colsum @ x, rtol=1e-9, atol=1e-8 * np.abs(y).sum())
+        if not dp:
+            assert prm["variant"] == "merge" and prm["index16"] == 1 and prm["tile_width"] > 0   # slots, tiled
+    # the narrow-band numbering of the same mesh
+    n2, rp2, ci2, va2 = synth.cant3_like(order="x_fastest")
+    x2 = rng.uniform(-1, 1, n2)
+    m = capi.CsrMatrix.from_host(n2, n2, rp2, ci2, va2)
+    oracle.assert_almost_equal(m.spmv(x2), oracle.csr_spmv(rp2, ci2, va2, x2), what="cant3 x_fastest")
+    m.close()
