@@ -1914,7 +1914,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0];
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
-  return CASK_HIP_OK;
+  return cask_hip_precond_check(precond);
 }
 
 }  // extern "C"

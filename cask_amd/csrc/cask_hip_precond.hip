@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -75,6 +76,106 @@ __global__ void k_trsv_levels(int l0, int l1, int lower, const int *__restrict__
   }
 }
 
+// ---- synchronisation-free triangular solve ---------------------------------------------------------------------
+// Level scheduling pays a barrier (or a launch) per dependency level: 57 436 levels on the G3_circuit-like factor in
+// natural order = 245 ms per application (round 1).  Here ONE launch solves the whole triangle: waves take chunks of
+// 64 consecutive rows (in dependency order: ascending for the lower, descending for the upper solve) from a global
+// counter, one row per lane, and a lane walks its row entry by entry IN STORED ORDER -- the arithmetic of solve_row,
+// bit for bit -- waiting for each x[c] it needs:
+//  * c in the wave's own chunk: the producing lane's result comes by a cross-lane read (ds_bpermute) as soon as
+//    that lane has finished -- a chain of consecutive rows costs a few dozen cycles per row, not a memory round trip;
+//  * c in an earlier chunk: x[] is pre-filled with a NaN sentinel and every result is ONE 8-byte write-through store
+//    (sc1), so "is it ready" and "what is it" are the same 8-byte sc1 load: the value is its own flag, nothing can be
+//    observed half-done (MI355X_MICROARCH: 8-byte granules, hand-off without a separate flag).
+// Progress: a wave only ever waits for rows of chunks handed out BEFORE its own, i.e. held by waves that are already
+// running, whatever order the hardware dispatched workgroups in; the earliest unfinished chunk never waits for anybody.
+// Every wait is bounded (TRSV_MAX_POLLS, far beyond any real wait): on overflow the kernel raises *err and finishes
+// with the values it has, so a launch always drains.
+constexpr unsigned long long TRSV_SENTINEL = 0x7FF8C0DECA5C0DE5ull;   // a quiet NaN no computation produces
+constexpr int TRSV_MAX_POLLS = 1 << 22;
+
+__global__ void k_fill_sentinel(int64_t n, double *x, int *counter) {
+  const double sent = __longlong_as_double((long long)TRSV_SENTINEL);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = sent;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256)
+k_trsv_syncfree(int n, int flags, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                const double *__restrict__ b, double *x, int *counter, int *err) {
+  const bool lower = flags & 1, unit = flags & 2;
+  const int lane = threadIdx.x & 63;
+  const int n_chunks = (n + 63) >> 6;
+  while (true) {
+    int chunk = 0;
+    if (lane == 0) chunk = atomicAdd(counter, 1);
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    if (chunk >= n_chunks) break;
+    const int base = chunk << 6, i = base + lane;              // position in dependency order
+    const bool active = i < n;
+    const int r = active ? (lower ? i : n - 1 - i) : 0;
+    int k = active ? rp[r] : 0;
+    const int end = active ? rp[r + 1] : 0;
+    double s = active ? b[r] : 0.0, diag = 0.0, xr = 0.0;
+    int fin = active ? 0 : 1, polls = 0;
+    // Two kinds of step alternate.  FAST steps (no global load in them): diagonal entries and entries whose producer
+    // is a lane of this wave that has finished -- a run of consecutive dependent rows advances at cross-lane speed.
+    // When no lane can take a fast step any more, ONE poll of x[c] for the lanes that wait on an earlier chunk.
+    int c = 0, kind = 0, src = lane;                            // kind: 0 none, 1 diagonal/skip, 2 in-wave, 3 earlier chunk
+    double v = 0.0;
+    bool fetched = false;                                       // (c, v, kind, src) describe entry k
+    while (__ballot(!fin) != 0ull) {                            // wave-uniform
+      bool progress;
+      do {
+        progress = false;
+        if (!fin && !fetched && k < end) {
+          c = ci[k];
+          v = val[k];
+          if (c == r) kind = 1;
+          else if (lower ? c > r : c < r) kind = 1;             // not in this triangle (extract_triangle leaves none)
+          else {
+            const int pos = lower ? c : n - 1 - c;              // the producer's position in dependency order (< i)
+            if (pos >= base) { kind = 2; src = pos - base; }
+            else kind = 3;
+          }
+          fetched = true;
+        }
+        const int want = (!fin && fetched && kind == 2) ? src : lane;
+        const double x_in = shfl_f64(xr, want);                 // all lanes take part
+        const int fin_in = __builtin_amdgcn_ds_bpermute(want << 2, fin);
+        if (!fin && fetched) {
+          if (kind == 1) {
+            if (c == r) diag = v;
+            k++; fetched = false; progress = true;
+          } else if (kind == 2 && fin_in) {
+            s -= v * x_in;
+            k++; fetched = false; progress = true;
+          }
+        }
+        if (!fin && !fetched && k == end) {
+          xr = unit ? s : s / diag;
+          __hip_atomic_store(x + r, xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 8-byte write-through store
+          fin = 1;
+          progress = true;
+        }
+      } while (__ballot(progress) != 0ull);
+      if (!fin && fetched && kind == 3) {                       // one poll, then back to the fast steps
+        const double xv = __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned long long)__double_as_longlong(xv) != TRSV_SENTINEL) { s -= v * xv; k++; fetched = false; }
+        else if (++polls > TRSV_MAX_POLLS) { *err = 1; s -= v * xv; k++; fetched = false; }
+        else __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+}
+
 __global__ void k_scale(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r, double *__restrict__ z) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     z[i] = r[i] * dinv[i];
@@ -124,6 +225,8 @@ struct TriFactor {
   int n_levels = 0;
   struct Step { int l0, l1, lo, hi; bool wide; };     // levels [l0,l1) = positions [lo,hi) of `order`
   std::vector<Step> steps;
+  DevBuf<int> sync;                                   // [0] chunk counter, [1] error flag of the sync-free solve
+  int sf_grid = 0;
 
   int build(int n_, bool lower_, const std::vector<int> &h_rp, const std::vector<int> &h_ci,
             const std::vector<double> &h_val) {
@@ -165,11 +268,39 @@ struct TriFactor {
     PC_TRY(val.upload(h_val));
     PC_TRY(order.upload(ord));
     PC_TRY(level_ptr.upload(lp));
+    PC_TRY(sync.alloc(2));
+    PC_TRY(hipMemset(sync.p, 0, 2 * sizeof(int)));
+    int occ = 0, cus = 0, dev = 0;
+    PC_TRY(hipGetDevice(&dev));
+    PC_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trsv_syncfree, 256, 0));
+    PC_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int want = ((n + 63) / 64 + 3) / 4;
+    sf_grid = std::max(1, std::min(want, std::max(1, occ) * cus));
     return CASK_HIP_OK;
+  }
+
+  // Level-scheduled by default; CASK_HIP_TRSV=syncfree selects the one-launch synchronisation-free solve.  Measured
+  // on the G3_circuit-like ILU(0) factors (57 436 levels, profiles/r02_trsv.txt): levels 225 ms, sync-free 210-270 ms
+  // per PCG pass -- no better.  The critical path is 57 K DEPENDENT rows either way, and a dependent step costs
+  // ~2 us in both schedules: in the sync-free kernel every step of a lane re-reads its row entry from L1/L2 and the
+  // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
+  // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
+  // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
+  bool use_syncfree() const {
+    static const char *force = std::getenv("CASK_HIP_TRSV");
+    return force && std::string(force) == "syncfree";
   }
 
   int solve(const double *d_b, double *d_x, hipStream_t s) const {
     const int flags = (lower ? 1 : 0) | (unit ? 2 : 0);
+    if (n > 0 && use_syncfree()) {
+      const int fill_grid = (int)std::min<int64_t>(1024, ((int64_t)n + 255) / 256);
+      hipLaunchKernelGGL(k_fill_sentinel, dim3(fill_grid), dim3(256), 0, s, (int64_t)n, d_x, sync.p);
+      hipLaunchKernelGGL(k_trsv_syncfree, dim3(sf_grid), dim3(256), 0, s, n, flags, rp.p, ci.p, val.p, d_b, d_x, sync.p,
+                         sync.p + 1);
+      PC_TRY(hipGetLastError());
+      return CASK_HIP_OK;
+    }
     for (const Step &st : steps) {
       if (st.wide)
         hipLaunchKernelGGL(k_trsv_level, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, flags,
@@ -341,7 +472,7 @@ int cask_hip_precond_apply(cask_hip_precond *p, const double *r, double *z) {
   int rc = cask_hip_precond_apply_device(p, p->d_r.p, p->d_z.p, nullptr);
   if (rc) return rc;
   PC_TRY(hipMemcpy(z, p->d_z.p, (size_t)p->n * sizeof(double), hipMemcpyDeviceToHost));
-  return CASK_HIP_OK;
+  return cask_hip_precond_check(p);
 }
 
 int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32_t *col_ind, const double *values,
@@ -365,6 +496,9 @@ int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32
   rc = t.solve(b.p, out.p, nullptr);
   if (rc) return rc;
   PC_TRY(hipMemcpy(x, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  int sync_err = 0;
+  PC_TRY(hipMemcpy(&sync_err, t.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (sync_err) return report_failure(CASK_HIP_ERR_RUNTIME, "triangular solve: a dependency never arrived (poll limit reached)");
   return CASK_HIP_OK;
 }
 
@@ -383,3 +517,13 @@ int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d
   return 1;
 }
 
+
+// After a host synchronisation: did a sync-free triangular solve of this preconditioner give up on a dependency?
+int cask_hip_precond_check(cask_hip_precond *p) {
+  if (!p || p->kind == CASK_HIP_PRECOND_JACOBI) return CASK_HIP_OK;
+  int e[2] = {0, 0};
+  if (p->L.sync.p) PC_TRY(hipMemcpy(&e[0], p->L.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (p->U.sync.p) PC_TRY(hipMemcpy(&e[1], p->U.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (e[0] || e[1]) return report_failure(CASK_HIP_ERR_RUNTIME, "triangular solve: a dependency never arrived (poll limit reached)");
+  return CASK_HIP_OK;
+}

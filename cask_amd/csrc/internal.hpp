@@ -41,5 +41,6 @@ struct DevBuf {
 // written, fixed grid => reproducible), 0 if the caller must apply and reduce separately, < 0 on error.
 struct cask_hip_precond;
 int cask_hip_precond_rows(const cask_hip_precond *p);      // order of the matrix the preconditioner was built from
+int cask_hip_precond_check(cask_hip_precond *p);           // after a host sync: error flag of the sync-free triangular solves
 int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d_z, double *d_partials,
                                int max_partials, int *n_partials, const int *d_done, hipStream_t stream);

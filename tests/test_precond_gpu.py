@@ -15,7 +15,7 @@ import scipy.sparse as sp
 import oracle
 from oracle import mmio
 from cask_amd import capi, synth
-from conftest import GOLDEN, have_gpu
+from conftest import GOLDEN, REPO, have_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a GPU")]
 
@@ -158,3 +158,34 @@ def test_argument_checks():
         capi.Preconditioner("ilu0", 2, [0, 2, 2], [1, 0], [1.0, 2.0])
     with pytest.raises(ValueError, match="kind"):
         capi.Preconditioner(7, 1, [0, 1], [0], [1.0])
+
+
+def test_syncfree_triangular_solve_matches_level_schedule():
+    """The one-launch synchronisation-free solve (CASK_HIP_TRSV=syncfree; an option, see cask_hip_precond.hip) walks
+    every row in stored order like the level-scheduled one: identical bits, on a factor with thousands of levels."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+from cask_amd import capi, synth
+n, rp, ci, va = synth.small("G3_circuit", factor=16)
+rng = np.random.default_rng(3)
+r = rng.standard_normal(n)
+pc = capi.Preconditioner("ilu0_unit", n, rp, ci, va)
+z = pc.apply(r)
+lo = capi.trsolve(n, rp, ci, va, r, lower=True)
+up = capi.trsolve(n, rp, ci, va, r, lower=False)
+np.save(sys.argv[1], np.concatenate([z, lo, up]))
+print(pc.info()["levels_lower"])
+'''
+    outs = {}
+    for mode in ("levels", "syncfree"):
+        path = f"/tmp/cask_trsv_{mode}.npy"
+        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, CASK_HIP_TRSV=mode), cwd=str(REPO))
+        assert res.returncode == 0, res.stderr[-1500:]
+        assert int(res.stdout.strip().splitlines()[-1]) > 500
+        outs[mode] = np.load(path)
+    assert np.array_equal(outs["levels"], outs["syncfree"])
