@@ -89,6 +89,7 @@ struct Plan {
   int n_far = 0, far_grid = 0;
   FarPanels far_panels{};
   DevBuf<int> far_col, far_dst;
+  DevBuf<int> far_col_block;       // far_columns = 2: the far columns block-major (gathered by the product kernel itself)
   DevBuf<double> farx;
   // VECTOR
   DevBuf<int2v> xspan;
@@ -169,7 +170,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.index16 == 0) out.index16 = 1;
   if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
-  if (out.far_columns < -1 || out.far_columns > 1) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0 or 1");
+  if (out.far_columns < -1 || out.far_columns > 2) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0, 1 or 2");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
@@ -506,6 +507,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.n_far = pl.far_grid = 0;
   pl.far_col.release();
   pl.far_dst.release();
+  pl.far_col_block.release();
   pl.farx.release();
   pl.grid = 0;
   pl.lds_bytes = 0;
@@ -577,7 +579,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       // webbase-1M-like: product 24.4 -> 19.5-21.3 us, but the gather launch is two dependent memory round trips
       // with little parallelism (9.4 us for 23 MB), 29-31 us in all; G3_circuit-like 22.1 -> 27.3 us.  It does cut
       // the fabric traffic, which is what the column panels are for; it does not cut the time.
-      bool far = prm.far_columns == 1 && !m.halo_addr && max_slots <= 65536;
+      bool far = prm.far_columns >= 1 && !m.halo_addr && max_slots <= 65536;
       long n_far = 0;
       if (far) {
         std::vector<BlockDesc> trial = blocks;
@@ -591,7 +593,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         }
       }
       if (!far) build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16, false, nullptr);
-      pl.prm.far_columns = far ? 1 : -1;
+      pl.prm.far_columns = far ? prm.far_columns : -1;
       if (far) {
         // farx is block-major (one coalesced run per block); the pre-gather walks the far nonzeros sorted by column
         // panel, then block, then nonzero -- the order far_of already has inside a block
@@ -615,10 +617,17 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         for (int p = 0; p <= FAR_PANELS; p++) pl.far_panels.start[p] = count[p];
         for (int p = 0; p < FAR_PANELS; p++) per_panel = std::max(per_panel, (count[p + 1] - count[p] + FAR_CHUNK - 1) / FAR_CHUNK);
         pl.n_far = (int)n_far;
-        pl.far_grid = per_panel * FAR_PANELS;
-        HIP_TRY(pl.far_col.upload(fcol));
-        HIP_TRY(pl.far_dst.upload(fdst));
-        HIP_TRY(pl.farx.alloc((size_t)n_far));
+        if (prm.far_columns == 2) {                           // no pre-gather: the product kernel gathers through this list
+          std::vector<int> fcb((size_t)n_far);
+          for (size_t b = 0; b < blocks.size(); b++)
+            for (size_t j = 0; j < far_of[b].size(); j++) fcb[(size_t)base[b] + j] = m.h_ci[far_of[b][j]];
+          HIP_TRY(pl.far_col_block.upload(fcb));
+        } else {
+          pl.far_grid = per_panel * FAR_PANELS;
+          HIP_TRY(pl.far_col.upload(fcol));
+          HIP_TRY(pl.far_dst.upload(fdst));
+          HIP_TRY(pl.farx.alloc((size_t)n_far));
+        }
       }
       if (m.halo_addr) place_seam_blocks(m, blocks, chunk_starts, prm.xcd_remap > 0);
       int max_used = 0;                                       // slots of the fullest tile (chunks + far slots)
@@ -746,7 +755,11 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.solver_pass = pass != nullptr;
   if (pass) l.pass = *pass;
   l.farx = nullptr;
-  if (pl.n_far > 0) {                                         // x values of the far nonzeros, panel by panel
+  l.far_col = nullptr;
+  l.far = pl.n_far > 0;
+  if (pl.n_far > 0 && pl.far_col_block.p) {
+    l.far_col = pl.far_col_block.p;
+  } else if (pl.n_far > 0) {                                  // x values of the far nonzeros, panel by panel
     hipLaunchKernelGGL(k_far_gather, dim3(pl.far_grid), dim3(256), 0, s, pl.far_panels, pl.far_col.p, pl.far_dst.p, x,
                        pl.farx.p);
     l.farx = pl.farx.p;

@@ -210,7 +210,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
                                            double *prod, int *roff, double *xs, const XHalo &halo,
                                            const double *__restrict__ w, double *wl, int lb,
                                            const SolverPass &sp, const PassScalars &ps,
-                                           const double *__restrict__ farx) {
+                                           const double *__restrict__ farx, const int *__restrict__ far_col) {
   const int WG = blockDim.x, tid = threadIdx.x;
 #if defined(CASK_ABL) && (CASK_ABL & 2)                       // diagnostic build: what does the second window cost?
   constexpr bool COMP = false;
@@ -277,14 +277,17 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
         }
       }
     } else if (FAR && (d.kind_g & KIND_FAR)) {                // workgroup-uniform
-      // far slots: behind the block's chunks sit the x values of its far columns, gathered column panel by column
-      // panel by k_far_gather into farx[d.aux ...] just before this launch (d.cmin of them)
+      // far slots: behind the block's chunks sit the x values of its far columns (d.cmin of them) -- gathered column
+      // panel by column panel by k_far_gather into farx[d.aux ...] just before this launch, or (far_col != NULL:
+      // far_columns = 2) gathered here from x through the block's list of far columns: the list entries are
+      // requested now, the gathers go out behind the stream like a seam block's remote loads
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
       const int tile_slots = d.cwidth - d.cmin, last_far = max(d.cmin - 1, 0);
 #pragma unroll
       for (int u = 0; u < XU; u++) {
         const int cidx = u * wpw + wave;                      // wave-uniform chunk index; slot = 64*cidx + lane
         if (cidx * 64 < tile_slots) xw[u] = x[min(xchunk[cidx] + lane, xlim)];
+        else if (far_col)           xsrc[u] = (uint64_t)far_col[d.aux + min(cidx * 64 + lane - tile_slots, last_far)];
         else                        xw[u] = farx[d.aux + min(cidx * 64 + lane - tile_slots, last_far)];
       }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
@@ -338,6 +341,13 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
       xw[u] = load_at(xsrc[u]);
       if (COMP) xb[COMP ? u : 0] = load_at(xsrc[u] + 8 * (uint64_t)sp.b_off);
     }
+  }
+  if (FAR && XU > 0 && far_col && (d.kind_g & KIND_FAR)) {    // direct far gathers (workgroup-uniform)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpw = WG >> 6;
+    const int tile_slots = d.cwidth - d.cmin;
+#pragma unroll
+    for (int u = 0; u < XU; u++)
+      if ((u * wpw + wave) * 64 >= tile_slots) xw[u] = x[(int)xsrc[u]];
   }
   // dot epilogue (EXT kernels, launch-uniform test): the block's slice of w, requested behind the stream
   // (youngest loads: nothing waits for them until the products are stored), parked in LDS for the row sums
@@ -496,7 +506,7 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
                                             double *__restrict__ y, double *prod, int *roff, double *xs,
                                             const XHalo &halo, const DotEpilogue &dot, int lb,
                                             const SolverPass &sp, const PassScalars &ps,
-                                            const double *__restrict__ farx) {
+                                            const double *__restrict__ farx, const int *__restrict__ far_col) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
   // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
@@ -510,10 +520,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
     merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                            halo, wsrc, wl, lb, sp, ps, farx);
+                                            halo, wsrc, wl, lb, sp, ps, farx, far_col);
   else
     merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                             halo, wsrc, wl, lb, sp, ps, farx);
+                                             halo, wsrc, wl, lb, sp, ps, farx, far_col);
   const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
 
   double dsum;
@@ -552,7 +562,8 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
-                             PassArg<EXT> pass_arg, const double *__restrict__ farx) {
+                             PassArg<EXT> pass_arg, const double *__restrict__ farx,
+                             const int *__restrict__ far_col) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
@@ -660,10 +671,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
     merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                             xs, halo, dot, lb, sp, ps, farx);
+                                             xs, halo, dot, lb, sp, ps, farx, far_col);
   else
     merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                              xs, halo, dot, lb, sp, ps, farx);
+                                              xs, halo, dot, lb, sp, ps, farx, far_col);
   CASK_STAMP(5);
 }
 

@@ -26,6 +26,8 @@ struct MergeLaunch {
   bool solver_pass;                // EXT == 2 launch: `pass` describes the composed operand and the scalars
   SolverPass pass;
   const double *farx;              // plans with far slots: the x values k_far_gather left for them; else NULL
+  const int *far_col;              // far_columns = 2: block-major list of the far columns, gathered by the product kernel itself
+  bool far;                        // the plan has far slots
 };
 
 template <int IPT>

@@ -12,7 +12,7 @@ static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hi
 #define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS)                                                   \
   hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR>), grid, block, l.lds_bytes, s,      \
                      l.blocks, l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, \
-                     y, l.partials, l.halo, l.dot, PASS, l.farx)
+                     y, l.partials, l.halo, l.dot, PASS, l.farx, l.far_col)
   // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one, a solver
   // pass the one that composes its operand
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
@@ -34,11 +34,11 @@ static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hi
   constexpr bool TILED = XU > 0;
   constexpr bool CAN12 = TILED && IPT == 8;                   // 12-bit packed slots exist for 8 items per thread
   constexpr bool CANWIDE = CAN12 && XU >= 2;                  // paired window loads: packed plans whose tiles are one window
-  if (TILED && l.ci16 && l.farx && l.packed12 && CAN12) {
+  if (TILED && l.ci16 && l.far && l.packed12 && CAN12) {
     if (l.any_skew) CASK_LAUNCH_F(true, TILED, CAN12, true);
     else if (nt)    CASK_LAUNCH_F(true, TILED, CAN12, false);
     else            CASK_LAUNCH_F(false, TILED, CAN12, false);
-  } else if (TILED && l.ci16 && l.farx) {
+  } else if (TILED && l.ci16 && l.far) {
     if (l.any_skew) CASK_LAUNCH_F(true, TILED, false, true);
     else if (nt)    CASK_LAUNCH_F(true, TILED, false, false);
     else            CASK_LAUNCH_F(false, TILED, false, false);

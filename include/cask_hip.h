@@ -60,7 +60,9 @@ typedef struct cask_hip_params {
                              * served from a side buffer that a pre-gather launch fills column panel by column panel
                              * (one panel of x per XCD's L2) -- the reference's column blocking (SparseMatrix.hpp:459-482)
                              * applied to the scattered part only.  1 = on, 0 / -1 = off (measured: the extra launch
-                             * costs more than the saved line fills on every BASELINE family) */
+                             * costs more than the saved line fills on every BASELINE family);
+                             * 2 = far slots without the pre-gather: the product kernel gathers them from x itself,
+                             * through a per-block list of far columns */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {

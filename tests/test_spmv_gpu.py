@@ -32,6 +32,8 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096, far_columns=1),    # far slots, 16-bit indices
     dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=2048, far_columns=1),    # far slots, 12-bit packed
     dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=128, far_columns=1, nontemporal=-1),
+    dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, far_columns=2),    # far slots gathered in-kernel
+    dict(variant="merge", items_per_thread=8, wg_size=128, tile_width=1024, far_columns=2, nontemporal=-1),
     dict(variant="merge_wave", items_per_thread=2, wg_size=64),
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
@@ -358,15 +360,15 @@ def test_far_columns_path_is_taken_and_exact():
     want = oracle.csr_spmv(rp, ci, va, x)
     base = dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096)
     ys = {}
-    for far in (-1, 0, 1):
+    for far in (-1, 0, 1, 2):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(far_columns=far, **base))
         got = m.params.as_dict()["far_columns"]
         ys[far] = (m.spmv(x), m.spmv(x), got)
         m.close()
         oracle.assert_almost_equal(ys[far][0], want, what=f"far={far}")
         assert np.array_equal(ys[far][0], ys[far][1])
-    assert ys[-1][2] == -1 and ys[1][2] == 1 and ys[0][2] == -1         # opt-in: the default plan is unchanged
-    assert np.array_equal(ys[1][0], ys[-1][0]) and np.array_equal(ys[0][0], ys[-1][0])
+    assert ys[-1][2] == -1 and ys[1][2] == 1 and ys[2][2] == 2
+    assert np.array_equal(ys[1][0], ys[-1][0]) and np.array_equal(ys[0][0], ys[-1][0]) and np.array_equal(ys[2][0], ys[-1][0])
 
 
 def test_cant3_fem_blocks_wide_band():
