@@ -178,86 +178,7 @@ __global__ void k_cg_update_p(int64_t n, const double *__restrict__ part_rr, int
   if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *iters = iter; }
 }
 
-// BiCG: alpha = rho / (pt.q); x += alpha p; r -= alpha q; rt -= alpha qt;
-// partials of r.r (-> part_rr) and rt.r (-> part_rho).  pt.q arrives as partials.
-__global__ void k_bicg_update(int64_t n, const double *rho, const double *__restrict__ part_ptq, int n_part,
-                              const double *__restrict__ p, const double *__restrict__ q,
-                              const double *__restrict__ qt, double *__restrict__ x,
-                              double *__restrict__ r, double *__restrict__ rt,
-                              double *__restrict__ part_rr, double *__restrict__ part_rho, const int *done) {
-  __shared__ double red[16];
-  if (done && *done) return;
-  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
-  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p), *q2 = reinterpret_cast<const dbl2 *>(q),
-             *qt2 = reinterpret_cast<const dbl2 *>(qt);
-  dbl2 *x2 = reinterpret_cast<dbl2 *>(x), *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
-  double a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
-  CASK_PAIR_LOOP(n >> 1) {
-    const dbl2 pv = p2[i], qv = q2[i], qtv = qt2[i];
-    dbl2 xv = x2[i], rv = r2[i], rtv = rt2[i];
-    xv.x = fma(alpha, pv.x, xv.x);
-    xv.y = fma(alpha, pv.y, xv.y);
-    rv.x = fma(-alpha, qv.x, rv.x);
-    rv.y = fma(-alpha, qv.y, rv.y);
-    rtv.x = fma(-alpha, qtv.x, rtv.x);
-    rtv.y = fma(-alpha, qtv.y, rtv.y);
-    x2[i] = xv;
-    r2[i] = rv;
-    rt2[i] = rtv;
-    a_rr0 = fma(rv.x, rv.x, a_rr0);
-    a_rr1 = fma(rv.y, rv.y, a_rr1);
-    a_rho0 = fma(rtv.x, rv.x, a_rho0);
-    a_rho1 = fma(rtv.y, rv.y, a_rho1);
-  }
-  if (owns_tail(n)) {
-    x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
-    const double rn = fma(-alpha, q[n - 1], r[n - 1]);
-    const double rtn = fma(-alpha, qt[n - 1], rt[n - 1]);
-    r[n - 1] = rn;
-    rt[n - 1] = rtn;
-    a_rr0 = fma(rn, rn, a_rr0);
-    a_rho0 = fma(rtn, rn, a_rho0);
-  }
-  __syncthreads();
-  const double s1 = wg_sum(a_rr0 + a_rr1, red);
-  __syncthreads();
-  const double s2 = wg_sum(a_rho0 + a_rho1, red);
-  if (threadIdx.x == 0) { part_rr[blockIdx.x] = s1; part_rho[blockIdx.x] = s2; }
-}
-
-// BiCG: converged if r.r <= tol^2; else beta = rho_new/rho; p = r + beta p; pt = rt + beta pt
-__global__ void k_bicg_update_p(int64_t n, const double *__restrict__ part_rr, const double *__restrict__ part_rho,
-                                int n_part, const double *rho, double *rho_out, double tol2, int iter,
-                                const double *__restrict__ r, const double *__restrict__ rt,
-                                double *__restrict__ p, double *__restrict__ pt, int *done, int *iters) {
-  __shared__ double red[16];
-  if (*done) return;
-  const double rr = partials_or_scalar(part_rr, n_part, red);
-  if (rr <= tol2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *done = 1;
-    return;
-  }
-  const double rho_new = partials_or_scalar(part_rho, n_part, red);
-  const double beta = rho_new / *rho;
-  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
-  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt);
-  CASK_PAIR_LOOP(n >> 1) {
-    const dbl2 rv = r2[i], rtv = rt2[i];
-    dbl2 pv = p2[i], ptv = pt2[i];
-    pv.x = fma(beta, pv.x, rv.x);
-    pv.y = fma(beta, pv.y, rv.y);
-    ptv.x = fma(beta, ptv.x, rtv.x);
-    ptv.y = fma(beta, ptv.y, rtv.y);
-    p2[i] = pv;
-    pt2[i] = ptv;
-  }
-  if (owns_tail(n)) {
-    p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
-    pt[n - 1] = fma(beta, pt[n - 1], rt[n - 1]);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *rho_out = rho_new; *iters = iter; }
-}
-// ---- two-launch passes (the product kernel composes the direction: SolverPass, spmv_common.hpp) ------------
+// ---- the update launches of cask_hip_solve_device (classic and composed passes) ---------------------------
 // Vectors that peers read over xGMI (row-sharded solvers) are stored write-through at system scope.
 __device__ __forceinline__ void store_pair(dbl2 *p, dbl2 v, int sys_scope) {
   if (sys_scope) {
@@ -344,6 +265,88 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
   __syncthreads();
   const double s2 = wg_sum(a_rho0 + a_rho1, red);
   if (threadIdx.x == 0) { part_rr[blockIdx.x] = s1; part_rho[blockIdx.x] = s2; }
+}
+
+// Classic passes, last launch: the solution update the pass owes, the convergence test, the direction update --
+//   x += alpha p (SparseLinearSolvers.hpp:210; alpha as k_cg_update_r left it) ; rsnew = r.r ; converged if
+//   rsnew <= tol^2 (:220-226, nothing after it) ; else iterations = iter, p = r + (rsnew/rsold) p (:229-231).
+// x is updated here and not next to r because this launch reads p anyway: one pass over p less per iteration.
+__global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, int n_part, const double *rsold,
+                               double *rsnew_out, const double *alpha, double tol2, int iter,
+                               const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x,
+                               int *done, int *iters, int sys_scope) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double rsnew = partials_or_scalar(part_rr, n_part, red);
+  const bool stop = rsnew <= tol2;
+  const double a = *alpha, beta = stop ? 0.0 : rsnew / *rsold;
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
+  CASK_PAIR_LOOP(n >> 1) {
+    dbl2 pv = p2[i], xv = x2[i];
+    xv.x = fma(a, pv.x, xv.x);
+    xv.y = fma(a, pv.y, xv.y);
+    x2[i] = xv;
+    if (!stop) {                                              // launch-uniform
+      const dbl2 rv = r2[i];
+      pv.x = fma(beta, pv.x, rv.x);
+      pv.y = fma(beta, pv.y, rv.y);
+      store_pair(p2 + i, pv, sys_scope);
+    }
+  }
+  if (owns_tail(n)) {
+    const double pn = p[n - 1];
+    x[n - 1] = fma(a, pn, x[n - 1]);
+    if (!stop) store_one(p + (n - 1), fma(beta, pn, r[n - 1]), sys_scope);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *rsnew_out = rsnew;
+    if (stop) *done = 1; else *iters = iter;
+  }
+}
+
+// BiCG: x += alpha p ; converged if r.r <= tol^2 ; else beta = rho_new/rho, p = r + beta p, pt = rt + beta pt
+__global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, const double *__restrict__ part_rho,
+                                 int n_part, const double *rho, double *rho_out, const double *alpha, double tol2,
+                                 int iter, const double *__restrict__ r, const double *__restrict__ rt,
+                                 double *__restrict__ p, double *__restrict__ pt, double *__restrict__ x, int *done,
+                                 int *iters, int sys_scope) {
+  __shared__ double red[16];
+  if (*done) return;
+  const double rr = partials_or_scalar(part_rr, n_part, red);
+  const bool stop = rr <= tol2;
+  double rho_new = 0.0;
+  if (!stop) rho_new = partials_or_scalar(part_rho, n_part, red);
+  const double a = *alpha, beta = stop ? 0.0 : rho_new / *rho;
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt), *x2 = reinterpret_cast<dbl2 *>(x);
+  CASK_PAIR_LOOP(n >> 1) {
+    dbl2 pv = p2[i], xv = x2[i];
+    xv.x = fma(a, pv.x, xv.x);
+    xv.y = fma(a, pv.y, xv.y);
+    x2[i] = xv;
+    if (!stop) {
+      const dbl2 rv = r2[i], rtv = rt2[i];
+      dbl2 ptv = pt2[i];
+      pv.x = fma(beta, pv.x, rv.x);
+      pv.y = fma(beta, pv.y, rv.y);
+      ptv.x = fma(beta, ptv.x, rtv.x);
+      ptv.y = fma(beta, ptv.y, rtv.y);
+      store_pair(p2 + i, pv, sys_scope);
+      store_pair(pt2 + i, ptv, sys_scope);
+    }
+  }
+  if (owns_tail(n)) {
+    const double pn = p[n - 1];
+    x[n - 1] = fma(a, pn, x[n - 1]);
+    if (!stop) {
+      store_one(p + (n - 1), fma(beta, pn, r[n - 1]), sys_scope);
+      store_one(pt + (n - 1), fma(beta, pt[n - 1], rt[n - 1]), sys_scope);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (stop) *done = 1; else { *rho_out = rho_new; *iters = iter; }
+  }
 }
 
 // Row-sharded solvers: this rank's partial sums -> one scalar each (fixed order), ready for the all-reduce.

@@ -1731,20 +1731,14 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       n_dot = 0;
     }
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
-    if (st.composed) {
-      if (bicg)
-        hipLaunchKernelGGL(k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
-                           scal.p + SC_ALPHA, (const int *)done, st.sys_scope);
-      else
-        hipLaunchKernelGGL(k_cg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
-                           (const int *)done, st.sys_scope);
-    } else if (bicg) {
-      hipLaunchKernelGGL(k_bicg_update, bg, bw, 0, s, n, rsold, dot_part, n_dot, slot(SLOT_P0), q.p, qt.p, d_x, r, rt,
-                         part_a.p, part_b.p, (const int *)done);
-    } else {
-      hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, dot_part, n_dot, slot(SLOT_P0), q.p, d_x, r, part_a.p,
-                         (const int *)done);                                            // :208-218
-    }
+    // r -= alpha q (and rt -= alpha qt) with the shares of r.r (and rt.r); alpha stays on the device for the launch
+    // that applies x += alpha p: the next product (composed passes) or the p update below (classic passes)
+    if (bicg)
+      hipLaunchKernelGGL(k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
+                         scal.p + SC_ALPHA, (const int *)done, st.sys_scope);
+    else
+      hipLaunchKernelGGL(k_cg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
+                         (const int *)done, st.sys_scope);                              // :208, :212, :218
     const double *chk_part = part_a.p, *rho_part = part_b.p;
     int n_chk = g;
     if (st.sharded) {                                         // r.r (and rt.r): one collective
@@ -1758,11 +1752,11 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     }
     if (!st.composed) {
       if (bicg)
-        hipLaunchKernelGGL(k_bicg_update_p, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, tol2, i, r, rt,
-                           slot(SLOT_P0), slot(SLOT_PT0), done, iters);
+        hipLaunchKernelGGL(k_bicg_update_px, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA,
+                           tol2, i, r, rt, slot(SLOT_P0), slot(SLOT_PT0), d_x, done, iters, st.sys_scope);
       else
-        hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, tol2, i, r, slot(SLOT_P0), done,
-                           iters);                                                      // :220-231
+        hipLaunchKernelGGL(k_cg_update_px, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA, tol2, i, r,
+                           slot(SLOT_P0), d_x, done, iters, st.sys_scope);              // :210, :220-231
     }
     if (!st.composed && st.sharded && !st.exchange) {
       // classic passes with in-kernel halos: the p update above must be complete on every rank before any
