@@ -262,7 +262,7 @@ def traffic_record(workload):
     if tfile.exists():
         try:
             t = json.loads(tfile.read_text())
-            return t.get("hbm_bytes_per_launch"), f"profiles/{tfile.name} (rocprofv3 PMC passes of round {t.get('round', '?')}, " \
+            return t.get("hbm_bytes_per_launch"), f"profiles/{tfile.name} (rocprofv3 PMC passes of round {t.get('tag', '?')}, " \
                                                   "FETCH_SIZE x calibration + WRITE_SIZE; not measured in this run)"
         except Exception:
             pass

@@ -1470,6 +1470,21 @@ static int solver_common_checks(cask_hip_matrix *m, const double *rhs, double *x
 // callback): product, x/r update, p update as separate launches.  Row-sharded: the partial sums are added to
 // one scalar per rank and all-reduced through the caller's callback between the launches; those collectives are
 // also what orders a rank's stores to its vector slices against the peers' in-kernel halo loads.
+//
+// Cross-rank hazards of a composed pass i with in-kernel halos (K1_i = product launch(es), K2_i = update launch,
+// AR1_i = all-reduce of p.Ap / pt.q, AR2_i = all-reduce of r.r (and rt.r); an all-reduce completes on a rank only
+// after every rank has enqueued its contribution behind its own preceding kernels):
+//   * K1_i reads the peers' r (rt): written by their K2_{i-1}, which precedes their contribution to AR2_{i-1},
+//     which K1_i waits for (it consumes the reduced scalars).               [pass 0: r is final before the r.r
+//     all-reduce of the set-up]
+//   * K1_i reads the peers' p_old = P[(i-1)&1]: written by their K1_{i-1}, two collectives earlier.
+//   * K1_i WRITES its own P[i&1], which peers read as p_old in THEIR K1_{i-1}: those launches precede the peers'
+//     contributions to AR1_{i-1}, which completed before this rank's K2_{i-1}, hence before K1_i.
+//   * K2_i WRITES this rank's r: peers read it in their K1_i, before their contribution to AR1_i, which this rank's
+//     K2_i waits for.
+// A classic pass with in-kernel halos has no collective between its p update and the next product: it spends a
+// third one as a fence.  Vector slots peers read are written with system-scope write-through stores and read with
+// system-scope loads.
 namespace {
 
 struct SolveSetup {
