@@ -59,7 +59,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "atmosmodd"])
     ap.add_argument("--solver", default=None, choices=["cg", "bicg"], help="time solver passes instead of products")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager"],
+                    help="graph: the K steps as one HIP graph; sequence: K launches from one C call (no graph start-up "
+                         "inside a short timed region); eager: per-step calls; auto: sequence below 200 steps, else graph")
     ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -429,6 +431,10 @@ def run_spmv(cx, weak):
     torch.cuda.synchronize()
 
     launch_mode = args.launch if exchange != "all_gather" else "eager"
+    if launch_mode == "auto":
+        # measured (one box): graph 8.65 / 8.27 us per step at 20 / 1000 steps, sequence 8.47 / 8.51: a graph start
+        # costs ~9 us even queued behind another replay, which only a long region amortises
+        launch_mode = "sequence" if args.steps < 200 and exchange in ("none", "p2p_fused") else "graph"
     graph, preroll = None, 0
     if launch_mode == "graph":
         try:
@@ -458,7 +464,7 @@ def run_spmv(cx, weak):
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph, launch_mode = None, "eager"
-    if use_dist:
+    if use_dist and launch_mode == "graph":
         # ranks must agree on the launch mode only for reporting; the timed region has no collective in p2p mode
         launch_mode = "graph" if cx.all_reduce_scalar(1.0 if graph is not None else 0.0, dist.ReduceOp.MIN) > 0.5 \
             else "eager"
@@ -470,16 +476,30 @@ def run_spmv(cx, weak):
         for _ in range(preroll):
             graph.replay()
 
+    sequence = launch_mode == "sequence" and exchange in ("none", "p2p_fused")     # a step is exactly one launch
+
     def run_steps():
         if graph is not None:
             graph.replay()
+        elif sequence:
+            capi.spmv_sequence_device(mats, x_in, y, args.steps)
         else:
             for i in range(args.steps):
                 step(i)
-    dev_ms, wall = timed_region(cx, run_steps, lead_in=graph.replay if graph is not None else None)
+    if sequence:                                                # the same ~40 ms of sustained load in front of the region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run_steps()
+        e1.record()
+        torch.cuda.synchronize()
+        preroll = int(min(2000, max(2, 40.0 / max(e0.elapsed_time(e1), 1e-3))))
+        for _ in range(preroll):
+            run_steps()
+    dev_ms, wall = timed_region(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None))
     clock = "HIP events around the K timed steps on the launch stream" + (
         "; an untimed replay is queued in front of the first event so that the timed replay starts on a busy stream "
-        "(starting a graph on an idle stream costs ~15 us: 8 % of a 20-step region)" if graph is not None else "")
+        "(starting a graph on an idle stream costs ~15 us: 8 % of a 20-step region)" if graph is not None else
+        "; an untimed sequence of K launches is queued in front of the first event" if sequence else "")
     y_gpu = y.cpu().numpy()
     rows_wrong = None
     if use_dist:

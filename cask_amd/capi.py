@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
     "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
     "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
-    "cask_hip_solve_device",
+    "cask_hip_solve_device", "cask_hip_spmv_sequence_device",
 )
 SOLVER_CG, SOLVER_BICG = 1, 2
 SOLVER_AUTO, SOLVER_COMPOSED, SOLVER_CLASSIC = 0, 1, 2
@@ -130,6 +130,8 @@ def load() -> ctypes.CDLL:
         L.cask_hip_precond_apply_device.argtypes = [vp, vp, vp, vp]
         L.cask_hip_trsolve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp]
         L.cask_hip_pcg.argtypes = [vp, vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
+    if hasattr(L, "cask_hip_spmv_sequence_device"):
+        L.cask_hip_spmv_sequence_device.argtypes = [vp, i32, vp, vp, i32, vp]
     if hasattr(L, "cask_hip_solve_device"):
         L.cask_hip_solve_device.argtypes = [vp, vp, POINTER(SolverConfig), vp, vp, i32, dbl, POINTER(i32), POINTER(i32),
                                             POINTER(dbl), vp]
@@ -410,6 +412,13 @@ def trsolve(n, row_ptr, col_ind, values, rhs, lower=True) -> np.ndarray:
     x = np.empty(n, dtype=np.float64)
     _check(load().cask_hip_trsolve(n, ci.size, _p(rp), _p(ci), _p(va), int(bool(lower)), _p(b), _p(x)))
     return x
+
+
+def spmv_sequence_device(mats, x_t, y_t, k, stream=None):
+    """k products in stream order from one call: product i uses mats[i % len(mats)] (cask_hip_spmv_sequence_device)."""
+    arr = (c_void_p * len(mats))(*[m._h for m in mats])
+    _check(load().cask_hip_spmv_sequence_device(arr, len(mats), c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                                int(k), c_void_p(_stream_ptr(stream))))
 
 
 def _stream_ptr(stream):

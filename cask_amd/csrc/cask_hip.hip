@@ -1128,6 +1128,24 @@ int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, voi
   return launch_spmv(*m, d_x, d_y, static_cast<hipStream_t>(stream));
 }
 
+int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
+                                  int32_t k, void *stream) {
+  if (!mats || n_mats <= 0 || k < 0) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  for (int i = 0; i < n_mats; i++) {
+    if (!mats[i]) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+    if (mats[i]->n_rows != mats[0]->n_rows || mats[i]->n_cols != mats[0]->n_cols)
+      return fail(CASK_HIP_ERR_INVALID, "the handles of a sequence must have one shape");
+  }
+  if ((mats[0]->n_cols > 0 && !d_x) || (mats[0]->n_rows > 0 && !d_y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  if (reinterpret_cast<uintptr_t>(d_x) & 15) return fail(CASK_HIP_ERR_INVALID, "x must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < k; i++) {
+    int rc = launch_spmv(*mats[i % n_mats], d_x, d_y, s);
+    if (rc) return rc;
+  }
+  return CASK_HIP_OK;
+}
+
 int cask_hip_spmv_dot_device(cask_hip_matrix *m, const double *d_x, double *d_y, const double *d_w, double *d_result,
                              void *stream) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");

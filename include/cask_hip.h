@@ -152,6 +152,13 @@ int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y);
  * counterpart of the timed region in Spmv.cpp:270-285. */
 int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, void *stream);
 
+/* k products in stream order from ONE host call: product i is y = A_(i mod n_mats) x.  All handles have the
+ * shape of mats[0].  What a caller that issues many products back to back (a benchmark rotating over device
+ * copies of a matrix, a solver's inner loop) uses to keep the per-launch host cost at the runtime's launch cost
+ * instead of a language binding's call cost. */
+int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
+                                  int32_t k, void *stream);
+
 /* y = A x and *d_result = w . y in one pass (device vectors, asynchronous on `stream`): with a
  * MERGE design point every workgroup leaves its rows' share of the dot behind and a one-workgroup
  * kernel adds the shares in block order (reproducible); other design points run the product and

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Every bench.py workload / launch form once (1 rank, RCCL at world 1, 4-rank dry runs sharing the GPU); run on the GPU box.
 set -x
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > gpurun_out/b1.json 2> gpurun_out/b1.err; tail -c 600 gpurun_out/b1.err

@@ -1,3 +1,5 @@
+#!/bin/bash
+# tools/gatherbench.hip with timing and the L2->fabric read-request counters; run on the GPU box.
 cd $GRAFT_REPO_ROOT
 ./build/gatherbench
 cd /tmp && export TMPDIR=/tmp
