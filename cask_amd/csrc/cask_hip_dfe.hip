@@ -3,6 +3,7 @@
 // Compatibility path -- correctness first; the tuned path is cask_hip.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +71,53 @@ __global__ void k_dfe_block_starts(const int *__restrict__ colptr, int n, int n_
   }
 }
 
+// Run-length-encoded column pointers (SkipEmptyRowsSpmv, Spmv.hpp:213-250): in every block but the first and the
+// last, a run of k empty rows is ONE entry k | 1<<31 and a non-empty row keeps its cumulative end, so a block's
+// stream is shorter than n entries and where block b starts depends on all blocks before it -- on the DFE the read
+// control counts rows as it goes (ParallelCsrReadControl.java:175-189).  Here: does the stream carry any bit-31
+// entry at all (cumulative ends never do)? if so find every block's first entry by one counting walk over the
+// stream, then expand the blocks in parallel (one thread per block) into the plain n-entries-per-block form the
+// row kernel reads.
+__global__ void k_dfe_has_rle(const unsigned *__restrict__ colptr, long long len, int *flag) {
+  bool any = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    any = any || (colptr[i] & 0x80000000u);
+  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void k_dfe_rle_block_offsets(const unsigned *__restrict__ colptr, long long len, int n, int n_blocks,
+                                        long long *__restrict__ first_entry, int *err) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  long long i = 0;
+  for (int b = 0; b < n_blocks; b++) {
+    first_entry[b] = i;
+    long long rows = 0;
+    while (rows < n) {
+      if (i >= len) { *err = 1; return; }
+      const unsigned e = colptr[i++];
+      rows += (e & 0x80000000u) ? (long long)(e & 0x7fffffffu) : 1;
+    }
+    if (rows != n) { *err = 1; return; }
+  }
+  first_entry[n_blocks] = i;
+}
+__global__ void k_dfe_rle_expand(const unsigned *__restrict__ colptr, const long long *__restrict__ first_entry, int n,
+                                 int n_blocks, int *__restrict__ expanded) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  int *out = expanded + (long long)b * n;
+  int row = 0, prev = 0;
+  for (long long i = first_entry[b]; i < first_entry[b + 1] && row < n; i++) {
+    const unsigned e = colptr[i];
+    if (e & 0x80000000u) {
+      int k = (int)(e & 0x7fffffffu);
+      for (; k > 0 && row < n; k--) out[row++] = prev;
+    } else {
+      prev = (int)e;
+      out[row++] = prev;
+    }
+  }
+}
+
 // One thread per row; per column block: the row's run of packed {double value, int32 index} records
 // (12 bytes, Spmv.hpp:14-20) against that block's slice of x, partial sums added in block order
 // (SpmvKernel.java:61-78 + BramSpmvReductionKernel :250-309).
@@ -117,7 +165,7 @@ void cask_hip_dfe_dram_read(const cask_hip_dfe_config *cfg, int64_t size_bytes_c
 }
 
 void cask_hip_dfe_run(const cask_hip_dfe_config *cfg, int64_t nIterations, int64_t nBlocks, int64_t, const int64_t *colPtrStart,
-                      const int32_t *, const int64_t *recordsStart, const int32_t *, const int32_t *nrows,
+                      const int32_t *colptrSizes, const int64_t *recordsStart, const int32_t *, const int32_t *nrows,
                       const int64_t *outStart, const int32_t *, const int32_t *, const int64_t *vStart) {
   if (cfg->num_pipes <= 0 || cfg->num_controllers <= 0 || cfg->num_pipes % cfg->num_controllers != 0) {
     std::fprintf(stderr, "cask_hip_dfe: numPipes should be a multiple of numControllers\n");
@@ -140,10 +188,42 @@ void cask_hip_dfe_run(const cask_hip_dfe_config *cfg, int64_t nIterations, int64
       const unsigned *records = reinterpret_cast<const unsigned *>(base + recordsStart[p]);
       const double *x = reinterpret_cast<const double *>(base + vStart[p]);
       double *out = reinterpret_cast<double *>(base + outStart[p]);
+      // run-length-encoded column pointers? (only the first iteration needs to look)
+      int *expanded = nullptr;
+      if (nBlocks > 2 && colptrSizes && colptrSizes[p] > 0) {
+        const long long len = colptrSizes[p] / 4;
+        int *d_flag = nullptr, h_flag[2] = {0, 0};
+        DFE_CHECK(hipMalloc(reinterpret_cast<void **>(&d_flag), 2 * sizeof(int)));
+        DFE_CHECK(hipMemset(d_flag, 0, 2 * sizeof(int)));
+        hipLaunchKernelGGL(k_dfe_has_rle, dim3((unsigned)std::min<long long>(1024, (len + 255) / 256)), dim3(256), 0, 0,
+                           reinterpret_cast<const unsigned *>(colptr), len, d_flag);
+        DFE_CHECK(hipMemcpy(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (h_flag[0]) {
+          long long *d_first = nullptr;
+          DFE_CHECK(hipMalloc(reinterpret_cast<void **>(&d_first), sizeof(long long) * (size_t)(nBlocks + 1)));
+          DFE_CHECK(hipMalloc(reinterpret_cast<void **>(&expanded), sizeof(int) * (size_t)n * (size_t)nBlocks));
+          hipLaunchKernelGGL(k_dfe_rle_block_offsets, dim3(1), dim3(64), 0, 0, reinterpret_cast<const unsigned *>(colptr),
+                             len, n, (int)nBlocks, d_first, d_flag + 1);
+          hipLaunchKernelGGL(k_dfe_rle_expand, dim3(((int)nBlocks + 63) / 64), dim3(64), 0, 0,
+                             reinterpret_cast<const unsigned *>(colptr), d_first, n, (int)nBlocks, expanded);
+          DFE_CHECK(hipMemcpy(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost));
+          DFE_CHECK(hipFree(d_first));
+          if (h_flag[1]) {
+            std::fprintf(stderr, "cask_hip_dfe: run-length-encoded column pointers do not add up to %d rows per block\n", n);
+            std::abort();
+          }
+          colptr = expanded;
+        }
+        DFE_CHECK(hipFree(d_flag));
+      }
       hipLaunchKernelGGL(k_dfe_block_starts, dim3(1), dim3(64), 0, 0, colptr, n, (int)nBlocks, cfg->input_width, d_starts);
       hipLaunchKernelGGL(k_dfe_rows, dim3((n + 255) / 256), dim3(256), 0, 0, colptr, records, d_starts, x, n,
                          (int)nBlocks, cfg->cache_size, out);
       DFE_CHECK(hipGetLastError());
+      if (expanded) {
+        DFE_CHECK(hipDeviceSynchronize());
+        DFE_CHECK(hipFree(expanded));
+      }
     }
   DFE_CHECK(hipDeviceSynchronize());
   DFE_CHECK(hipFree(d_starts));

@@ -33,8 +33,28 @@ def _pad_to(arr, multiple_bytes):
     return np.concatenate([arr, np.zeros(add, dtype=arr.dtype)])
 
 
-def do_blocking(n_cols, rp, ci, va, cache_size, input_width):
-    """One partition (a row slice with n rows): returns dict(colptr, records, n, n_blocks, out_bytes, vlc)."""
+def encode_empty_rows(row_ends):
+    """SkipEmptyRowsSpmv::encodeEmptyRows (Spmv.hpp:213-237): a run of k empty rows becomes one entry k | 1<<31,
+    a non-empty row keeps its cumulative end."""
+    out, run, prev = [], 0, 0
+    for e in row_ends.tolist():
+        if e == prev:
+            run += 1
+        else:
+            if run:
+                out.append(run | (1 << 31))
+            run = 0
+            out.append(e)
+        prev = e
+    if run:
+        out.append(run | (1 << 31))
+    return np.asarray(out, dtype=np.uint32).view(np.int32)
+
+
+def do_blocking(n_cols, rp, ci, va, cache_size, input_width, rle=False):
+    """One partition (a row slice with n rows): returns dict(colptr, records, n, n_blocks, out_bytes, vlc).
+    rle: the SkipEmptyRowsSpmv architecture -- the column pointers of every block but the first and the last are
+    run-length encoded (preprocessBlock, Spmv.hpp:240-250)."""
     n = rp.size - 1
     n_blocks = n_cols // cache_size + (0 if n_cols % cache_size == 0 else 1)
     rows = np.repeat(np.arange(n), np.diff(rp))
@@ -43,7 +63,8 @@ def do_blocking(n_cols, rp, ci, va, cache_size, input_width):
     for b in range(n_blocks):
         sel = blk == b
         cnt = np.bincount(rows[sel], minlength=n)
-        colptr_parts.append(np.cumsum(cnt).astype(np.int32))            # n cumulative row ENDS, no leading 0
+        ends = np.cumsum(cnt).astype(np.int32)                          # n cumulative row ENDS, no leading 0
+        colptr_parts.append(encode_empty_rows(ends) if rle and 0 < b < n_blocks - 1 else ends)
         rec = np.zeros(int(sel.sum()), dtype=RECORD)
         rec["value"] = va[sel]
         rec["index"] = ci[sel] - b * cache_size
@@ -55,10 +76,10 @@ def do_blocking(n_cols, rp, ci, va, cache_size, input_width):
             "n": n, "n_blocks": n_blocks, "out_bytes": out_len * 8, "vector_load_cycles": v_len // max(n_blocks, 1)}
 
 
-def preprocess(n_rows, n_cols, rp, ci, va, num_pipes, cache_size, input_width):
+def preprocess(n_rows, n_cols, rp, ci, va, num_pipes, cache_size, input_width, rle=False):
     per = n_rows // num_pipes
     if per == 0:
-        p = do_blocking(n_cols, rp, ci, va, cache_size, input_width)
+        p = do_blocking(n_cols, rp, ci, va, cache_size, input_width, rle)
         z = dict(p)
         z["records"] = p["records"].copy()
         z["records"]["value"] = 0
@@ -67,7 +88,7 @@ def preprocess(n_rows, n_cols, rp, ci, va, num_pipes, cache_size, input_width):
     for i in range(num_pipes):
         cnt = per if i < num_pipes - 1 else n_rows - start
         k0, k1 = rp[start], rp[start + cnt]
-        parts.append(do_blocking(n_cols, rp[start:start + cnt + 1] - k0, ci[k0:k1], va[k0:k1], cache_size, input_width))
+        parts.append(do_blocking(n_cols, rp[start:start + cnt + 1] - k0, ci[k0:k1], va[k0:k1], cache_size, input_width, rle))
         start += cnt
     return parts
 

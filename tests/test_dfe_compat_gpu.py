@@ -78,3 +78,31 @@ def test_stream_format_restatement_matches_the_cpu_decoder():
                                                       np.frombuffer(p["records"].tobytes(), dtype=np.uint8), xp)
                         for p in parts])
     oracle.assert_almost_equal(y, oracle.csr_spmv(m.row_ptr, m.col_ind, m.values, x), what="format restatement")
+
+
+@pytest.mark.parametrize("arch", [(2, 2, 32, 4), (1, 1, 64, 16), (3, 3, 1024, 8)], ids=lambda a: "p%d_c%d_cache%d_w%d" % a)
+def test_triple_decodes_run_length_encoded_column_pointers(arch, expected_y):
+    """SkipEmptyRowsSpmv's stream (Spmv.hpp:213-250): middle blocks carry runs of empty rows as `length | 1<<31`.
+    The reference only ever ran it against the mock; here the GPU decodes it, and the C decoder of the oracle agrees."""
+    pipes, ctrls, cache, width = arch
+    cfg = Cfg(pipes, ctrls, cache, width)
+    triple, lib = make_triple(cfg)
+    some_rle = False
+    for key, path in golden_matrix_files():
+        m = mmio.read_matrix(path)
+        if m.n > 16000 or m.m // cache > 600:
+            continue
+        parts = dfe_format.preprocess(m.n, m.m, m.row_ptr, m.col_ind, m.values, pipes, cache, width, rle=True)
+        plain = dfe_format.preprocess(m.n, m.m, m.row_ptr, m.col_ind, m.values, pipes, cache, width)
+        some_rle = some_rle or any(p["colptr"].size < q["colptr"].size for p, q in zip(parts, plain))
+        x = mmio.test_vector(m.m)
+        got = dfe_format.spmv_through_triple(triple, m.n, parts, x, pipes, ctrls, cache)
+        oracle.assert_almost_equal(got, expected_y[key], what=f"rle {key} {arch}")
+        if m.n <= 200:                                          # and the CPU decoder of the same stream
+            xp = np.concatenate([x, np.zeros((-x.size) % cache)])
+            y = np.concatenate([oracle.partition_decode_spmv(p["n"], p["n_blocks"], cache, width, True, p["colptr"],
+                                                              np.frombuffer(p["records"].tobytes(), dtype=np.uint8), xp)
+                                for p in parts])
+            oracle.assert_almost_equal(y[: m.n] if m.n >= pipes else y[: m.n], expected_y[key], what=f"rle cpu {key}")
+    assert some_rle, "no fixture produced an encoded block: the test would prove nothing"
+    lib.cask_hip_dfe_reset()
