@@ -53,9 +53,9 @@ clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip build/te
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel
-ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p cask_hip_precond merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
+ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p cask_hip_precond cask_hip_rccl merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
 ENGINEOBJ  := $(ENGINESRC:%=build/obj/%.o)
-ENGINEHDR  := $(wildcard cask_amd/csrc/*.hpp) include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h
+ENGINEHDR  := $(wildcard cask_amd/csrc/*.hpp) include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h include/cask_hip_rccl.h
 build/obj/%.o: cask_amd/csrc/%.hip $(ENGINEHDR)
 	mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
@@ -82,12 +82,12 @@ clean:
 # diagnostic build with in-kernel phase stamps (tools/stamps.py); never used by tests or bench
 build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip
+	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip cask_amd/csrc/cask_hip_rccl.hip
 
 # ablation builds of the solver pass (development only): build/libcask_hip_abl<N>.so
 build/libcask_hip_abl%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DCASK_ABL=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip
+	$(HIPCC) $(HIPFLAGS) -DCASK_ABL=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip cask_amd/csrc/cask_hip_rccl.hip
 
 # row f3: MatrixMarket ingest timing (host only)
 build/ingest_time: tools/ingest_time.cpp $(HOSTHDR)

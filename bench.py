@@ -693,7 +693,8 @@ def run_solver(cx):
                                     "all_gather": "per product: RCCL all_gather of the operand; dot products: RCCL all_reduce"}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if world > 1 else None,
                        "solve_check": check, "design_point": sh.matrix.params.as_dict(),
-                       "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3)},
+                       "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3),
+                       "collectives": getattr(sh, "last_collectives", "none")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                          "kernel": f"{kind} pass (k_spmv_merge + update kernels)",

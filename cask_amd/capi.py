@@ -338,11 +338,17 @@ class CsrMatrix:
         cfg.stride = stride
         cfg.n_full = n_full
         keep = []
-        if allreduce is not None:
+        if isinstance(allreduce, NativeComm):                  # RCCL issued by the engine itself (include/cask_hip_rccl.h)
+            cfg.allreduce = ctypes.cast(load().cask_hip_rccl_allreduce, ALLREDUCE_FN)
+            cfg.allreduce_user = allreduce.handle
+        elif allreduce is not None:
             cb = ALLREDUCE_FN(lambda p, c, s, u: int(allreduce(p, c, s) or 0))
             cfg.allreduce = cb
             keep.append(cb)
-        if exchange is not None:
+        if isinstance(exchange, NativeComm):
+            cfg.exchange = ctypes.cast(load().cask_hip_rccl_allgather, EXCHANGE_FN)
+            cfg.exchange_user = exchange.handle
+        elif exchange is not None:
             cb2 = EXCHANGE_FN(lambda a, b, s, u: int(exchange(a, b, s) or 0))
             cfg.exchange = cb2
             keep.append(cb2)
@@ -357,6 +363,62 @@ class CsrMatrix:
         """Preconditioned CG (pcg<double, Precon>, SparseLinearSolvers.hpp:162-239) with a ``Preconditioner``."""
         fn = load().cask_hip_pcg
         return self._solve(lambda h, *a: fn(h, precond._h if precond is not None else None, *a), rhs, x0, maxiters, tol)
+
+
+RCCL_SYMBOLS = ("cask_hip_rccl_unique_id", "cask_hip_rccl_comm_create", "cask_hip_rccl_comm_destroy",
+                "cask_hip_rccl_allreduce", "cask_hip_rccl_allgather")
+
+
+class NativeComm:
+    """An RCCL communicator owned by the engine (include/cask_hip_rccl.h): the all-reduce / operand all-gather of a
+    row-sharded solve issued from C on the solver's stream.  ``unique_id()`` on rank 0, ship the bytes, then
+    ``NativeComm(id, rank, world, bounds)`` on every rank (collective)."""
+
+    @staticmethod
+    def _lib():
+        L = load()
+        if not getattr(L, "_rccl_bound", False):
+            L.cask_hip_rccl_unique_id.argtypes = [c_void_p]
+            L.cask_hip_rccl_comm_create.argtypes = [c_void_p, c_int32, c_int32, c_void_p, POINTER(c_void_p)]
+            L.cask_hip_rccl_comm_destroy.argtypes = [c_void_p]
+            L.cask_hip_rccl_allreduce.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+            L.cask_hip_rccl_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+            for name in RCCL_SYMBOLS:
+                getattr(L, name).restype = ctypes.c_int
+            L._rccl_bound = True
+        return L
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_ubyte * 128)()
+        _check(NativeComm._lib().cask_hip_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, world: int, bounds=None):
+        L = self._lib()
+        b = np.ascontiguousarray(bounds, dtype=np.int64) if bounds is not None else None
+        h = c_void_p()
+        idbuf = (ctypes.c_ubyte * 128).from_buffer_copy(uid)
+        _check(L.cask_hip_rccl_comm_create(idbuf, rank, world, _p(b) if b is not None else None, byref(h)))
+        self.handle = h
+
+    def allreduce(self, t, stream=None):
+        _check(self._lib().cask_hip_rccl_allreduce(c_void_p(t.data_ptr()), t.numel(), c_void_p(_stream_ptr(stream)), self.handle))
+
+    def allgather(self, local_t, full_t, stream=None):
+        _check(self._lib().cask_hip_rccl_allgather(c_void_p(local_t.data_ptr()), c_void_p(full_t.data_ptr()),
+                                                   c_void_p(_stream_ptr(stream)), self.handle))
+
+    def close(self):
+        if self.handle:
+            self._lib().cask_hip_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Preconditioner:

@@ -217,6 +217,47 @@ class ShardedSpmv:
         return s
 
     # -- solvers: the engine's own kernels and recurrences (cask_hip_solve_device) ----------------------
+    def native_comm(self):
+        """The engine's own RCCL communicator over this operator's ranks (include/cask_hip_rccl.h), created on first
+        use -- collectively: every rank must come here -- when the process group runs on the nccl backend.  None if
+        RCCL cannot be opened on some rank, or with CASK_NO_NATIVE_RCCL set: the solvers then fall back to the
+        torch.distributed callbacks."""
+        import os
+        import torch.distributed as dist
+        if getattr(self, "_native_tried", False):
+            return self._native
+        self._native_tried, self._native = True, None
+        if os.environ.get("CASK_NO_NATIVE_RCCL") or not dist.is_initialized() or dist.get_backend(self.group) != "nccl":
+            return None
+        from . import capi
+        torch = self.torch
+        uid, err = [None], None
+        if self.rank == 0:
+            try:
+                uid[0] = capi.NativeComm.unique_id()
+            except Exception as e:  # noqa: BLE001 - agreed on below
+                err = repr(e)
+        dist.broadcast_object_list(uid, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
+        comm = None
+        if uid[0] is not None:
+            try:
+                comm = capi.NativeComm(uid[0], self.rank, self.world, self.bounds)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if float(ok[0]) < 0.5:
+            if comm is not None:
+                comm.close()
+            if self.rank == 0:
+                import sys
+                print(f"[cask_amd.dist] native RCCL unavailable ({err}); using torch.distributed callbacks", file=sys.stderr)
+            return None
+        self._native = comm
+        return comm
+
+
     def _allreduce_callback(self):
         """``allreduce(ptr, count, stream) -> 0`` for cask_hip_solve_device: sums ``count`` doubles at a device
         address over the ranks of ``self.group``, ordered on torch's current stream (the one the solver runs
@@ -272,8 +313,9 @@ class ShardedSpmv:
         # CASK_FORCE_COLLECTIVES: take the row-sharded path (callbacks, RCCL collectives) with a single rank -- how the
         # nccl backend is exercised on a 1-GPU box
         collective = self.world > 1 or (bool(os.environ.get("CASK_FORCE_COLLECTIVES")) and dist.is_initialized())
+        native = self.native_comm() if collective else None
         if collective:
-            kw["allreduce"] = self._allreduce_callback()
+            kw["allreduce"] = native if native is not None else self._allreduce_callback()
             if mode == capi.SOLVER_AUTO:
                 # every rank must run the same form of pass (same collectives): composed only if every rank's
                 # design points have the fused dot epilogue (a block with < 2 nonzeros runs the VECTOR kernel)
@@ -290,7 +332,9 @@ class ShardedSpmv:
                 raise RuntimeError("A and A^T must share one PeerExchange (from_global(..., share_with=...))")
             kw.update(shared_base=ex.shared.ptr, stride=ex.stride)
         elif collective:
-            kw.update(exchange=self._exchange_callback(), n_full=self.n)
+            kw.update(exchange=native if native is not None else self._exchange_callback(), n_full=self.n)
+        self.last_collectives = "native RCCL (issued by the engine)" if native is not None else (
+            "torch.distributed callbacks" if collective else "none")
         it, conv, us = self.matrix.solve_device(b_local.contiguous(), x, kind=kind,
                                                 transposed=transposed.matrix if transposed is not None else None,
                                                 mode=mode, maxiters=maxiters, tol=tol, **kw)

@@ -85,6 +85,12 @@ def test_rccl_collectives_run_at_world_one():
     chk = rec["config"]["solve_check"]
     assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
     assert chk["residual_2norm_by_oracle_product"] <= 2e-5
+    assert rec["config"]["collectives"].startswith("native RCCL")          # ncclAllReduce / ncclAllGather from the engine
+    # ... and the same through the torch.distributed callbacks
+    env.update(MASTER_PORT=str(free_port()), CASK_NO_NATIVE_RCCL="1")
+    rec2 = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
+    assert rec2["config"]["collectives"] == "torch.distributed callbacks"
+    assert rec2["config"]["solve_check"]["iterations"] == chk["iterations"]
 
 
 def test_config4_webbase_row_partitioned_dry_run():

@@ -47,6 +47,19 @@ def test_dfe_compat_triple_is_exported():
         assert re.search(rf"\bT {name}\b", out), name
 
 
+def test_native_rccl_entry_points_are_exported_without_a_link_dependency():
+    """include/cask_hip_rccl.h: the collectives of the sharded solvers issued by the engine; RCCL itself is opened at
+    run time, so the library must not name it as a dependency."""
+    text = re.sub(r"/\*.*?\*/", "", (REPO / "include" / "cask_hip_rccl.h").read_text(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cask_hip_rccl_[a-z_]+)\s*\(", text)))
+    assert declared == sorted(capi.RCCL_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(capi.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), name
+    needed = subprocess.run(["readelf", "-d", str(capi.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+
+
 def test_code_object_is_gfx950_only():
     blob = capi.LIB_PATH.read_bytes()
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
