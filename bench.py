@@ -301,7 +301,7 @@ def run_spmv(cx, weak):
     x_slice = x_host[bounds[rank]:bounds[rank + 1]].copy()
 
     # ---- exchange (N > 1): in-kernel halo / halo pull over shared slices, or RCCL all-gather ------------
-    exchange, peer, p2p_error, halo_frac = "none", None, None, 0.0
+    exchange, peer, p2p_error, halo_frac, native = "none", None, None, 0.0, None
     ci_dev, n_cols_dev = ci, n_global
     if use_dist:
         from cask_amd import p2p
@@ -397,6 +397,7 @@ def run_spmv(cx, weak):
         gather = cdist.ShardedSpmv(bounds, rank, world, None, dev)
         x_local = torch.from_numpy(x_slice).to(dev)
         x_in = gather.x_full
+        native = gather.native_comm()                            # the engine's own RCCL communicator (nccl backend), else None
         gather.gather_x(x_local)
     else:
         x_in = torch.from_numpy(x_host).to(dev)
@@ -422,7 +423,10 @@ def run_spmv(cx, weak):
         if exchange == "p2p":
             peer.pull()                                          # remote loads over xGMI, on the launch stream
         elif exchange == "all_gather":
-            gather.gather_x(x_local)                             # RCCL all_gather_into_tensor (uneven slices padded)
+            if native is not None:
+                native.allgather(x_local, x_in)                  # ncclAllGather (uneven slices: grouped broadcasts) on this stream
+            else:
+                gather.gather_x(x_local)                         # torch.distributed all_gather_into_tensor (uneven slices padded)
         mats[i % copies].spmv_device(x_in, y)
 
     # ---- warm-up (eager) -------------------------------------------------------
@@ -555,7 +559,8 @@ def run_spmv(cx, weak):
                                                  "(one launch per step, no collective)",
                                     "p2p": f"per step: pull of {peer.n_halo if peer else 0} halo entries over xGMI from the "
                                            "neighbours' shared x slices (one kernel, no collective)",
-                                    "all_gather": "per step: RCCL all_gather(x)"}[exchange],
+                                    "all_gather": "per step: RCCL all_gather(x)" + (
+                                        " issued by the engine (cask_hip_rccl_allgather)" if native is not None else "")}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
                        "matrix_copies_rotated": copies, "launch": launch_mode, "untimed_preroll_replays": preroll, "design_point": design,
