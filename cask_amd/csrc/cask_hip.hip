@@ -1327,7 +1327,25 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
   if (warmup < 0) warmup = 0;
   warmup = std::min(warmup, 3);
   HIP_TRY(hipSetDevice(m->device));
-  if (m->halo_addr) return fail(CASK_HIP_ERR_INVALID, "tune the block before attaching halo sources");
+  // A block with halo sources is tuned with them detached: its extended columns then index the caller-sized x of the
+  // sweep (own entries + a local halo copy), the shapes are ranked without the remote loads, and the halo comes back
+  // on the winner.
+  const int saved_n_own = m->halo_n_own;
+  const uint64_t *saved_halo = m->halo_addr;
+  struct HaloGuard {
+    cask_hip_matrix *m; int n_own; const uint64_t *addr;
+    ~HaloGuard() {
+      if (addr && !m->halo_addr) {
+        m->halo_n_own = n_own;
+        m->halo_addr = addr;
+        (void)build_plan(*m, m->requested);
+      }
+    }
+  } halo_guard{m, saved_n_own, saved_halo};
+  if (saved_halo) {
+    m->halo_n_own = std::numeric_limits<int>::max();
+    m->halo_addr = nullptr;
+  }
   DevBuf<double> x, y;
   HIP_TRY(x.alloc(m->n_cols));
   HIP_TRY(y.alloc(m->n_rows));
@@ -1414,6 +1432,10 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
           }
   if (n_results) *n_results = std::min(count, max_results);
   if (best_index) *best_index = (best < max_results) ? best : -1;
+  if (saved_halo) {                                           // back on, before the winner's plan is built
+    m->halo_n_own = saved_n_own;
+    m->halo_addr = saved_halo;
+  }
   int rc;
   if (best >= 0) {
     rc = build_plan(*m, best_params);
