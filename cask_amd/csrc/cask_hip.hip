@@ -1063,7 +1063,7 @@ int cask_hip_csr_create_device(int32_t n_rows, int32_t n_cols, int64_t nnz, cons
     DevBuf<int> range;
     const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::min()};
     HIP_TRY(range.upload(init, 2));
-    const int grid = (int)std::min<int64_t>(1024, (nnz + 255) / 256);
+    const int grid = (int)std::min<int64_t>(256, (nnz + 255) / 256);
     hipLaunchKernelGGL(k_col_range, dim3(grid), dim3(256), 0, nullptr, nnz, d_col_ind, range.p);
     HIP_TRY(hipGetLastError());
     int got[2];

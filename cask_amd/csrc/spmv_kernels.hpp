@@ -388,7 +388,11 @@ __global__ void k_col_range(int64_t n, const int *__restrict__ ci, int *out) {
     lo = min(lo, __shfl_xor(lo, o));
     hi = max(hi, __shfl_xor(hi, o));
   }
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ int slo[16], shi[16];                            // one atomic pair per workgroup, not per wave
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) { lo = min(lo, slo[w]); hi = max(hi, shi[w]); }
     atomicMin(out, lo);
     atomicMax(out + 1, hi);
   }

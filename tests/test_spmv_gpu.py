@@ -398,3 +398,24 @@ def test_cant3_fem_blocks_wide_band():
     m = capi.CsrMatrix.from_host(n2, n2, rp2, ci2, va2)
     oracle.assert_almost_equal(m.spmv(x2), oracle.csr_spmv(rp2, ci2, va2, x2), what="cant3 x_fastest")
     m.close()
+
+
+def test_sequence_of_products_from_one_call():
+    """cask_hip_spmv_sequence_device: k products in stream order, rotating over handles of one shape (what bench.py
+    times for short regions); the last product's y is the last handle's."""
+    import torch
+    n, rp, ci, va = synth.small("cant", factor=32)
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    mats = [capi.CsrMatrix.from_host(n, n, rp, ci, va * s) for s in (1.0, 2.0, 3.0)]
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    base = oracle.csr_spmv(rp, ci, va, x)
+    for k, scale in ((1, 1.0), (5, 2.0), (9, 3.0)):             # product k-1 uses handle (k-1) % 3
+        capi.spmv_sequence_device(mats, xt, yt, k)
+        torch.cuda.synchronize()
+        oracle.assert_almost_equal(yt.cpu().numpy(), scale * base, what=f"sequence k={k}")
+    other = capi.CsrMatrix.from_host(4, 4, [0, 1, 2, 3, 4], [0, 1, 2, 3], [1.0] * 4)
+    with pytest.raises(ValueError):
+        capi.spmv_sequence_device([mats[0], other], xt, yt, 2)
+    for m in mats + [other]:
+        m.close()
