@@ -202,14 +202,22 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
                               double *alpha_out, const int *done, int sys_scope) {
   __shared__ double red[16];
   if (*done) return;
-  const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   const dbl2 *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r);
+  // every lane's first pair is requested BEFORE the partial sums are waited for: the sums are a dependent L2 round
+  // trip at the head of every workgroup (~1 us), the vector loads do not depend on alpha
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));
+  const dbl2 zero2 = {0.0, 0.0};
+  const dbl2 av0 = n2 ? Ap2[i0] : zero2;
+  const dbl2 rv0 = n2 ? r2[i0] : zero2;
+  const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   double acc0 = 0.0, acc1 = 0.0;
-  CASK_PAIR_LOOP(n >> 1) {
-    const dbl2 av = Ap2[i];
-    dbl2 rv = r2[i];
+  for (bool first = true; i < n2; i += stride, first = false) {
+    const dbl2 av = first ? av0 : Ap2[i];
+    dbl2 rv = first ? rv0 : r2[i];
     rv.x = fma(-alpha, av.x, rv.x);
     rv.y = fma(-alpha, av.y, rv.y);
     store_pair(r2 + i, rv, sys_scope);
@@ -233,14 +241,19 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
                                 double *__restrict__ part_rho, double *alpha_out, const int *done, int sys_scope) {
   __shared__ double red[16];
   if (*done) return;
-  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   const dbl2 *q2 = reinterpret_cast<const dbl2 *>(q), *qt2 = reinterpret_cast<const dbl2 *>(qt);
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
+  const dbl2 zero2 = {0.0, 0.0};
+  const dbl2 qv0 = n2 ? q2[i0] : zero2, qtv0 = n2 ? qt2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2, rtv0 = n2 ? rt2[i0] : zero2;
+  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   double a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
-  CASK_PAIR_LOOP(n >> 1) {
-    const dbl2 qv = q2[i], qtv = qt2[i];
-    dbl2 rv = r2[i], rtv = rt2[i];
+  for (bool first = true; i < n2; i += stride, first = false) {
+    const dbl2 qv = first ? qv0 : q2[i], qtv = first ? qtv0 : qt2[i];
+    dbl2 rv = first ? rv0 : r2[i], rtv = first ? rtv0 : rt2[i];
     rv.x = fma(-alpha, qv.x, rv.x);
     rv.y = fma(-alpha, qv.y, rv.y);
     rtv.x = fma(-alpha, qtv.x, rtv.x);
@@ -277,18 +290,23 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
                                int *done, int *iters, int sys_scope) {
   __shared__ double red[16];
   if (*done) return;
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
+  const dbl2 zero2 = {0.0, 0.0};
+  const dbl2 pv0 = n2 ? p2[i0] : zero2, xv0 = n2 ? x2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2;
   const double rsnew = partials_or_scalar(part_rr, n_part, red);
   const bool stop = rsnew <= tol2;
   const double a = *alpha, beta = stop ? 0.0 : rsnew / *rsold;
-  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
-  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
-  CASK_PAIR_LOOP(n >> 1) {
-    dbl2 pv = p2[i], xv = x2[i];
+  for (bool first = true; i < n2; i += stride, first = false) {
+    dbl2 pv = first ? pv0 : p2[i], xv = first ? xv0 : x2[i];
     xv.x = fma(a, pv.x, xv.x);
     xv.y = fma(a, pv.y, xv.y);
     x2[i] = xv;
     if (!stop) {                                              // launch-uniform
-      const dbl2 rv = r2[i];
+      const dbl2 rv = first ? rv0 : r2[i];
       pv.x = fma(beta, pv.x, rv.x);
       pv.y = fma(beta, pv.y, rv.y);
       store_pair(p2 + i, pv, sys_scope);
@@ -313,21 +331,27 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
                                  int *iters, int sys_scope) {
   __shared__ double red[16];
   if (*done) return;
+  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
+  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt), *x2 = reinterpret_cast<dbl2 *>(x);
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
+  const dbl2 zero2 = {0.0, 0.0};
+  const dbl2 pv0 = n2 ? p2[i0] : zero2, xv0 = n2 ? x2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2, rtv0 = n2 ? rt2[i0] : zero2,
+             ptv0 = n2 ? pt2[i0] : zero2;
   const double rr = partials_or_scalar(part_rr, n_part, red);
   const bool stop = rr <= tol2;
   double rho_new = 0.0;
   if (!stop) rho_new = partials_or_scalar(part_rho, n_part, red);
   const double a = *alpha, beta = stop ? 0.0 : rho_new / *rho;
-  const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
-  dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt), *x2 = reinterpret_cast<dbl2 *>(x);
-  CASK_PAIR_LOOP(n >> 1) {
-    dbl2 pv = p2[i], xv = x2[i];
+  for (bool first = true; i < n2; i += stride, first = false) {
+    dbl2 pv = first ? pv0 : p2[i], xv = first ? xv0 : x2[i];
     xv.x = fma(a, pv.x, xv.x);
     xv.y = fma(a, pv.y, xv.y);
     x2[i] = xv;
     if (!stop) {
-      const dbl2 rv = r2[i], rtv = rt2[i];
-      dbl2 ptv = pt2[i];
+      const dbl2 rv = first ? rv0 : r2[i], rtv = first ? rtv0 : rt2[i];
+      dbl2 ptv = first ? ptv0 : pt2[i];
       pv.x = fma(beta, pv.x, rv.x);
       pv.y = fma(beta, pv.y, rv.y);
       ptv.x = fma(beta, ptv.x, rtv.x);
