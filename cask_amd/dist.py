@@ -132,12 +132,20 @@ class ShardedSpmv:
             obj = cls(bounds, rank, world, lambda xe, yl: mat.spmv_device(xe, yl), dev, group, exchange=ex)
             obj.fused_halo = False
             obj.n_halo = n_halo
-            if fused_halo and mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2:
-                if n_halo:
-                    mat.set_halo_sources(n_local, addr)   # the product kernel reads the halo from the peers itself
-                obj.fused_halo = True
-            elif ex.n_slots != 1 or share_with is not None:
-                raise capi.CaskHipError("solver slots / shared vectors need the in-kernel halo (MERGE variant)")
+            can_fuse = mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2
+            if fused_halo:
+                # every rank or none: a block too small for the MERGE kernel on ONE rank must not leave the others
+                # waiting in a collective
+                can_all = all(gather_objects(bool(can_fuse)))
+                if can_all:
+                    if n_halo:
+                        mat.set_halo_sources(n_local, addr)   # the product kernel reads the halo from the peers itself
+                    obj.fused_halo = True
+                elif ex.n_slots != 1 or share_with is not None:
+                    if share_with is None:
+                        obj.close()
+                    raise capi.CaskHipError("solver slots / shared vectors need the in-kernel halo, and some rank's block "
+                                            "cannot run the MERGE kernel (fewer than 2 nonzeros)")
         elif exchange == "all_gather":
             mat = capi.CsrMatrix.from_host(n_local, n_cols, rp, ci, va, params)
             obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)

@@ -234,3 +234,69 @@ def test_eight_way_partition_block_by_block(name):
         torch.cuda.synchronize()
         m.close()
         oracle.assert_almost_equal(y.cpu().numpy(), want[bounds[g]:bounds[g + 1]], what=f"{name} block {g}/8")
+
+
+def _tiny_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from cask_amd import capi
+    from cask_amd import dist as cdist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, rp, ci, va, b = _tiny_system()
+        bounds = [0, 3, 6, 7]                       # rank 2 owns ONE row with ONE nonzero: no MERGE plan there
+
+        def fence():
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        res = {}
+        try:
+            cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, exchange="p2p", fence=fence, fused_halo=True,
+                                          solver_slots=3, bounds=bounds)
+            res["p2p"] = "built"
+        except capi.CaskHipError as e:
+            res["p2p"] = "refused: " + str(e)[:40]
+        sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, bounds=bounds)
+        res["fuses_dot"] = bool(sh.matrix.info.fuses_dot)
+        bl = torch.from_numpy(b[bounds[rank]:bounds[rank + 1]].copy()).cuda()
+        xs, it, conv = sh.cg(bl, tol=1e-12)
+        torch.cuda.synchronize()
+        res.update(x=xs.cpu().numpy(), it=it, conv=conv)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def _tiny_system():
+    import scipy.sparse as sp
+    a = sp.diags([np.arange(2.0, 9.0)], [0], format="lil")
+    for i, j, v in ((0, 1, 0.5), (1, 2, -0.25), (2, 4, 0.125), (3, 5, 0.5), (0, 5, -0.5)):
+        a[i, j] = v
+        a[j, i] = v
+    a = sp.csr_matrix(a)
+    a.sort_indices()
+    x0 = np.arange(1.0, 8.0)
+    return 7, a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64), a @ x0
+
+
+def test_a_rank_without_a_merge_plan_does_not_strand_the_others():
+    """Every rank of a sharded solve must take the same form of pass.  A block with fewer than 2 nonzeros runs the
+    VECTOR kernel (no dot epilogue, no in-kernel halo): the in-kernel-halo construction is then refused on EVERY rank
+    (a refusal on one rank alone would leave the others in a collective), and the all-gather solver agrees on the
+    classic pass collectively."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tiny_worker, args=(3, free_port(), out), nprocs=3, join=True)
+    res = [out[r] for r in range(3)]
+    assert all(r["p2p"].startswith("refused") for r in res), [r["p2p"] for r in res]
+    assert [r["fuses_dot"] for r in res] == [True, True, False]
+    n, rp, ci, va, b = _tiny_system()
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b, tol=1e-12)
+    assert want_conv and all(r["conv"] for r in res) and len({r["it"] for r in res}) == 1
+    assert abs(res[0]["it"] - want_it) <= 1
+    np.testing.assert_allclose(np.concatenate([r["x"] for r in res]), np.arange(1.0, 8.0), rtol=1e-10, atol=1e-10)
