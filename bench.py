@@ -146,8 +146,87 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
     return out
 
 
+def mkl_solver_passes(mkl, kind, rp, ci, va, b, passes, threads):
+    """`passes` passes of the reference's CG recurrence (pcg, SparseLinearSolvers.hpp:200-232: product, ddot, daxpy,
+    daxpby) -- or of BiCG with the transposed product -- on MKL calls, as the reference's CPU path makes them (it calls
+    mkl_dcsrsymv on the stored triangle; the full-matrix mkl_cspblas_dcsrgemv does the same flops).  Seconds."""
+    n = rp.size - 1
+    mkl.MKL_Set_Num_Threads(ctypes.c_int(threads))
+    mkl.cblas_ddot.restype = ctypes.c_double
+    p_ = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    nn, trN, trT = ctypes.c_int(n), ctypes.c_char(b"N"), ctypes.c_char(b"T")
+
+    def gemv(tr, x, y):
+        mkl.mkl_cspblas_dcsrgemv(ctypes.byref(tr), ctypes.byref(nn), p_(va), p_(rp), p_(ci), p_(x), p_(y))
+
+    dot = lambda x, y: mkl.cblas_ddot(n, p_(x), 1, p_(y), 1)  # noqa: E731
+    axpy = lambda a, x, y: mkl.cblas_daxpy(n, ctypes.c_double(a), p_(x), 1, p_(y), 1)  # noqa: E731
+    axpby = lambda a, x, bb, y: mkl.cblas_daxpby(n, ctypes.c_double(a), p_(x), 1, ctypes.c_double(bb), p_(y), 1)  # noqa: E731
+    x, r = np.zeros(n), b.copy()
+    p, q = r.copy(), np.zeros(n)
+    if kind == "bicg":
+        rt, pt, qt = r.copy(), r.copy(), np.zeros(n)
+    rho = dot(r, r)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        gemv(trN, p, q)
+        if kind == "cg":
+            alpha = rho / max(dot(p, q), 1e-300)
+            axpy(alpha, p, x)
+            axpy(-alpha, q, r)
+            rho_new = dot(r, r)
+            axpby(1.0, r, rho_new / max(rho, 1e-300), p)
+        else:
+            gemv(trT, pt, qt)
+            alpha = rho / max(dot(pt, q), 1e-300)
+            axpy(alpha, p, x)
+            axpy(-alpha, q, r)
+            axpy(-alpha, qt, rt)
+            dot(r, r)
+            rho_new = dot(rt, r)
+            beta = rho_new / (rho if rho != 0 else 1e-300)
+            axpby(1.0, r, beta, p)
+            axpby(1.0, rt, beta, pt)
+        rho = rho_new if np.isfinite(rho_new) and rho_new != 0 else 1.0
+    return time.perf_counter() - t0
+
+
 def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
-    """The oracle's CG / BiCG (1 core) for a bounded number of passes; GFLOP/s on the same flop count as `value`."""
+    """MKL (the reference's CPU path: pcg on mkl_dcsrsymv + cblas, SparseLinearSolvers.hpp:162-239) on pinned threads,
+    and the oracle's CG / BiCG (1 core) as the secondary figure; a bounded number of passes each; GFLOP/s on the same
+    flop count as `value`."""
+    port = cpu_baseline_solver_port(kind, rp, ci, va, b, min(seconds, 4.0))
+    mkl = load_mkl()
+    if mkl is None:
+        return port
+    try:
+        n, nnz = rp.size - 1, int(ci.size)
+        flops = (2 * nnz + 12 * n) if kind == "cg" else (4 * nnz + 20 * n)
+        mkl.MKL_Get_Max_Threads.restype = ctypes.c_int
+        max_threads = int(mkl.MKL_Get_Max_Threads())
+        by_threads, best = {}, None
+        for t in sorted({t for t in (8, 16, 32, 64) if t <= max_threads} | {min(16, max_threads)}):
+            mkl_solver_passes(mkl, kind, rp, ci, va, b, 3, t)                     # warm-up
+            passes = 20
+            el = mkl_solver_passes(mkl, kind, rp, ci, va, b, passes, t)
+            if el < seconds / 8:
+                passes = int(min(2000, passes * (seconds / 4) / max(el, 1e-4)))
+                el = mkl_solver_passes(mkl, kind, rp, ci, va, b, passes, t)
+            rate = flops * passes / el / 1e9
+            by_threads[str(t)] = round(rate, 3)
+            if best is None or rate > best[0]:
+                best = (rate, t, passes, el)
+        return {"value": round(best[0], 4), "unit": "GFLOP/s", "cores": best[1], "kind": "mkl",
+                "routine": f"{kind} passes on mkl_cspblas_dcsrgemv + cblas_ddot/daxpy/daxpby (oneMKL, GNU threading layer, pinned)",
+                "host_cores": os.cpu_count(), "sample": f"{best[2]} passes with {best[1]} threads in {best[3]:.1f} s",
+                "gflops_by_threads": by_threads, "port": port}
+    except Exception as e:  # pragma: no cover - diagnostic only
+        port["mkl_error"] = repr(e)
+        return port
+
+
+def cpu_baseline_solver_port(kind, rp, ci, va, b, seconds):
+    """The oracle's CG / BiCG (1 core) for a bounded number of passes."""
     import oracle
     n, nnz = rp.size - 1, int(ci.size)
     passes = 10
