@@ -697,7 +697,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     pl.ldsx = pl.xu > 0;
     pl.lds_bytes = base_lds + 8 * pl.xu * prm.wg_size;
   } else {
-    const int rows_per_wg = prm.wg_size / prm.lanes_per_row;
+    // L >= 4: the pair-load kernel, VEC_RG row groups per wave (spmv_kernels.hpp)
+    const int rows_per_wg = prm.wg_size / prm.lanes_per_row * (prm.lanes_per_row >= 4 ? VEC_RG : 1);
     pl.grid = (m.n_rows + rows_per_wg - 1) / rows_per_wg;
     int max_width = 0;
     if (tile > 0 && m.nnz > 0) {
@@ -716,6 +717,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     }
     pl.ldsx = max_width > 0;
     pl.lds_bytes = 8 * max_width;
+    if (prm.lanes_per_row >= 4 && max_width > 0)              // the pair-load kernel parks VEC_XW entries per lane
+      pl.lds_bytes = 8 * std::max(max_width, std::min(VEC_XW * prm.wg_size, MAX_LDS_BYTES / 8));
   }
   if (!pl.ldsx && pl.prm.tile_width > 0 && m.nnz > 0) {
     // no block fits the tile: run the plain-gather kernels
@@ -730,9 +733,15 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   const dim3 grid(pl.grid), block(pl.prm.wg_size);
   const int remap = pl.prm.xcd_remap > 0, tile = std::max(0, pl.prm.tile_width);
   const bool nt = pl.prm.nontemporal > 0;
-#define CASK_LAUNCH_V(LDSX, NT)                                                                          \
-  hipLaunchKernelGGL((k_spmv_vector<L, LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, remap, \
-                     tile, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y)
+#define CASK_LAUNCH_V(LDSX, NT)                                                                                \
+  do {                                                                                                         \
+    if (L >= 4)                                                                                                \
+      hipLaunchKernelGGL((k_spmv_vector2<(L >= 4 ? L : 4), LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, \
+                         remap, tile, (int)m.nnz, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y);                  \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_spmv_vector<L, LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, remap, \
+                         tile, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y);                                     \
+  } while (0)
   if (pl.ldsx) { if (nt) CASK_LAUNCH_V(true, true); else CASK_LAUNCH_V(true, false); }
   else         { if (nt) CASK_LAUNCH_V(false, true); else CASK_LAUNCH_V(false, false); }
 #undef CASK_LAUNCH_V

@@ -77,6 +77,122 @@ __global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width,
   if (j == 0 && row < n_rows) y[row] = acc;
 }
 
+// ------------------------------------------------ vector variant, pair loads (L >= 4)
+// The same family -- L lanes of a wave per row -- built the way the merge kernel streams: 16-byte value pairs and
+// 8-byte index pairs (a lane owns elements 2p, 2p+1 of its row), and VEC_RG row groups per wave in flight at once, so
+// a lane has VEC_RG * VEC_U pair loads outstanding before it consumes the first (the round-1 kernel had four 8+4-byte
+// loads).  A row group is the 64/L consecutive rows one wave covers at a time; a workgroup owns
+// (wg_size/L) * VEC_RG consecutive rows.  Rows longer than 2*L*VEC_U elements loop.  Partial sums stay in
+// registers (DPP butterfly over the L lanes): no product staging in LDS, one barrier (the x window).
+constexpr int VEC_RG = 4;   // row groups per wave
+constexpr int VEC_U = 2;    // pair loads per lane and row before the first use
+constexpr int VEC_XW = 4;   // x-window loads per lane (windows of up to VEC_XW * wg_size entries are staged in LDS)
+template <int L, bool LDSX, bool NT>
+__global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, int nnz,
+                               const int2v *__restrict__ xspan,
+                               const int *__restrict__ rp, const int *__restrict__ ci,
+                               const double *__restrict__ val, const double *__restrict__ x,
+                               double *__restrict__ y) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *xs = reinterpret_cast<double *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = logical_block(blockIdx.x, n_wg, remap);
+  constexpr int RPW = 64 / L;                                 // rows of one row group
+  const int rows_per_wg = (blockDim.x / L) * VEC_RG;
+  const int j = lane & (L - 1), q = lane / L;
+  const int row0 = wg * rows_per_wg + wave * (RPW * VEC_RG) + q;
+  if (nnz == 0) {                                             // nothing to stream (and no valid pair to clamp to)
+#pragma unroll
+    for (int g = 0; g < VEC_RG; g++)
+      if (j == 0 && row0 + g * RPW < n_rows) y[row0 + g * RPW] = 0.0;
+    return;
+  }
+
+  // Issue order as in the merge kernel: row bounds (oldest), then the x window into registers, then the stream --
+  // the stream waits for the row bounds only, the window is parked in LDS while the stream is in flight.
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  const int max_gpair = ((nnz + 1) >> 1) - 1;                 // last valid pair of the arrays
+  int s[VEC_RG], e[VEC_RG];
+#pragma unroll
+  for (int g = 0; g < VEC_RG; g++) {
+    const int row = min(row0 + g * RPW, n_rows - 1);
+    s[g] = rp[row];
+    e[g] = rp[row + 1];
+    if (row0 + g * RPW >= n_rows) e[g] = s[g];                // past the matrix: an empty row
+  }
+  int cmin = 0;
+  bool in_lds = false;
+  double xw[VEC_XW];
+  if (LDSX) {
+    const int2v span = xspan[wg];
+    cmin = span.x;
+    in_lds = span.y > 0 && span.y <= tile_width && span.y <= VEC_XW * (int)blockDim.x;   // workgroup-uniform
+    if (in_lds) {
+#pragma unroll
+      for (int u = 0; u < VEC_XW; u++) xw[u] = x[cmin + min(u * (int)blockDim.x + tid, span.y - 1)];
+    }
+  }
+  dbl2 v[VEC_RG][VEC_U];
+  int2v c[VEC_RG][VEC_U];
+#pragma unroll
+  for (int g = 0; g < VEC_RG; g++) {
+    const int plast = min(max(e[g] - 1, s[g]) >> 1, max_gpair);
+#pragma unroll
+    for (int u = 0; u < VEC_U; u++) {
+      const int p = min((s[g] >> 1) + u * L + j, plast);     // clamped: a valid pair of (or next to) the row
+      v[g][u] = stream_load<NT>(val2 + p);
+      c[g][u] = stream_load<NT>(ci2 + p);
+    }
+  }
+  if (LDSX && in_lds) {
+#pragma unroll
+    for (int u = 0; u < VEC_XW; u++) xs[u * blockDim.x + tid] = xw[u];
+    __syncthreads();
+  }
+  double acc[VEC_RG];
+#pragma unroll
+  for (int g = 0; g < VEC_RG; g++) {
+    acc[g] = 0.0;
+    const int plast = min(max(e[g] - 1, s[g]) >> 1, max_gpair);
+    dbl2 xv[VEC_U];
+#pragma unroll
+    for (int u = 0; u < VEC_U; u++) {
+      const int p = (s[g] >> 1) + u * L + j;
+      // a clamped lane re-read a pair some other lane owns (its products are masked below); the second element of
+      // the very last pair of an odd-nnz matrix lies behind col_ind: give it the first one's column
+      const int cx = c[g][u].x, cy = 2 * min(p, plast) + 1 < nnz ? c[g][u].y : c[g][u].x;
+      if (LDSX && in_lds) {
+        const int hi = tile_width - 1;
+        xv[u].x = xs[min(max(cx - cmin, 0), hi)];
+        xv[u].y = xs[min(max(cy - cmin, 0), hi)];
+      } else {
+        xv[u].x = x[cx];
+        xv[u].y = x[cy];
+      }
+      if (p <= plast) {
+        if (2 * p >= s[g] && 2 * p < e[g]) acc[g] = fma(v[g][u].x, xv[u].x, acc[g]);
+        if (2 * p + 1 >= s[g] && 2 * p + 1 < e[g]) acc[g] = fma(v[g][u].y, xv[u].y, acc[g]);
+      }
+    }
+    // the rest of a long row (wave-uniform per row group only through the lanes' own bounds: a plain loop)
+    for (int p = (s[g] >> 1) + VEC_U * L + j; p <= plast && 2 * p < e[g]; p += L) {
+      const dbl2 vv = stream_load<NT>(val2 + p);
+      const int2v cc = stream_load<NT>(ci2 + p);
+      const int c1 = 2 * p + 1 < nnz ? cc.y : cc.x;
+      const double x0 = (LDSX && in_lds) ? xs[min(max(cc.x - cmin, 0), tile_width - 1)] : x[cc.x];
+      const double x1 = (LDSX && in_lds) ? xs[min(max(c1 - cmin, 0), tile_width - 1)] : x[c1];
+      if (2 * p >= s[g]) acc[g] = fma(vv.x, x0, acc[g]);
+      if (2 * p + 1 < e[g]) acc[g] = fma(vv.y, x1, acc[g]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < VEC_RG; g++) {
+    const double r = group_sum<L>(acc[g]);
+    if (j == 0 && row0 + g * RPW < n_rows) y[row0 + g * RPW] = r;
+  }
+}
+
 // --------------------------------------------- merge variant, pipelined waves
 // Same merge-path decomposition, but the unit of work is a WAVE and the waves
 // are persistent: each wave walks a strided list of small blocks (at most
