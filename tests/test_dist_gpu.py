@@ -71,11 +71,14 @@ def _worker(rank, world, port, case, out):
                 x0 = np.random.default_rng(5).uniform(-1, 1, n)
                 b = oracle.csr_spmv(rp, ci, va, x0)
             bl = torch.from_numpy(b[b0:b1].copy()).cuda()
+            x_init = None
+            if case.get("x_init") is not None:                 # a non-zero initial guess: the set-up product reads it
+                x_init = torch.from_numpy(np.asarray(case["x_init"])[b0:b1].copy()).cuda()   # through the halo too
             for mode in case.get("modes", (0,)):
                 if bicg:
-                    xs, it, conv = sh.bicg(sht, bl, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
+                    xs, it, conv = sh.bicg(sht, bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
                 else:
-                    xs, it, conv = sh.cg(bl, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
+                    xs, it, conv = sh.cg(bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
                 torch.cuda.synchronize()
                 res[f"x{mode}"], res[f"it{mode}"], res[f"conv{mode}"] = xs.cpu().numpy(), it, conv
                 res[f"us{mode}"] = sh.last_usec_per_iteration
@@ -300,3 +303,30 @@ def test_a_rank_without_a_merge_plan_does_not_strand_the_others():
     assert want_conv and all(r["conv"] for r in res) and len({r["it"] for r in res}) == 1
     assert abs(res[0]["it"] - want_it) <= 1
     np.testing.assert_allclose(np.concatenate([r["x"] for r in res]), np.arange(1.0, 8.0), rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("exchange", ["p2p", "all_gather"])
+def test_sharded_solvers_with_a_nonzero_initial_guess(exchange):
+    """r = b - A x0 with x0 != 0: the set-up product reads the initial guess of every rank (through the halo table
+    with the slot offset, or the all-gather) before the first pass."""
+    spec = ("small", "G3_circuit", 64)
+    n, rp, ci, va = _matrix(spec)
+    rng = np.random.default_rng(17)
+    b, x_init = rng.standard_normal(n), rng.uniform(-1, 1, n)
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b, x0=x_init)
+    modes = (1, 2) if exchange == "p2p" else (0,)
+    res = run_world(3, {"matrix": spec, "exchange": exchange, "b": b, "x_init": x_init, "modes": modes})
+    for mode in modes:
+        got = np.concatenate([r[f"x{mode}"] for r in res])
+        assert all(r[f"conv{mode}"] == want_conv for r in res)
+        assert all(abs(r[f"it{mode}"] - want_it) <= 2 for r in res), ([r[f"it{mode}"] for r in res], want_it)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+    # BiCG, nonsymmetric, same thing
+    spec = ("small", "atmosmodd", 64)
+    n, rp, ci, va = _matrix(spec)
+    b, x_init = rng.standard_normal(n), rng.uniform(-1, 1, n)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b, x0=x_init, tol=1e-9)
+    res = run_world(2, {"matrix": spec, "exchange": exchange, "solver": "bicg", "b": b, "x_init": x_init, "tol": 1e-9})
+    got = np.concatenate([r["x0"] for r in res])
+    assert want_conv and all(r["conv0"] for r in res) and all(abs(r["it0"] - want_it) <= 1 for r in res)
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)

@@ -180,3 +180,16 @@ def test_composed_and_classic_passes_agree_bit_for_bit():
             m.close()
         assert out["1"][1:] == out["2"][1:], (name, out["1"][1:], out["2"][1:])
         assert np.array_equal(out["1"][0], out["2"][0]), name
+
+
+def test_solvers_with_a_nonzero_initial_guess():
+    for name, solver in (("cant", "cg"), ("atmosmodd", "bicg")):
+        n, rp, ci, va = synth.small(name, factor=32)
+        rng = np.random.default_rng(23)
+        b, x_init = rng.standard_normal(n), rng.uniform(-1, 1, n)
+        want, want_it, want_conv = (oracle.cg_full if solver == "cg" else oracle.bicg)(rp, ci, va, b, x0=x_init, tol=1e-9)
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+        got, it, conv, _ = (m.cg if solver == "cg" else m.bicg)(b, x0=x_init, tol=1e-9)
+        m.close()
+        assert conv == want_conv and abs(it - want_it) <= 2, (name, it, want_it)
+        np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(want).max()))
