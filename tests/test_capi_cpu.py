@@ -60,6 +60,17 @@ def test_native_rccl_entry_points_are_exported_without_a_link_dependency():
     assert "rccl" not in needed.lower()
 
 
+def test_native_rccl_entry_points_validate_their_arguments():
+    L = capi.NativeComm._lib()
+    assert L.cask_hip_rccl_allreduce(None, 1, None, None) == 1              # CASK_HIP_ERR_INVALID: no communicator
+    assert L.cask_hip_rccl_allgather(None, None, None, None) == 1
+    assert L.cask_hip_rccl_unique_id(None) == 1
+    import ctypes
+    h = ctypes.c_void_p()
+    assert L.cask_hip_rccl_comm_create(None, 0, 1, None, ctypes.byref(h)) == 1
+    assert L.cask_hip_rccl_comm_destroy(None) == 0
+
+
 def test_code_object_is_gfx950_only():
     blob = capi.LIB_PATH.read_bytes()
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
