@@ -49,7 +49,13 @@ build/test_context_hip: tests/clients/test_context_client.cpp $(LIBDIR)/libCaskH
 	mkdir -p build
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -L$(GENDIR) -lCaskHip -lSpmv_hip -lcask_hip $(RPATHS)
 
-clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip build/test_context_hip
+# plain C over the C ABI alone: a row-sharded solve with the engine's RCCL collectives
+build/test_sharded_solver_hip: tests/clients/test_sharded_solver_client.c $(LIBDIR)/libcask_hip.so include/cask_hip.h include/cask_hip_rccl.h
+	mkdir -p build
+	gcc -std=c11 -O2 -Wall -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o $@ $< -L$(LIBDIR) -lcask_hip -L/opt/rocm/lib -lamdhip64 -lm \
+	  $(RPATHS) -Wl,-rpath,/opt/rocm/lib
+
+clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip build/test_context_hip build/test_sharded_solver_hip
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel

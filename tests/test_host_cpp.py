@@ -139,3 +139,13 @@ def test_dse_executable_writes_dse_out(plain_mtx_dir, tmp_path):
     # and the generator accepts what the DSE wrote
     subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dse", str(tmp_path / "dse_out.json"),
                     "--out-dir", str(tmp_path)], check=True, capture_output=True)
+
+
+@pytest.mark.gpu
+def test_sharded_solver_client_in_plain_c():
+    """INTEGRATION.md section 6 as a program: C ABI only (cask_hip.h + cask_hip_rccl.h), RCCL communicator at world 1,
+    cask_hip_solve_device with the native all-reduce / all-gather callbacks, CG and BiCG."""
+    make("build/test_sharded_solver_hip")
+    out = subprocess.run([str(REPO / "build" / "test_sharded_solver_hip")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-800:], out.stderr[-800:])
+    assert "CG:" in out.stdout and "BiCG:" in out.stdout
