@@ -121,12 +121,13 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
     e[g] = rp[row + 1];
     if (row0 + g * RPW >= n_rows) e[g] = s[g];                // past the matrix: an empty row
   }
-  int cmin = 0;
+  int cmin = 0, span_hi = 0;                                  // span_hi: last staged window entry (gathers are clamped to it)
   bool in_lds = false;
   double xw[VEC_XW];
   if (LDSX) {
     const int2v span = xspan[wg];
     cmin = span.x;
+    span_hi = max(span.y - 1, 0);
     in_lds = span.y > 0 && span.y <= tile_width && span.y <= VEC_XW * (int)blockDim.x;   // workgroup-uniform
     if (in_lds) {
 #pragma unroll
@@ -163,9 +164,8 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
       // the very last pair of an odd-nnz matrix lies behind col_ind: give it the first one's column
       const int cx = c[g][u].x, cy = 2 * min(p, plast) + 1 < nnz ? c[g][u].y : c[g][u].x;
       if (LDSX && in_lds) {
-        const int hi = tile_width - 1;
-        xv[u].x = xs[min(max(cx - cmin, 0), hi)];
-        xv[u].y = xs[min(max(cy - cmin, 0), hi)];
+        xv[u].x = xs[min(max(cx - cmin, 0), span_hi)];
+        xv[u].y = xs[min(max(cy - cmin, 0), span_hi)];
       } else {
         xv[u].x = x[cx];
         xv[u].y = x[cy];
@@ -180,8 +180,8 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
       const dbl2 vv = stream_load<NT>(val2 + p);
       const int2v cc = stream_load<NT>(ci2 + p);
       const int c1 = 2 * p + 1 < nnz ? cc.y : cc.x;
-      const double x0 = (LDSX && in_lds) ? xs[min(max(cc.x - cmin, 0), tile_width - 1)] : x[cc.x];
-      const double x1 = (LDSX && in_lds) ? xs[min(max(c1 - cmin, 0), tile_width - 1)] : x[c1];
+      const double x0 = (LDSX && in_lds) ? xs[min(max(cc.x - cmin, 0), span_hi)] : x[cc.x];
+      const double x1 = (LDSX && in_lds) ? xs[min(max(c1 - cmin, 0), span_hi)] : x[c1];
       if (2 * p >= s[g]) acc[g] = fma(vv.x, x0, acc[g]);
       if (2 * p + 1 < e[g]) acc[g] = fma(vv.y, x1, acc[g]);
     }
