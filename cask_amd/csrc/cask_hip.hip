@@ -1257,8 +1257,8 @@ int cask_hip_spmv_time(cask_hip_matrix *m, const double *d_x, double *d_y, int32
     int rc = launch_spmv(*m, d_x, d_y, m->stream);
     if (rc) return rc;
   }
-  std::vector<hipEvent_t> ev((size_t)iters + 1);
-  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  std::vector<DevEvent> ev((size_t)iters + 1);
+  for (auto &e : ev) HIP_TRY(e.create());
   HIP_TRY(hipEventRecord(ev[0], m->stream));
   for (int i = 0; i < iters; i++) {
     int rc = launch_spmv(*m, d_x, d_y, m->stream);
@@ -1272,7 +1272,6 @@ int cask_hip_spmv_time(cask_hip_matrix *m, const double *d_x, double *d_y, int32
     HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     us[i] = ms * 1e3;
   }
-  for (auto &e : ev) (void)hipEventDestroy(e);
   std::sort(us.begin(), us.end());
   if (usec_median) *usec_median = us[us.size() / 2];
   if (usec_min) *usec_min = us[0];
@@ -1289,22 +1288,28 @@ static int time_graph(std::vector<cask_hip_matrix *> &mats, const double *x, dou
     if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(s));
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  struct GraphPair {                                          // destroyed on every way out
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~GraphPair() {
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+  } g;
   HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = CASK_HIP_OK;
   for (int i = 0; i < k && rc == CASK_HIP_OK; i++) rc = launch_spmv(*mats[(size_t)i % mats.size()], x, y, s);
-  hipError_t e = hipStreamEndCapture(s, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  hipError_t e = hipStreamEndCapture(s, &g.graph);
+  if (rc) return rc;
   if (e != hipSuccess) return fail(CASK_HIP_ERR_RUNTIME, std::string("graph capture: ") + hipGetErrorString(e));
-  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail(CASK_HIP_ERR_RUNTIME, std::string("graph instantiate: ") + hipGetErrorString(e)); }
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) return fail(CASK_HIP_ERR_RUNTIME, std::string("graph instantiate: ") + hipGetErrorString(e));
+  DevEvent e0, e1;
+  HIP_TRY(e0.create()); HIP_TRY(e1.create());
   double best = 0.0;
   for (int r = 0; r < warm_replays + reps; r++) {
     HIP_TRY(hipEventRecord(e0, s));
-    HIP_TRY(hipGraphLaunch(exec, s));
+    HIP_TRY(hipGraphLaunch(g.exec, s));
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipStreamSynchronize(s));
     float ms = 0.f;
@@ -1312,8 +1317,6 @@ static int time_graph(std::vector<cask_hip_matrix *> &mats, const double *x, dou
     const double us = ms * 1e3 / k;
     if (r >= warm_replays && (best == 0.0 || us < best)) best = us;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
   *usec = best;
   return CASK_HIP_OK;
 }
@@ -1704,8 +1707,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r (and p) is final before the first pass
   if (rc) return rc;
 
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  DevEvent e0, e1;
+  HIP_TRY(e0.create()); HIP_TRY(e1.create());
   HIP_TRY(hipEventRecord(e0, s));
   const int check_every = 16;
   int h_flags[2] = {0, 0};
@@ -1852,7 +1855,6 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0];
   // passes launched after the converged one are no-ops: prefer the rate measured up to the last
@@ -1924,8 +1926,8 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, partials.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
 
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  DevEvent e0, e1;
+  HIP_TRY(e0.create()); HIP_TRY(e1.create());
   HIP_TRY(hipEventRecord(e0, s));
   const int check_every = 16;
   int h_flags[2] = {0, 0};
@@ -1981,7 +1983,6 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0];
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);

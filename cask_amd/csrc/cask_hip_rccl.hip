@@ -31,18 +31,14 @@ struct RcclApi {
   std::string error;
 };
 
-RcclApi &api() {
-  static RcclApi a;
-  static bool tried = false;
-  if (tried) return a;
-  tried = true;
+void load_rccl(RcclApi &a) {
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (a.handle) break;
   }
   if (!a.handle) {
     a.error = "librccl.so.1 not found";
-    return a;
+    return;
   }
 #define CASK_SYM(field, sym)                                              \
   a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, #sym));   \
@@ -57,6 +53,10 @@ RcclApi &api() {
   CASK_SYM(GroupEnd, ncclGroupEnd);
   CASK_SYM(GetErrorString, ncclGetErrorString);
 #undef CASK_SYM
+}
+
+RcclApi &api() {                                              // loaded once (thread-safe static initialisation)
+  static RcclApi a = [] { RcclApi x; load_rccl(x); return x; }();
   return a;
 }
 
@@ -103,7 +103,10 @@ int cask_hip_rccl_comm_create(const unsigned char *id, int32_t rank, int32_t wor
     c->bounds.assign(bounds, bounds + world + 1);
     c->even = true;
     for (int g = 0; g < world; g++)
-      if (bounds[g + 1] < bounds[g]) { delete c; return report_failure(CASK_HIP_ERR_INVALID, "bounds must be non-decreasing"); }
+      if (bounds[0] != 0 || bounds[g + 1] < bounds[g]) {
+        delete c;
+        return report_failure(CASK_HIP_ERR_INVALID, "bounds must start at 0 and be non-decreasing");
+      }
     for (int g = 1; g < world; g++) c->even = c->even && (bounds[g + 1] - bounds[g] == bounds[1] - bounds[0]);
   }
   ncclResult_t r = a.CommInitRank(&c->comm, world, uid, rank);
@@ -134,6 +137,7 @@ int cask_hip_rccl_allreduce(double *d_values, int32_t count, void *stream, void 
 int cask_hip_rccl_allgather(const double *d_local, double *d_full, void *stream, void *comm) {
   cask_hip_comm *c = static_cast<cask_hip_comm *>(comm);
   if (!c || !d_full || c->bounds.empty()) return report_failure(CASK_HIP_ERR_INVALID, "communicator has no row bounds");
+  if (!d_local && c->bounds[c->rank + 1] > c->bounds[c->rank]) return report_failure(CASK_HIP_ERR_INVALID, "d_local is NULL");
   RcclApi &a = api();
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c->even) {

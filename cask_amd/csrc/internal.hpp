@@ -34,6 +34,19 @@ struct DevBuf {
   hipError_t upload(const std::vector<T> &h) { return upload(h.data(), h.size()); }
 };
 
+// Owning event (the timing paths return early on errors).
+struct DevEvent {
+  hipEvent_t e = nullptr;
+  DevEvent() = default;
+  DevEvent(const DevEvent &) = delete;
+  DevEvent &operator=(const DevEvent &) = delete;
+  ~DevEvent() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  hipError_t create() { return hipEventCreate(&e); }
+  operator hipEvent_t() const { return e; }
+};
+
 }  // namespace caskhip
 
 // Between cask_hip.hip (the PCG driver) and cask_hip_precond.hip: z = M^-1 r together with the partial sums of

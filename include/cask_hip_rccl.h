@@ -29,8 +29,8 @@ typedef struct cask_hip_comm cask_hip_comm;
 
 int cask_hip_rccl_unique_id(unsigned char *id_out /* CASK_HIP_RCCL_ID_BYTES */);
 
-/* bounds: world+1 row boundaries of the partition (rank g owns [bounds[g], bounds[g+1])), needed by the operand
- * all-gather; NULL if only all-reduces are used.  Uses the current HIP device. */
+/* bounds: world+1 row boundaries of the partition (bounds[0] = 0; rank g owns [bounds[g], bounds[g+1])), needed by
+ * the operand all-gather; NULL if only all-reduces are used.  Uses the current HIP device. */
 int cask_hip_rccl_comm_create(const unsigned char *id, int32_t rank, int32_t world, const int64_t *bounds,
                               cask_hip_comm **out);
 int cask_hip_rccl_comm_destroy(cask_hip_comm *comm);
