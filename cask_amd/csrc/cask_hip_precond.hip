@@ -11,10 +11,9 @@
 //
 // The factorisation is a setup step and runs on the host (as in the reference: its constructor is
 // sequential CPU code); every application runs on the device.  A triangular solve is a chain of
-// dependency levels: rows of one level are independent.  Wide levels get a launch of their own, runs
-// of narrow levels are walked by ONE workgroup with a barrier between levels (a stencil matrix in
-// natural order has thousands of levels of a few hundred rows: a launch per level would cost 2 us
-// each, a barrier costs 0.2).
+// dependency levels: rows of one level are independent.  Wide levels (>= WIDE_LEVEL rows) get a launch
+// of their own; runs of narrow levels are walked by ONE workgroup with a barrier between levels, out of
+// a level-ordered copy of the factor staged through LDS a chunk ahead (k_trsv_packed, round 2).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,8 +38,21 @@ namespace {
       return report_failure(CASK_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-constexpr int TRSV_WG = 1024;          // the workgroup that walks runs of narrow levels
-constexpr int WIDE_LEVEL = 16384;      // rows from which a level gets a launch of its own
+constexpr int TRSV_WG = 1024;          // the workgroup that walks runs of narrow levels (row-indexed fallback kernel)
+constexpr int WIDE_LEVEL = 256;        // rows from which a level gets a launch of its own (the packed walk gives a
+                                       // level to ONE wave: beyond a few strides of 64 rows a launch is cheaper)
+constexpr int WIDE_LEVEL_ROWWALK = 16384;  // the same for the row-indexed walk of round 1 (1024 threads per level)
+
+// ---- the packed walk (k_trsv_packed): runs of narrow levels by ONE workgroup, everything but x off the critical path
+constexpr int PK_T = 256;              // threads
+constexpr int PK_CH = 1024;            // positions (rows in level order) staged per chunk
+constexpr int PK_ECAP = 3072;          // off-diagonal entries staged per chunk
+constexpr int PK_RING = 4096;          // x values of the most recent positions kept in LDS; >= 2 PK_CH + WIDE_LEVEL
+constexpr int PK_PJ = PK_CH / PK_T, PK_EJ = PK_ECAP / PK_T;
+constexpr unsigned PK_NEAR = 0x80000000u;
+static_assert(PK_RING >= 2 * PK_CH + WIDE_LEVEL && (PK_RING & (PK_RING - 1)) == 0, "ring covers what staging cannot prefetch");
+constexpr size_t PK_LDS_BYTES = sizeof(double) * (PK_RING + 2 * PK_ECAP + 2 * PK_CH) +
+                                sizeof(int) * (PK_ECAP + (PK_CH + 1) + (PK_CH + 1));
 
 // x[r] = (b[r] - sum_{c != r, c in the triangle} val * x[c]) / val[r][r], entries in stored order
 // flags: bit 0 = lower triangle, bit 1 = unit diagonal (the stored diagonal is ignored)
@@ -73,6 +85,220 @@ __global__ void k_trsv_levels(int l0, int l1, int lower, const int *__restrict__
     const int lo = level_ptr[l], hi = level_ptr[l + 1];
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) solve_row(order[i], lower, rp, ci, val, b, x);
     __syncthreads();
+  }
+}
+
+// ---- packed walk of a run of narrow levels -------------------------------------------------------------------------
+// k_trsv_levels pays, per level, a chain of dependent global loads (level_ptr -> order -> row_ptr -> entry -> x[c]):
+// ~2 us a level, 57 436 levels on the G3_circuit-like factors.  Only x[c] really depends on the previous level.  Here
+// the factor is stored a second time in LEVEL ORDER ("positions"; diagonal split off, the other entries of a row in
+// their stored order, so the arithmetic is solve_row's bit for bit) and cut into chunks of <= PK_CH positions /
+// PK_ECAP entries.  One workgroup walks the chunks: while chunk k is solved out of LDS, the registers of the 256
+// threads already hold chunk k+1 (rows, diagonals, b[row], entries) -- streaming loads issued a whole chunk ahead.
+// A dependency x[c] comes from one of two places, decided when the factor is built:
+//   near   the producer is among the last PK_RING positions of this launch: every solved x is also kept in an LDS
+//          ring indexed by position, so the value is one LDS read away;
+//   early  the producer was finished before chunk k-1 started: x[c] is loaded from memory with the rest of the chunk,
+//          a chunk ahead (PK_RING >= 2 PK_CH + the widest level makes these two cases cover everything).
+// Per level the dependent work is LDS reads, the row's FMAs, an LDS write and a barrier that waits for LDS only (the
+// prefetch stays in flight across it; x goes to memory once per chunk, out of the ring).
+// Measured, one ILU(0) application (two solves), MI355X, against the row-indexed walk (profiles/r02_trsv.txt):
+// G3_circuit-like (57 436 levels of ~28 rows) 44.6 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
+// 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 44.8 vs 177 ms.  Still ~0.29 us per level: the
+// four waves' turns and preparation steps cost what they cost one after the other (ablations in the same file), and a
+// chunk costs ~3.5 us of staging on top.
+struct PackedTri {
+  const int *row, *eptr, *seg;
+  const int4 *hdr;                     // per chunk: {first position, positions, first entry, entries}, {first segment, segments, -, -}
+  const unsigned *code;
+  const double *diag, *val;
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ void __launch_bounds__(PK_T)
+k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b, double *x) {
+  extern __shared__ double pk_lds[];
+  double *ring = pk_lds;
+  double *s_val = ring + PK_RING, *s_x = s_val + PK_ECAP, *s_b = s_x + PK_ECAP, *s_diag = s_b + PK_CH;
+  int *s_src = reinterpret_cast<int *>(s_diag + PK_CH);       // per entry: where its x value is (byte offset in LDS)
+  int *s_e = s_src + PK_ECAP;                                 // PK_CH + 1 entry offsets, chunk-relative
+  int *s_seg = s_e + PK_CH + 1;                               // segment ends, chunk-relative
+  const char *lds_bytes = reinterpret_cast<const char *>(pk_lds);
+  const int tid = threadIdx.x;
+
+  // the chunk in flight (position idx = tid + PK_T * j, entry tid + PK_T * j)
+  int r_row[PK_PJ], r_e[PK_PJ + 1], r_seg[PK_PJ + 1];
+  double r_diag[PK_PJ], r_b[PK_PJ], r_val[PK_EJ], r_x[PK_EJ];
+  unsigned r_code[PK_EJ];
+  int4 h0, h1;                                                // header of the chunk after the one in the registers
+  int w_row[PK_PJ];                                           // rows of the chunk being solved (for writing x back)
+
+  // Loads are unconditional (indices clamped into the chunk; the arrays carry one spare element) so that all of a
+  // chunk's streaming loads are in flight together, then the gathers that need a loaded index.  The chunk's header
+  // arrives with the chunk before it, so nothing here waits for a scalar.
+  auto load_chunk = [&](int cs, int cnt, int ebase, int ecnt, int sbase, int scnt) {
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_row[j] = t.row[cs + min(tid + PK_T * j, cnt - 1)];
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) r_code[j] = t.code[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_diag[j] = t.diag[cs + min(tid + PK_T * j, cnt - 1)];
+#pragma unroll
+    for (int j = 0; j < PK_PJ + 1; j++) {
+      r_e[j] = t.eptr[cs + min(tid + PK_T * j, cnt)] - ebase;
+      r_seg[j] = t.seg[sbase + min(tid + PK_T * j, scnt - 1)] - cs;
+    }
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) r_val[j] = t.val[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_b[j] = b[r_row[j]];
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) {
+      const bool early = tid + PK_T * j < ecnt && !(r_code[j] & PK_NEAR);
+      r_x[j] = __hip_atomic_load(x + (early ? r_code[j] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto store_chunk = [&](int cnt, int ecnt, int scnt) {
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < cnt) {
+        s_diag[idx] = r_diag[j];
+        s_b[idx] = r_b[j];
+      }
+      w_row[j] = r_row[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PK_PJ + 1; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx <= cnt) s_e[idx] = r_e[j];
+      if (idx < scnt) s_seg[idx] = r_seg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < ecnt) {
+        // a near value is read from the ring, an early one from s_x: one address either way, no select in the walk
+        s_src[idx] = (r_code[j] & PK_NEAR) ? (int)((r_code[j] & (PK_RING - 1)) * 8u)
+                                           : (int)((PK_RING + PK_ECAP + idx) * 8);
+        s_val[idx] = r_val[j];
+        s_x[idx] = r_x[j];
+      }
+    }
+  };
+
+  h0 = t.hdr[2 * c0];
+  h1 = t.hdr[2 * c0 + 1];
+  int cs = uniform(h0.x), cnt = uniform(h0.y), ebase = uniform(h0.z), ecnt = uniform(h0.w), sbase = uniform(h1.x),
+      scnt = uniform(h1.y);
+  load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
+  if (c0 + 1 < c1) {
+    h0 = t.hdr[2 * c0 + 2];
+    h1 = t.hdr[2 * c0 + 3];
+  }
+  for (int k = c0; k < c1; k++) {
+    // chunk k-1 is finished, and its x stores have left this CU before anybody issues chunk k+1's early loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    store_chunk(cnt, ecnt, scnt);
+    const int cur_cs = cs, n_pos = cnt, n_seg = scnt;
+    __syncthreads();
+    if (k + 1 < c1) {
+      cs = uniform(h0.x); cnt = uniform(h0.y); ebase = uniform(h0.z); ecnt = uniform(h0.w);
+      sbase = uniform(h1.x); scnt = uniform(h1.y);
+      load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
+      if (k + 2 < c1) {
+        h0 = t.hdr[2 * k + 4];
+        h1 = t.hdr[2 * k + 5];
+      }
+    }
+    // The walk touches LDS only (no global access inside: the prefetch above stays in flight across it).  The four
+    // waves take the levels in turn (level L belongs to wave L % 4, lane i solves its i-th row).  A level's only
+    // dependent work is: x reads, the row's FMAs, the ring write.  Everything else -- the level's bounds, the rows'
+    // right-hand sides and entry ranges, the entries themselves (three dependent LDS reads) -- its wave does one
+    // step per barrier interval while the other three waves have their turns.
+    constexpr int PK_Q = 2;
+    const int wave = tid >> 6, lane = tid & 63;
+    int my_level = wave, l_lo = 0, l_hi = 0, idx = 0, e0 = 0, ne = 0;
+    double acc = 0.0, diag = 1.0, q_val[PK_Q];
+    int q_src[PK_Q];
+    auto bounds = [&]() {                                     // step 1
+      l_lo = my_level > 0 ? uniform(s_seg[my_level - 1]) : 0;
+      l_hi = uniform(s_seg[my_level]);
+    };
+    auto rows = [&]() {                                       // step 2 (idx: this lane's row of the level)
+      ne = 0;
+      if (idx < l_hi) {
+        acc = s_b[idx];
+        diag = s_diag[idx];
+        e0 = s_e[idx];
+        ne = s_e[idx + 1] - e0;
+      }
+    };
+    auto entries = [&]() {                                    // step 3
+      if (idx < l_hi) {
+#pragma unroll
+        for (int q = 0; q < PK_Q; q++) {
+          const int e = e0 + min(q, max(ne - 1, 0));
+          q_val[q] = s_val[e];
+          q_src[q] = s_src[e];
+        }
+      }
+    };
+    auto solve = [&]() {
+      if (idx < l_hi) {
+        double xv[PK_Q];
+#pragma unroll
+        for (int q = 0; q < PK_Q; q++) xv[q] = *reinterpret_cast<const double *>(lds_bytes + q_src[q]);
+        double s = acc;
+#pragma unroll
+        for (int q = 0; q < PK_Q; q++)
+          if (q < ne) s -= q_val[q] * xv[q];
+        for (int e = e0 + PK_Q; e < e0 + ne; e++)             // longer rows: the rest straight from LDS
+          s -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
+        ring[(cur_cs + idx) & (PK_RING - 1)] = unit ? s : s / diag;
+      }
+    };
+    if (my_level < n_seg) {                                   // the first level of every wave: all three steps now
+      bounds();
+      idx = l_lo + lane;
+      rows();
+      entries();
+    }
+#ifndef CASK_ABL
+#define CASK_ABL 0
+#endif
+    for (int sg = 0; sg < (CASK_ABL == 1 ? 0 : n_seg); sg++) { // ablations (development): 1 no walk, 6 no solve, 7 no preparation
+      const int turn = (sg - wave) & 3;                       // wave-uniform
+      if (turn == 0) {
+        if (CASK_ABL != 6) solve();
+        for (idx += 64; idx < l_hi; idx += 64) {              // a level wider than a wave: the other rows one by one
+          rows();
+          entries();
+          solve();
+        }
+        my_level += 4;
+      } else if (CASK_ABL != 7 && my_level < n_seg) {
+        if (turn == 1) {
+          bounds();
+          idx = l_lo + lane;
+        } else if (turn == 2) {
+          rows();
+        } else {
+          entries();
+        }
+      }
+      lds_barrier();                                          // the level's x values are in the ring
+    }
+    // the chunk's results: ring -> x (PK_CH <= PK_RING: all of them are still there)
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < n_pos)
+        __hip_atomic_store(x + w_row[j], ring[(cur_cs + idx) & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -223,8 +449,13 @@ struct TriFactor {
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
-  struct Step { int l0, l1, lo, hi; bool wide; };     // levels [l0,l1) = positions [lo,hi) of `order`
-  std::vector<Step> steps;
+  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; };   // levels [l0,l1) = positions [lo,hi) of `order`;
+  std::vector<Step> steps;                                      // chunks [c0,c1) of the packed form (c0 < 0: none)
+  // the factor once more in level order for k_trsv_packed (see there)
+  DevBuf<int> pk_row, pk_eptr, pk_seg;
+  DevBuf<int4> pk_hdr;
+  DevBuf<unsigned> pk_code;
+  DevBuf<double> pk_diag, pk_val;
   DevBuf<int> sync;                                   // [0] chunk counter, [1] error flag of the sync-free solve
   int sf_grid = 0;
 
@@ -252,17 +483,20 @@ struct TriFactor {
     std::vector<int> fill(lp.begin(), lp.end() - 1);
     for (int r = 0; r < n; r++) ord[fill[level[r]]++] = r;
     steps.clear();
+    const int wide_from = forced_mode() == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
     for (int l = 0; l < n_levels;) {
-      if (lp[l + 1] - lp[l] >= WIDE_LEVEL) {
-        steps.push_back(Step{l, l + 1, lp[l], lp[l + 1], true});
+      if (lp[l + 1] - lp[l] >= wide_from) {
+        steps.push_back(Step{l, l + 1, lp[l], lp[l + 1], true, -1, -1});
         l++;
         continue;
       }
       int e = l;
-      while (e < n_levels && lp[e + 1] - lp[e] < WIDE_LEVEL) e++;
-      steps.push_back(Step{l, e, lp[l], lp[e], false});
+      while (e < n_levels && lp[e + 1] - lp[e] < wide_from) e++;
+      steps.push_back(Step{l, e, lp[l], lp[e], false, -1, -1});
       l = e;
     }
+    int rc = build_packed(h_rp, h_ci, h_val, level, lp, ord);
+    if (rc) return rc;
     PC_TRY(rp.upload(h_rp));
     PC_TRY(ci.upload(h_ci));
     PC_TRY(val.upload(h_val));
@@ -279,17 +513,110 @@ struct TriFactor {
     return CASK_HIP_OK;
   }
 
-  // Level-scheduled by default; CASK_HIP_TRSV=syncfree selects the one-launch synchronisation-free solve.  Measured
+  // Level-ordered copy of the factor, its chunks and the source of every dependency (near / early), per narrow step.
+  // A step that cannot be packed (a row with more than PK_ECAP entries) keeps c0 = -1 and runs k_trsv_levels.
+  int build_packed(const std::vector<int> &h_rp, const std::vector<int> &h_ci, const std::vector<double> &h_val,
+                   const std::vector<int> &level, const std::vector<int> &lp, const std::vector<int> &ord) {
+    std::vector<int> pos_of((size_t)n), prow(ord), peptr((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) pos_of[ord[i]] = i;
+    std::vector<unsigned> pcode;
+    std::vector<double> pval, pdiag((size_t)n, 0.0);
+    pcode.reserve(h_ci.size());
+    pval.reserve(h_ci.size());
+    for (int i = 0; i < n; i++) {
+      const int r = ord[i];
+      for (int k = h_rp[r]; k < h_rp[r + 1]; k++) {
+        const int c = h_ci[k];
+        if (c == r) pdiag[i] = h_val[k];
+        else if (lower ? c < r : c > r) {
+          pcode.push_back((unsigned)c);                       // the column for now; near ones become positions below
+          pval.push_back(h_val[k]);
+        }
+      }
+      peptr[i + 1] = (int)pcode.size();
+    }
+    std::vector<int> chunk, segptr, seg;
+    for (Step &st : steps) {
+      if (st.wide) continue;
+      const size_t chunk0 = chunk.size(), segptr0 = segptr.size(), seg0 = seg.size();
+      bool ok = true;
+      int prev_start = st.lo;                                 // what a chunk's early loads may rely on: positions before this
+      for (int cs = st.lo; cs < st.hi && ok;) {
+        int ce = cs;
+        while (ce < st.hi && ce - cs < PK_CH && peptr[ce + 1] - peptr[cs] <= PK_ECAP) ce++;
+        if (ce == cs) { ok = false; break; }
+        chunk.push_back(cs);
+        segptr.push_back((int)seg.size());
+        for (int i = cs; i < ce;) {                           // level ends inside the chunk, and the chunk's own end
+          const int end = std::min(lp[level[ord[i]] + 1], ce);
+          seg.push_back(end);
+          i = end;
+        }
+        for (int i = cs; i < ce && ok; i++) {
+          const int level_end = lp[level[ord[i]] + 1];
+          for (int e = peptr[i]; e < peptr[i + 1]; e++) {
+            const int pp = pos_of[pcode[e]];
+            if (pp >= st.lo && pp >= level_end - PK_RING) pcode[e] = PK_NEAR | (unsigned)pp;
+            else if (pp >= prev_start) { ok = false; break; }  // cannot happen while PK_RING >= 2 PK_CH + WIDE_LEVEL
+          }
+        }
+        prev_start = cs;
+        cs = ce;
+      }
+      if (!ok) {                                              // restore the columns of what was already rewritten
+        chunk.resize(chunk0);
+        segptr.resize(segptr0);
+        seg.resize(seg0);
+        for (int i = st.lo; i < st.hi; i++)
+          for (int e = peptr[i]; e < peptr[i + 1]; e++)
+            if (pcode[e] & PK_NEAR) pcode[e] = (unsigned)ord[pcode[e] & ~PK_NEAR];
+        continue;
+      }
+      st.c0 = (int)chunk0;
+      st.c1 = (int)chunk.size();
+      chunk.push_back(st.hi);                                 // every step's list ends with its own sentinel
+      segptr.push_back((int)seg.size());
+    }
+    // chunk headers (the step lists in `chunk` / `segptr` end with a sentinel each, so entry k+1 closes chunk k)
+    std::vector<int4> hdr(2 * chunk.size());
+    for (size_t k = 0; k + 1 < chunk.size(); k++) {
+      const int cs = chunk[k], ce = chunk[k + 1];
+      if (ce <= cs) continue;                                 // a sentinel followed by the next step's first chunk
+      hdr[2 * k] = make_int4(cs, ce - cs, peptr[cs], peptr[ce] - peptr[cs]);
+      hdr[2 * k + 1] = make_int4(segptr[k], segptr[k + 1] - segptr[k], 0, 0);
+    }
+    pcode.push_back(0u);                                      // one spare element each: the kernel's clamped loads
+    pval.push_back(0.0);
+    seg.push_back(0);
+    PC_TRY(pk_row.upload(prow));
+    PC_TRY(pk_eptr.upload(peptr));
+    PC_TRY(pk_code.upload(pcode));
+    PC_TRY(pk_val.upload(pval));
+    PC_TRY(pk_diag.upload(pdiag));
+    PC_TRY(pk_hdr.upload(hdr));
+    PC_TRY(pk_seg.upload(seg));
+    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)PK_LDS_BYTES));
+    return CASK_HIP_OK;
+  }
+
+  // Level-scheduled by default (runs of narrow levels: the packed walk, k_trsv_packed; CASK_HIP_TRSV=levels keeps the
+  // row-indexed walk of round 1); CASK_HIP_TRSV=syncfree selects the one-launch synchronisation-free solve.  Measured
   // on the G3_circuit-like ILU(0) factors (57 436 levels, profiles/r02_trsv.txt): levels 225 ms, sync-free 210-270 ms
   // per PCG pass -- no better.  The critical path is 57 K DEPENDENT rows either way, and a dependent step costs
   // ~2 us in both schedules: in the sync-free kernel every step of a lane re-reads its row entry from L1/L2 and the
   // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
   // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
   // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
-  bool use_syncfree() const {
-    static const char *force = std::getenv("CASK_HIP_TRSV");
-    return force && std::string(force) == "syncfree";
+  static int forced_mode() {                                    // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk)
+    static const int mode = [] {
+      const char *force = std::getenv("CASK_HIP_TRSV");
+      if (!force) return 0;
+      return std::string(force) == "syncfree" ? 1 : std::string(force) == "levels" ? 2 : 0;
+    }();
+    return mode;
   }
+  bool use_syncfree() const { return forced_mode() == 1; }
 
   int solve(const double *d_b, double *d_x, hipStream_t s) const {
     const int flags = (lower ? 1 : 0) | (unit ? 2 : 0);
@@ -301,10 +628,15 @@ struct TriFactor {
       PC_TRY(hipGetLastError());
       return CASK_HIP_OK;
     }
+    // the packed walk reads b a chunk ahead of the x it writes: not for an in-place solve
+    const bool packed_ok = forced_mode() != 2 && d_b != d_x;
+    const PackedTri pk{pk_row.p, pk_eptr.p, pk_seg.p, pk_hdr.p, pk_code.p, pk_diag.p, pk_val.p};
     for (const Step &st : steps) {
       if (st.wide)
         hipLaunchKernelGGL(k_trsv_level, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, flags,
                            order.p, rp.p, ci.p, val.p, d_b, d_x);
+      else if (packed_ok && st.c0 >= 0)
+        hipLaunchKernelGGL(k_trsv_packed, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else
         hipLaunchKernelGGL(k_trsv_levels, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, flags, level_ptr.p, order.p,
                            rp.p, ci.p, val.p, d_b, d_x);

@@ -160,9 +160,13 @@ def test_argument_checks():
         capi.Preconditioner(7, 1, [0, 1], [0], [1.0])
 
 
-def test_syncfree_triangular_solve_matches_level_schedule():
-    """The one-launch synchronisation-free solve (CASK_HIP_TRSV=syncfree; an option, see cask_hip_precond.hip) walks
-    every row in stored order like the level-scheduled one: identical bits, on a factor with thousands of levels."""
+def test_triangular_solve_schedules_agree_bit_for_bit():
+    """Three schedules of the same triangular solve (cask_hip_precond.hip): the packed walk of narrow-level runs (the
+    default), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
+    (CASK_HIP_TRSV=syncfree).  All walk every row in stored order: identical bits -- on a grid factor with thousands
+    of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
+    per level run, entry-capped chunks) and an arrow matrix whose last row is longer than a chunk can hold (that
+    step falls back to the row-indexed walk)."""
     import os
     import subprocess
     import sys
@@ -170,22 +174,36 @@ def test_syncfree_triangular_solve_matches_level_schedule():
 import sys, numpy as np
 sys.path.insert(0, ".")
 from cask_amd import capi, synth
-n, rp, ci, va = synth.small("G3_circuit", factor=16)
+out, levels = [], []
 rng = np.random.default_rng(3)
-r = rng.standard_normal(n)
-pc = capi.Preconditioner("ilu0_unit", n, rp, ci, va)
-z = pc.apply(r)
-lo = capi.trsolve(n, rp, ci, va, r, lower=True)
-up = capi.trsolve(n, rp, ci, va, r, lower=False)
-np.save(sys.argv[1], np.concatenate([z, lo, up]))
-print(pc.info()["levels_lower"])
+def arrow(n):
+    rows = [[i] for i in range(n - 1)] + [list(range(n))]
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+    ci = np.concatenate(rows).astype(np.int32)
+    va = rng.uniform(0.5, 1.5, ci.size)
+    va[rp[1:] - 1] += 4.0
+    return n, rp, ci, va
+cases = [synth.small("G3_circuit", factor=16), synth.small("atmosmodd", factor=32),
+         synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000)]
+for n, rp, ci, va in cases:
+    r = rng.standard_normal(n)
+    for kind in ("ilu0_unit", "ilu0"):
+        pc = capi.Preconditioner(kind, n, rp, ci, va)
+        out.append(pc.apply(r))
+        levels.append(pc.info()["levels_lower"])
+    out.append(capi.trsolve(n, rp, ci, va, r, lower=True))
+    out.append(capi.trsolve(n, rp, ci, va, r, lower=False))
+np.save(sys.argv[1], np.concatenate(out))
+print(max(levels))
 '''
     outs = {}
-    for mode in ("levels", "syncfree"):
+    for mode in ("levels", "syncfree", "packed"):
         path = f"/tmp/cask_trsv_{mode}.npy"
-        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300,
+        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600,
                              env=dict(os.environ, CASK_HIP_TRSV=mode), cwd=str(REPO))
         assert res.returncode == 0, res.stderr[-1500:]
         assert int(res.stdout.strip().splitlines()[-1]) > 500
         outs[mode] = np.load(path)
+    assert np.all(np.isfinite(outs["levels"]))
     assert np.array_equal(outs["levels"], outs["syncfree"])
+    assert np.array_equal(outs["levels"], outs["packed"])
