@@ -21,6 +21,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "cask_hip.h"
@@ -117,6 +118,9 @@ struct PackedTri {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// LONG: the rows of the step have many entries (an FEM factor): the entries beyond the prepared ones are read four at a
+// time.  Short-row steps keep the one-by-one loop -- the unrolled one costs them 10 % in code they never run.
+template <bool LONG>
 __global__ void __launch_bounds__(PK_T)
 k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b, double *x) {
   extern __shared__ double pk_lds[];
@@ -256,8 +260,25 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
 #pragma unroll
         for (int q = 0; q < PK_Q; q++)
           if (q < ne) s -= q_val[q] * xv[q];
-        for (int e = e0 + PK_Q; e < e0 + ne; e++)             // longer rows: the rest straight from LDS
-          s -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
+        if constexpr (!LONG) {
+          for (int e = e0 + PK_Q; e < e0 + ne; e++)
+            s -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
+        } else
+        for (int e = e0 + PK_Q; e < e0 + ne; e += 4) {        // longer rows: the rest straight from LDS, four entries
+          double v4[4], x4[4];                                // per pair of dependent reads, still one FMA after the other
+          int a4[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int eu = min(e + u, e0 + ne - 1);
+            a4[u] = s_src[eu];
+            v4[u] = s_val[eu];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (e + u < e0 + ne) s -= v4[u] * x4[u];
+        }
         ring[(cur_cs + idx) & (PK_RING - 1)] = unit ? s : s / diag;
       }
     };
@@ -267,30 +288,48 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
       rows();
       entries();
     }
-#ifndef CASK_ABL
-#define CASK_ABL 0
-#endif
-    for (int sg = 0; sg < (CASK_ABL == 1 ? 0 : n_seg); sg++) { // ablations (development): 1 no walk, 6 no solve, 7 no preparation
-      const int turn = (sg - wave) & 3;                       // wave-uniform
-      if (turn == 0) {
-        if (CASK_ABL != 6) solve();
+    // One barrier interval of this wave; `turn` is a compile-time constant: every wave runs its own unrolled copy of
+    // the loop (four intervals per trip, no dispatch on the turn inside it).
+    auto interval = [&](auto turn_c) {
+      constexpr int turn = decltype(turn_c)::value;
+      if constexpr (turn == 0) {
+        solve();
         for (idx += 64; idx < l_hi; idx += 64) {              // a level wider than a wave: the other rows one by one
           rows();
           entries();
           solve();
         }
         my_level += 4;
-      } else if (CASK_ABL != 7 && my_level < n_seg) {
-        if (turn == 1) {
+      } else if (my_level < n_seg) {
+        if constexpr (turn == 1) {
           bounds();
           idx = l_lo + lane;
-        } else if (turn == 2) {
+        } else if constexpr (turn == 2) {
           rows();
         } else {
           entries();
         }
       }
       lds_barrier();                                          // the level's x values are in the ring
+    };
+    auto walk = [&](auto first_c) {                           // first: this wave's turn in interval 0
+      constexpr int f = decltype(first_c)::value;
+      int sg = 0;
+      for (; sg + 4 <= n_seg; sg += 4) {
+        interval(std::integral_constant<int, f>{});
+        interval(std::integral_constant<int, (f + 1) & 3>{});
+        interval(std::integral_constant<int, (f + 2) & 3>{});
+        interval(std::integral_constant<int, (f + 3) & 3>{});
+      }
+      if (sg < n_seg) interval(std::integral_constant<int, f>{});
+      if (sg + 1 < n_seg) interval(std::integral_constant<int, (f + 1) & 3>{});
+      if (sg + 2 < n_seg) interval(std::integral_constant<int, (f + 2) & 3>{});
+    };
+    switch (wave) {                                           // turn = (interval - wave) & 3
+      case 0: walk(std::integral_constant<int, 0>{}); break;
+      case 1: walk(std::integral_constant<int, 3>{}); break;
+      case 2: walk(std::integral_constant<int, 2>{}); break;
+      default: walk(std::integral_constant<int, 1>{}); break;
     }
     // the chunk's results: ring -> x (PK_CH <= PK_RING: all of them are still there)
 #pragma unroll
@@ -449,7 +488,7 @@ struct TriFactor {
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
-  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; };   // levels [l0,l1) = positions [lo,hi) of `order`;
+  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; bool long_rows; };   // levels [l0,l1) = positions [lo,hi) of `order`;
   std::vector<Step> steps;                                      // chunks [c0,c1) of the packed form (c0 < 0: none)
   // the factor once more in level order for k_trsv_packed (see there)
   DevBuf<int> pk_row, pk_eptr, pk_seg;
@@ -486,13 +525,13 @@ struct TriFactor {
     const int wide_from = forced_mode() == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
     for (int l = 0; l < n_levels;) {
       if (lp[l + 1] - lp[l] >= wide_from) {
-        steps.push_back(Step{l, l + 1, lp[l], lp[l + 1], true, -1, -1});
+        steps.push_back(Step{l, l + 1, lp[l], lp[l + 1], true, -1, -1, false});
         l++;
         continue;
       }
       int e = l;
       while (e < n_levels && lp[e + 1] - lp[e] < wide_from) e++;
-      steps.push_back(Step{l, e, lp[l], lp[e], false, -1, -1});
+      steps.push_back(Step{l, e, lp[l], lp[e], false, -1, -1, false});
       l = e;
     }
     int rc = build_packed(h_rp, h_ci, h_val, level, lp, ord);
@@ -574,6 +613,8 @@ struct TriFactor {
       }
       st.c0 = (int)chunk0;
       st.c1 = (int)chunk.size();
+      int64_t ents = peptr[st.hi] - peptr[st.lo];
+      st.long_rows = ents > 6 * (int64_t)(st.hi - st.lo);      // more than 6 entries a row on average
       chunk.push_back(st.hi);                                 // every step's list ends with its own sentinel
       segptr.push_back((int)seg.size());
     }
@@ -595,8 +636,10 @@ struct TriFactor {
     PC_TRY(pk_diag.upload(pdiag));
     PC_TRY(pk_hdr.upload(hdr));
     PC_TRY(pk_seg.upload(seg));
-    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)PK_LDS_BYTES));
+    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES));
+    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES));
     return CASK_HIP_OK;
   }
 
@@ -635,8 +678,10 @@ struct TriFactor {
       if (st.wide)
         hipLaunchKernelGGL(k_trsv_level, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, flags,
                            order.p, rp.p, ci.p, val.p, d_b, d_x);
+      else if (packed_ok && st.c0 >= 0 && st.long_rows)
+        hipLaunchKernelGGL(k_trsv_packed<true>, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else if (packed_ok && st.c0 >= 0)
-        hipLaunchKernelGGL(k_trsv_packed, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
+        hipLaunchKernelGGL(k_trsv_packed<false>, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else
         hipLaunchKernelGGL(k_trsv_levels, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, flags, level_ptr.p, order.p,
                            rp.p, ci.p, val.p, d_b, d_x);
