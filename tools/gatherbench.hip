@@ -3,6 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -o build/gatherbench tools/gatherbench.hip ; rocprofv3 --pmc ... -- build/gatherbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <random>
 
@@ -33,13 +34,18 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
   out[i] = acc;
 }
 
-int main() {
+int main(int argc, char **argv) {
+  const int alloc = argc > 1 ? atoi(argv[1]) : 0;   // 0 hipMalloc, 1 uncached, 2 fine-grained (hipExtMallocWithFlags)
   const int n_x = 1 << 20, n = 1 << 20;   // 8 MB table, 1M gathers
   std::vector<int> h(n);
   std::mt19937 rng(1);
   for (auto &v : h) v = rng() % n_x;
   int *idx; double *x, *out, *flush;
-  hipMalloc(&idx, n * 4); hipMalloc(&x, n_x * 8); hipMalloc(&out, 1 << 22); hipMalloc(&flush, 512 << 20);
+  hipMalloc(&idx, n * 4);
+  if (alloc == 0) hipMalloc(&x, n_x * 8);
+  else if (hipExtMallocWithFlags((void **)&x, n_x * 8, alloc == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) { printf("allocation mode %d refused\n", alloc); return 1; }
+  printf("table allocation: %s\n", alloc == 0 ? "hipMalloc" : alloc == 1 ? "uncached" : "fine-grained");
+  hipMalloc(&out, 1 << 22); hipMalloc(&flush, 512 << 20);
   hipMemcpy(idx, h.data(), n * 4, hipMemcpyHostToDevice);
   hipMemset(x, 0, n_x * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

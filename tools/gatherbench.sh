@@ -2,8 +2,11 @@
 # tools/gatherbench.hip with timing and the L2->fabric read-request counters; run on the GPU box.
 cd $GRAFT_REPO_ROOT
 ./build/gatherbench
+./build/gatherbench 1
+./build/gatherbench 2
+ALLOC=${1:-0}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gb_pmc -- $GRAFT_REPO_ROOT/build/gatherbench > /dev/null 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gb_pmc -- $GRAFT_REPO_ROOT/build/gatherbench $ALLOC > /dev/null 2>&1
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/gb_pmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
