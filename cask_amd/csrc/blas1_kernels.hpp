@@ -197,13 +197,15 @@ __device__ __forceinline__ void store_one(double *p, double v, int sys_scope) {
 // CG, second launch of a pass: alpha = rsold / (p.Ap) ; r -= alpha Ap ; shares of r.r
 // (SparseLinearSolvers.hpp:208, 212, 218).  x += alpha p (:210) is applied by the next product launch, which
 // reads p anyway; alpha is left in *alpha_out for it.
+template <bool JAC>
 __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__restrict__ part_pAp, int n_part,
                               const double *__restrict__ Ap, double *__restrict__ r, double *__restrict__ part_rr,
-                              double *alpha_out, const int *done, int sys_scope) {
+                              double *alpha_out, const int *done, int sys_scope, const double *__restrict__ dinv) {
   __shared__ double red[16];
   if (*done) return;
   const dbl2 *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r);
+  const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: the shares are of r.z with z = dinv * r (never stored)
   // every lane's first pair is requested BEFORE the partial sums are waited for: the sums are a dependent L2 round
   // trip at the head of every workgroup (~1 us), the vector loads do not depend on alpha
   const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
@@ -212,6 +214,8 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
   const dbl2 zero2 = {0.0, 0.0};
   const dbl2 av0 = n2 ? Ap2[i0] : zero2;
   const dbl2 rv0 = n2 ? r2[i0] : zero2;
+  dbl2 dv0 = zero2;
+  if constexpr (JAC) dv0 = n2 ? d2[i0] : zero2;
   const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   double acc0 = 0.0, acc1 = 0.0;
@@ -221,13 +225,19 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
     rv.x = fma(-alpha, av.x, rv.x);
     rv.y = fma(-alpha, av.y, rv.y);
     store_pair(r2 + i, rv, sys_scope);
-    acc0 = fma(rv.x, rv.x, acc0);
-    acc1 = fma(rv.y, rv.y, acc1);
+    if constexpr (JAC) {
+      const dbl2 dv = first ? dv0 : d2[i];
+      acc0 = fma(rv.x, rv.x * dv.x, acc0);
+      acc1 = fma(rv.y, rv.y * dv.y, acc1);
+    } else {
+      acc0 = fma(rv.x, rv.x, acc0);
+      acc1 = fma(rv.y, rv.y, acc1);
+    }
   }
   if (owns_tail(n)) {
     const double rn = fma(-alpha, Ap[n - 1], r[n - 1]);
     store_one(r + (n - 1), rn, sys_scope);
-    acc0 = fma(rn, rn, acc0);
+    acc0 = fma(rn, JAC ? rn * dinv[n - 1] : rn, acc0);
   }
   __syncthreads();
   const double s = wg_sum(acc0 + acc1, red);
@@ -284,19 +294,23 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
 //   x += alpha p (SparseLinearSolvers.hpp:210; alpha as k_cg_update_r left it) ; rsnew = r.r ; converged if
 //   rsnew <= tol^2 (:220-226, nothing after it) ; else iterations = iter, p = r + (rsnew/rsold) p (:229-231).
 // x is updated here and not next to r because this launch reads p anyway: one pass over p less per iteration.
+template <bool JAC>
 __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, int n_part, const double *rsold,
                                double *rsnew_out, const double *alpha, double tol2, int iter,
                                const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x,
-                               int *done, int *iters, int sys_scope) {
+                               int *done, int *iters, int sys_scope, const double *__restrict__ dinv) {
   __shared__ double red[16];
   if (*done) return;
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
+  const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: p = z + beta p with z = dinv * r recomputed here
   const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
   const dbl2 zero2 = {0.0, 0.0};
   const dbl2 pv0 = n2 ? p2[i0] : zero2, xv0 = n2 ? x2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2;
+  dbl2 dv0 = zero2;
+  if constexpr (JAC) dv0 = n2 ? d2[i0] : zero2;
   const double rsnew = partials_or_scalar(part_rr, n_part, red);
   const bool stop = rsnew <= tol2;
   const double a = *alpha, beta = stop ? 0.0 : rsnew / *rsold;
@@ -306,7 +320,12 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
     xv.y = fma(a, pv.y, xv.y);
     x2[i] = xv;
     if (!stop) {                                              // launch-uniform
-      const dbl2 rv = first ? rv0 : r2[i];
+      dbl2 rv = first ? rv0 : r2[i];
+      if constexpr (JAC) {
+        const dbl2 dv = first ? dv0 : d2[i];
+        rv.x *= dv.x;
+        rv.y *= dv.y;
+      }
       pv.x = fma(beta, pv.x, rv.x);
       pv.y = fma(beta, pv.y, rv.y);
       store_pair(p2 + i, pv, sys_scope);
@@ -315,7 +334,7 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
   if (owns_tail(n)) {
     const double pn = p[n - 1];
     x[n - 1] = fma(a, pn, x[n - 1]);
-    if (!stop) store_one(p + (n - 1), fma(beta, pn, r[n - 1]), sys_scope);
+    if (!stop) store_one(p + (n - 1), fma(beta, pn, JAC ? r[n - 1] * dinv[n - 1] : r[n - 1]), sys_scope);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *rsnew_out = rsnew;

@@ -1804,8 +1804,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       hipLaunchKernelGGL(k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
                          scal.p + SC_ALPHA, (const int *)done, st.sys_scope);
     else
-      hipLaunchKernelGGL(k_cg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
-                         (const int *)done, st.sys_scope);                              // :208, :212, :218
+      hipLaunchKernelGGL(k_cg_update_r<false>, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
+                         (const int *)done, st.sys_scope, (const double *)nullptr);     // :208, :212, :218
     const double *chk_part = part_a.p, *rho_part = part_b.p;
     int n_chk = g;
     if (st.sharded) {                                         // r.r (and rt.r): one collective
@@ -1822,8 +1822,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
         hipLaunchKernelGGL(k_bicg_update_px, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA,
                            tol2, i, r, rt, slot(SLOT_P0), slot(SLOT_PT0), d_x, done, iters, st.sys_scope);
       else
-        hipLaunchKernelGGL(k_cg_update_px, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA, tol2, i, r,
-                           slot(SLOT_P0), d_x, done, iters, st.sys_scope);              // :210, :220-231
+        hipLaunchKernelGGL(k_cg_update_px<false>, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA, tol2, i, r,
+                           slot(SLOT_P0), d_x, done, iters, st.sys_scope, (const double *)nullptr);   // :210, :220-231
     }
     if (!st.composed && st.sharded && !st.exchange) {
       // classic passes with in-kernel halos: the p update above must be complete on every rank before any
@@ -1934,6 +1934,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   int launched = 0;
   double clean_us = 0.0;
   const bool fused = plan_fuses_dot(m->plan);
+  const double *jacobi = cask_hip_precond_jacobi_scale(precond);   // 1/diag on the device, or NULL for the ILU kinds
   SolverLoadPolicy load_policy(m, nullptr, 6);
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
@@ -1948,22 +1949,26 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
       hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, p.p, Ap.p, partials.p, (const int *)done);
     }
     if (rc) return rc;
-    // x += alpha p ; r -= alpha Ap  (:210-212; the r.r shares this kernel also leaves are not used here)
-    hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rz.p,
-                       (const int *)done);
-    // z = M^-1 r (:215) and the shares of r.z (:218): one pass when the preconditioner can (Jacobi)
-    int n_rz = g;
-    const int fused_pc = cask_hip_precond_apply_dot(precond, r.p, z.p, partials_rz.p, BLAS_MAX_PARTIALS, &n_rz, done, s);
-    if (fused_pc < 0) return fail(CASK_HIP_ERR_RUNTIME, "preconditioner launch failed");
-    if (fused_pc == 0) {
+    if (jacobi) {
+      // Jacobi: z = dinv * r is never stored.  r -= alpha Ap with the shares of r.z (:212-218), then rsnew, the test,
+      // p = z + beta p with z recomputed and the x update this pass owes (:210, :220-231): 3 launches and 10 vector
+      // passes per iteration instead of 4 and 12
+      hipLaunchKernelGGL(k_cg_update_r<true>, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, Ap.p, r.p, partials_rz.p, scal.p + 2,
+                         (const int *)done, 0, jacobi);
+      hipLaunchKernelGGL(k_cg_update_px<true>, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, scal.p + 2, tol * tol, i, r.p,
+                         p.p, dx.p, done, iters, 0, jacobi);
+    } else {
+      // x += alpha p ; r -= alpha Ap  (:210-212; the r.r shares this kernel also leaves are not used here)
+      hipLaunchKernelGGL(k_cg_update_xr, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, p.p, Ap.p, dx.p, r.p, partials_rz.p,
+                         (const int *)done);
+      // z = M^-1 r (:215) and the shares of r.z (:218)
       rc = cask_hip_precond_apply_device(precond, r.p, z.p, s);
       if (rc) return rc;
       hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r.p, z.p, partials_rz.p, (const int *)done);
-      n_rz = g;
+      // rsnew = r.z ; converged? ; p = z + (rsnew/rsold) p   (:220-231)
+      hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, tol * tol, i, z.p, p.p, done,
+                         iters);
     }
-    // rsnew = r.z ; converged? ; p = z + (rsnew/rsold) p   (:220-231)
-    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, partials_rz.p, n_rz, rsold, rsnew, tol * tol, i, z.p, p.p, done,
-                       iters);
     launched = i + 1;
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));

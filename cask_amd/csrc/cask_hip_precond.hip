@@ -446,41 +446,6 @@ __global__ void k_scale(int64_t n, const double *__restrict__ dinv, const double
     z[i] = r[i] * dinv[i];
 }
 
-// Jacobi inside PCG: z = r / diag and the workgroup's share of r.z in one pass (16-byte accesses; the vectors
-// are the solver's own aligned allocations).  Fixed grid and butterfly order => reproducible.
-__global__ void k_scale_dot(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r,
-                            double *__restrict__ z, double *__restrict__ partials, const int *done) {
-  __shared__ double red[16];
-  if (done && *done) return;
-  typedef double dbl2 __attribute__((ext_vector_type(2)));
-  const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv), *r2 = reinterpret_cast<const dbl2 *>(r);
-  dbl2 *z2 = reinterpret_cast<dbl2 *>(z);
-  double a0 = 0.0, a1 = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 1); i += (int64_t)gridDim.x * blockDim.x) {
-    const dbl2 rv = r2[i], dv = d2[i];
-    dbl2 zv;
-    zv.x = rv.x * dv.x;
-    zv.y = rv.y * dv.y;
-    z2[i] = zv;
-    a0 = fma(rv.x, zv.x, a0);
-    a1 = fma(rv.y, zv.y, a1);
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const double zl = r[n - 1] * dinv[n - 1];
-    z[n - 1] = zl;
-    a0 = fma(r[n - 1], zl, a0);
-  }
-  double v = a0 + a1;
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
-    partials[blockIdx.x] = s;
-  }
-}
-
 // One triangular factor (diagonal included) on the device with its level schedule.
 struct TriFactor {
   int n = 0;
@@ -883,17 +848,9 @@ int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32
 
 int cask_hip_precond_rows(const cask_hip_precond *p) { return p ? p->n : -1; }
 
-int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d_z, double *d_partials,
-                               int max_partials, int *n_partials, const int *d_done, hipStream_t stream) {
-  if (!p || p->kind != CASK_HIP_PRECOND_JACOBI || p->n == 0) return 0;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_partials, ((int64_t)p->n / 2 + 255) / 256));
-  hipLaunchKernelGGL(k_scale_dot, dim3(grid), dim3(256), 0, stream, (int64_t)p->n, p->dinv.p, d_r, d_z, d_partials,
-                     d_done);
-  if (hipGetLastError() != hipSuccess) return -1;
-  *n_partials = grid;
-  return 1;
+const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p) {
+  return p && p->kind == CASK_HIP_PRECOND_JACOBI && p->n > 0 ? p->dinv.p : nullptr;
 }
-
 
 // After a host synchronisation: did a sync-free triangular solve of this preconditioner give up on a dependency?
 int cask_hip_precond_check(cask_hip_precond *p) {

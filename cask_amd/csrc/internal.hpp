@@ -49,11 +49,9 @@ struct DevEvent {
 
 }  // namespace caskhip
 
-// Between cask_hip.hip (the PCG driver) and cask_hip_precond.hip: z = M^-1 r together with the partial sums of
-// r.z in ONE pass when the preconditioner allows it (Jacobi); returns 1 if it did (partials[0 .. *n_partials)
-// written, fixed grid => reproducible), 0 if the caller must apply and reduce separately, < 0 on error.
+// Between cask_hip.hip (the PCG driver) and cask_hip_precond.hip.
 struct cask_hip_precond;
 int cask_hip_precond_rows(const cask_hip_precond *p);      // order of the matrix the preconditioner was built from
 int cask_hip_precond_check(cask_hip_precond *p);           // after a host sync: error flag of the sync-free triangular solves
-int cask_hip_precond_apply_dot(cask_hip_precond *p, const double *d_r, double *d_z, double *d_partials,
-                               int max_partials, int *n_partials, const int *d_done, hipStream_t stream);
+// Jacobi: the device vector of 1/diag (the PCG driver folds the scaling into its update kernels); NULL otherwise
+const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p);
