@@ -105,7 +105,7 @@ __global__ void k_trsv_levels(int l0, int l1, int lower, const int *__restrict__
 // prefetch stays in flight across it; x goes to memory once per chunk, out of the ring).
 // Measured, one ILU(0) application (two solves), MI355X, against the row-indexed walk (profiles/r02_trsv.txt):
 // G3_circuit-like (57 436 levels of ~28 rows) 44.6 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
-// 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 44.8 vs 177 ms.  Still ~0.29 us per level: the
+// 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 31.7 vs 177 ms.  Still ~0.29 us per level: the
 // four waves' turns and preparation steps cost what they cost one after the other (ablations in the same file), and a
 // chunk costs ~3.5 us of staging on top.
 struct PackedTri {
@@ -118,7 +118,7 @@ struct PackedTri {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// LONG: the rows of the step have many entries (an FEM factor): the entries beyond the prepared ones are read four at a
+// LONG: the rows of the step have many entries (an FEM factor): the entries beyond the prepared ones are read PK_U at a
 // time.  Short-row steps keep the one-by-one loop -- the unrolled one costs them 10 % in code they never run.
 template <bool LONG>
 __global__ void __launch_bounds__(PK_T)
@@ -224,6 +224,7 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
     // right-hand sides and entry ranges, the entries themselves (three dependent LDS reads) -- its wave does one
     // step per barrier interval while the other three waves have their turns.
     constexpr int PK_Q = 2;
+    constexpr int PK_U = 16;                                  // LONG: entries per pair of dependent LDS reads
     const int wave = tid >> 6, lane = tid & 63;
     int my_level = wave, l_lo = 0, l_hi = 0, idx = 0, e0 = 0, ne = 0;
     double acc = 0.0, diag = 1.0, q_val[PK_Q];
@@ -264,19 +265,19 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
           for (int e = e0 + PK_Q; e < e0 + ne; e++)
             s -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
         } else
-        for (int e = e0 + PK_Q; e < e0 + ne; e += 4) {        // longer rows: the rest straight from LDS, four entries
-          double v4[4], x4[4];                                // per pair of dependent reads, still one FMA after the other
-          int a4[4];
+        for (int e = e0 + PK_Q; e < e0 + ne; e += PK_U) {     // longer rows: the rest straight from LDS, PK_U entries
+          double v4[PK_U], x4[PK_U];                          // per pair of dependent reads, still one FMA after the other
+          int a4[PK_U];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < PK_U; u++) {
             const int eu = min(e + u, e0 + ne - 1);
             a4[u] = s_src[eu];
             v4[u] = s_val[eu];
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+          for (int u = 0; u < PK_U; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
 #pragma unroll
-          for (int u = 0; u < 4; u++)
+          for (int u = 0; u < PK_U; u++)
             if (e + u < e0 + ne) s -= v4[u] * x4[u];
         }
         ring[(cur_cs + idx) & (PK_RING - 1)] = unit ? s : s / diag;
