@@ -104,10 +104,10 @@ __global__ void k_trsv_levels(int l0, int l1, int lower, const int *__restrict__
 // Per level the dependent work is LDS reads, the row's FMAs, an LDS write and a barrier that waits for LDS only (the
 // prefetch stays in flight across it; x goes to memory once per chunk, out of the ring).
 // Measured, one ILU(0) application (two solves), MI355X, against the row-indexed walk (profiles/r02_trsv.txt):
-// G3_circuit-like (57 436 levels of ~28 rows) 44.6 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
-// 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 31.7 vs 177 ms.  Still ~0.29 us per level: the
-// four waves' turns and preparation steps cost what they cost one after the other (ablations in the same file), and a
-// chunk costs ~3.5 us of staging on top.
+// G3_circuit-like (57 436 levels of ~28 rows) 35.5 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
+// 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 31.7 vs 177 ms.  Still ~0.21 us per level on the
+// first: the waves' turns and preparation steps largely cost what they cost one after the other (ablations in the same
+// file), and a chunk costs ~3.5 us of staging on top.
 struct PackedTri {
   const int *row, *eptr, *seg;
   const int4 *hdr;                     // per chunk: {first position, positions, first entry, entries}, {first segment, segments, -, -}
