@@ -160,6 +160,56 @@ def test_argument_checks():
         capi.Preconditioner(7, 1, [0, 1], [0], [1.0])
 
 
+def _lower_system(n, deps, seed=0):
+    """Lower-triangular CSR (diagonal 2..3) with the strictly-lower columns `deps(i)` in row i."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for i in range(n):
+        cs = sorted(set(int(c) for c in deps(i) if 0 <= c < i)) + [i]
+        rows += [i] * len(cs)
+        cols += cs
+    vals = rng.uniform(-0.4, 0.4, len(cols))
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    a.setdiag(rng.uniform(2.0, 3.0, n))
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.copy()
+
+
+@pytest.mark.parametrize("case", ["one_row", "diagonal", "chain", "chain_far_back", "comb", "alternating_widths", "fan_in"])
+def test_packed_walk_edge_cases_match_the_oracle(case):
+    """Shapes that stress the packed walk of the triangular solves (cask_hip_precond.hip): a single row; no dependencies
+    at all (one wide level); a pure chain of 5000 levels of one row (several chunks, every dependency in the LDS
+    ring); the same chain with a second dependency 3000 / 4500 rows back (beyond what the ring may serve: loaded with
+    the chunk, a chunk ahead); a comb of 64-row levels; levels that alternate between 1 and 300 rows (packed steps and
+    per-level launches interleaved); rows that depend on 40 earlier rows each (long-row variant).  Lower solve, and the
+    transposed system as an upper solve."""
+    rng = np.random.default_rng(11)
+    if case == "one_row":
+        n, deps = 1, lambda i: []
+    elif case == "diagonal":
+        n, deps = 5000, lambda i: []
+    elif case == "chain":
+        n, deps = 5000, lambda i: [i - 1]
+    elif case == "chain_far_back":
+        n, deps = 9000, lambda i: [i - 1, i - 3000, i - 4500]
+    elif case == "comb":
+        n, deps = 64 * 120, lambda i: [i - 64, i - 128] if i >= 64 else []
+    elif case == "alternating_widths":
+        # blocks of 301 rows: a head row that depends on the previous block's head, then 300 rows that depend on it
+        n, deps = 301 * 40, lambda i: [i - 301] if i % 301 == 0 else [i - i % 301]
+    else:
+        n, deps = 3000, lambda i: list(rng.integers(0, max(i, 1), 40))
+    rp, ci, va = _lower_system(n, deps)
+    b = rng.standard_normal(n)
+    oracle.assert_almost_equal(capi.trsolve(n, rp, ci, va, b, lower=True), oracle.trsolve(rp, ci, va, b, lower=True),
+                               what=f"{case} lower")
+    at = sp.csr_matrix((va, ci, rp), shape=(n, n)).T.tocsr()
+    at.sort_indices()
+    urp, uci, uva = at.indptr.astype(np.int32), at.indices.astype(np.int32), at.data
+    oracle.assert_almost_equal(capi.trsolve(n, urp, uci, uva, b, lower=False), oracle.trsolve(urp, uci, uva, b, lower=False),
+                               what=f"{case} upper")
+
+
 def test_triangular_solve_schedules_agree_bit_for_bit():
     """Three schedules of the same triangular solve (cask_hip_precond.hip): the packed walk of narrow-level runs (the
     default), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
