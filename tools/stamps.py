@@ -15,11 +15,14 @@ import torch
 
 def main():
     wg, ipt = int(sys.argv[1]) if len(sys.argv) > 1 else 512, int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    n, rp, ci, va, _ = synth.load_or_make("cant")
+    name = sys.argv[3] if len(sys.argv) > 3 else "cant"           # any BASELINE look-alike
+    tile = int(sys.argv[4]) if len(sys.argv) > 4 else 1024        # 0 = AUTO, -1 = untiled
+    n, rp, ci, va, _ = synth.load_or_make(name)
     dev = torch.device("cuda", 0)
-    copies = 13
+    copies = 13 if name == "cant" else 5
     rp_t = torch.from_numpy(rp).to(dev)
-    prm = capi.make_params(variant="merge", wg_size=wg, items_per_thread=ipt, tile_width=1024)
+    prm = capi.make_params(variant="merge", wg_size=wg, items_per_thread=ipt, tile_width=tile)
+    print(name, "wg", wg, "items", ipt, "tile", tile)
     mats = [capi.CsrMatrix.from_device(n, n, rp_t, torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), prm)
             for _ in range(copies)]
     x = torch.from_numpy(np.arange(n) * 0.25 / n).to(dev)
