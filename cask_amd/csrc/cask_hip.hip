@@ -206,7 +206,7 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
     int by_len = 1;
     while (by_len < mean && by_len < 64) by_len *= 2;
     d.kind_g = std::min(64, std::max(1, std::min(by_rows, by_len)));
-    if (cur_max > SKEW_FACTOR * (d.kind_g & 0xff)) d.kind_g |= KIND_SKEW;   // long rows get a wave each
+    if (cur_max > skew_short_max(d.kind_g & 0xff)) d.kind_g |= KIND_SKEW;   // longer rows: 16 lanes or a wave each
     if (cur_nnz == 0) {
       // a run of empty rows: nothing to stream.  The stream path would still issue its clamped 16-byte pair
       // loads, and for a block at the (odd) end of the arrays the pair's second element lies past col_ind --

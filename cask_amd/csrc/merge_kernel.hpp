@@ -16,7 +16,7 @@ namespace caskhip {
 // elements in flight per lane, independent of row structure) and parks the
 // products in LDS; phase 2 sums each row's run of products with G lanes per
 // row (G chosen per block from its mean row length) and a DPP butterfly.
-// Rows longer than SKEW_FACTOR*G products are left to a second pass in which a whole wave sums one row
+// Rows longer than skew_short_max(G) products are left to a second pass in which 16 lanes or a whole wave sum one row
 // (power-law blocks: a 500-nonzero row among 3-nonzero rows would otherwise keep one lane busy for
 // microseconds while 255 idle).  The host flags such blocks (KIND_SKEW); others pay one compare.
 
@@ -54,14 +54,21 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
   const int rows_per_pass = blockDim.x / G;
   const int j = tid & (G - 1);
   double dsum = 0.0;
-  // pass 1: rows of ordinary length, G lanes each; long rows are left to pass 2
+  // Three classes of row (power-law blocks: ~680 rows on 256 threads, most with 1-2 products, a few with hundreds):
+  //   short  (<= skew_short_max(G) products)  G lanes each, all rows of the block in parallel -- pass 1;
+  //   medium (<= SKEW_MED_MAX, only when G <= 2)  16 lanes each, four rows per wave at a time   -- pass 2;
+  //   long   a whole wave each                                                                  -- pass 2.
+  // One lane walking a 30-product row while its 63 neighbours wait for it was 2 of the 3 us this phase took on the
+  // webbase-like matrix (profiles/r02_webbase_anatomy.txt).
+  constexpr int SHORT_MAX = skew_short_max(G);
+  constexpr int MED_MAX = G <= 2 ? SKEW_MED_MAX : SHORT_MAX;
   for (int r0 = 0; r0 < d.n_rows; r0 += rows_per_pass) {
     const int r = r0 + tid / G;
     double acc = 0.0;
     bool mine = r < d.n_rows;
     if (mine) {
       const int s = roff[r], e = roff[r + 1];
-      if (e - s > SKEW_FACTOR * G) {
+      if (e - s > SHORT_MAX) {
         mine = false;
       } else {
 #pragma unroll 4
@@ -74,19 +81,39 @@ __device__ __forceinline__ double reduce_rows(const BlockDesc &d, const double *
       if (EXT && w) dsum = fma(w[r], acc, dsum);
     }
   }
-  // pass 2: a whole wave per long row.  Every wave scans the row lengths 64 at a time (one ballot per
-  // chunk) and takes the long rows round-robin IN ROW ORDER, so which wave sums which row -- and with it
-  // the order of every floating-point addition -- is a function of the matrix alone (no queue, no atomics).
-  const int lane = tid & 63, wave = tid >> 6, wave_mask = (blockDim.x >> 6) - 1;
-  int seen = 0;
-  for (int c0 = 0; c0 < d.n_rows; c0 += 64) {                 // workgroup-uniform
+  // pass 2: every wave takes the 64-row chunks c = wave, wave + n_waves, ... ; one ballot per class and chunk tells
+  // it which rows are left.  Which lanes sum which row -- and with it the order of every floating-point addition --
+  // is a function of the matrix alone (no queue, no atomics).
+  const int lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  for (int c0 = wave * 64; c0 < d.n_rows; c0 += n_waves * 64) {   // wave-uniform
     const int r = c0 + lane;
-    const bool is_long = r < d.n_rows && roff[r + 1] - roff[r] > SKEW_FACTOR * G;
-    unsigned long long todo = __ballot(is_long);
-    while (todo) {                                            // wave-uniform
+    const int len = r < d.n_rows ? roff[r + 1] - roff[r] : 0;
+    unsigned long long med = __ballot(len > SHORT_MAX && len <= MED_MAX);
+    unsigned long long todo = __ballot(len > MED_MAX);
+    while (med) {                                             // four medium rows at a time, 16 lanes each
+      int pick[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        pick[g] = med ? __builtin_ctzll(med) : -1;
+        med &= med - 1;                                       // (0 stays 0)
+      }
+      const int gi = lane >> 4, gl = lane & 15;
+      const int b = gi == 0 ? pick[0] : gi == 1 ? pick[1] : gi == 2 ? pick[2] : pick[3];
+      double acc = 0.0;
+      if (b >= 0) {
+        const int s = roff[c0 + b], e = roff[c0 + b + 1];
+#pragma unroll 4
+        for (int k = s + gl; k < e; k += 16) acc += prod[k];
+      }
+      acc = group_sum<16>(acc);
+      if (gl == 0 && b >= 0) {
+        y[d.row_start + c0 + b] = acc;
+        if (EXT && w) dsum = fma(w[c0 + b], acc, dsum);
+      }
+    }
+    while (todo) {                                            // a whole wave per long row
       const int b = __builtin_ctzll(todo);
       todo &= todo - 1;
-      if (((seen++) & wave_mask) != wave) continue;
       const int row = c0 + b;
       const int s = roff[row], e = roff[row + 1];
       double a0 = 0.0, a1 = 0.0;

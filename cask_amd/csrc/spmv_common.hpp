@@ -201,5 +201,10 @@ __device__ __forceinline__ T stream_load(const T *p) {
 
 // Rows longer than SKEW_FACTOR * (lanes per row) products get a whole wave each in a second pass.
 constexpr int SKEW_FACTOR = 32;
+// MERGE blocks with 1 or 2 lanes per row (hundreds of short rows per block): rows beyond SKEW_SHORT * G products
+// leave the first pass already and are summed by 16 lanes (up to SKEW_MED_MAX products) or a wave.
+constexpr int SKEW_SHORT = 8;
+constexpr int SKEW_MED_MAX = 512;
+__host__ __device__ constexpr int skew_short_max(int g) { return g <= 2 ? SKEW_SHORT * g : SKEW_FACTOR * g; }
 
 }  // namespace caskhip
