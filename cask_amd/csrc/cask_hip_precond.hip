@@ -48,10 +48,10 @@ constexpr int WIDE_LEVEL_ROWWALK = 16384;  // the same for the row-indexed walk 
 constexpr int PK_T = 256;              // threads
 constexpr int PK_CH = 1024;            // positions (rows in level order) staged per chunk
 constexpr int PK_ECAP = 3072;          // off-diagonal entries staged per chunk
-constexpr int PK_RING = 4096;          // x values of the most recent positions kept in LDS; >= 2 PK_CH + WIDE_LEVEL
+constexpr int PK_RING = 4096;          // x values of the most recent positions kept in LDS; >= 3 PK_CH + WIDE_LEVEL
 constexpr int PK_PJ = PK_CH / PK_T, PK_EJ = PK_ECAP / PK_T;
 constexpr unsigned PK_NEAR = 0x80000000u;
-static_assert(PK_RING >= 2 * PK_CH + WIDE_LEVEL && (PK_RING & (PK_RING - 1)) == 0, "ring covers what staging cannot prefetch");
+static_assert(PK_RING >= 3 * PK_CH + WIDE_LEVEL && (PK_RING & (PK_RING - 1)) == 0, "ring covers what staging cannot prefetch");
 constexpr size_t PK_LDS_BYTES = sizeof(double) * (PK_RING + 2 * PK_ECAP + 2 * PK_CH) +
                                 sizeof(int) * (PK_ECAP + (PK_CH + 1) + (PK_CH + 1));
 
@@ -99,12 +99,12 @@ __global__ void k_trsv_levels(int l0, int l1, int lower, const int *__restrict__
 // A dependency x[c] comes from one of two places, decided when the factor is built:
 //   near   the producer is among the last PK_RING positions of this launch: every solved x is also kept in an LDS
 //          ring indexed by position, so the value is one LDS read away;
-//   early  the producer was finished before chunk k-1 started: x[c] is loaded from memory with the rest of the chunk,
-//          a chunk ahead (PK_RING >= 2 PK_CH + the widest level makes these two cases cover everything).
+//   early  the producer belongs to a chunk at least three before the consumer's: x[c] is loaded from memory with the
+//          rest of the chunk, a chunk ahead (PK_RING >= 3 PK_CH + the widest level makes the two cases cover everything).
 // Per level the dependent work is LDS reads, the row's FMAs, an LDS write and a barrier that waits for LDS only (the
 // prefetch stays in flight across it; x goes to memory once per chunk, out of the ring).
 // Measured, one ILU(0) application (two solves), MI355X, against the row-indexed walk (profiles/r02_trsv.txt):
-// G3_circuit-like (57 436 levels of ~28 rows) 35.5 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
+// G3_circuit-like (57 436 levels of ~28 rows) 32.2 vs 208 ms, atmosmodd-like (322 levels, most of them wide: launches)
 // 3.3 vs 38.8 ms, cant-like (8 548 levels of ~7 rows x 32 entries) 31.7 vs 177 ms.  Still ~0.21 us per level on the
 // first: the waves' turns and preparation steps largely cost what they cost one after the other (ablations in the same
 // file), and a chunk costs ~3.5 us of staging on top.
@@ -203,12 +203,15 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
     h1 = t.hdr[2 * c0 + 3];
   }
   for (int k = c0; k < c1; k++) {
-    // chunk k-1 is finished, and its x stores have left this CU before anybody issues chunk k+1's early loads
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Chunk k-1 is finished.  Its x stores (the youngest four memory operations of every thread) may still be on their
+    // way: only the stores of chunk k-2 and everything older must have landed before anybody issues chunk k+1's early
+    // loads below -- the factor's builder lets a chunk's early loads rely on chunks at least three back.  (Waiting for
+    // the write-through stores themselves cost 1.2 us per chunk.)  Both barriers order LDS traffic only.
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    lds_barrier();
     store_chunk(cnt, ecnt, scnt);
     const int cur_cs = cs, n_pos = cnt, n_seg = scnt;
-    __syncthreads();
+    lds_barrier();
     if (k + 1 < c1) {
       cs = uniform(h0.x); cnt = uniform(h0.y); ebase = uniform(h0.z); ecnt = uniform(h0.w);
       sbase = uniform(h1.x); scnt = uniform(h1.y);
@@ -334,10 +337,9 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
     }
     // the chunk's results: ring -> x (PK_CH <= PK_RING: all of them are still there)
 #pragma unroll
-    for (int j = 0; j < PK_PJ; j++) {
-      const int idx = tid + PK_T * j;
-      if (idx < n_pos)
-        __hip_atomic_store(x + w_row[j], ring[(cur_cs + idx) & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < PK_PJ; j++) {                         // always four stores per thread (see the wait above): lanes past
+      const int idx = min(tid + PK_T * j, n_pos - 1);         // the end repeat the chunk's last row (w_row is clamped alike)
+      __hip_atomic_store(x + w_row[j], ring[(cur_cs + idx) & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -545,7 +547,9 @@ struct TriFactor {
       if (st.wide) continue;
       const size_t chunk0 = chunk.size(), segptr0 = segptr.size(), seg0 = seg.size();
       bool ok = true;
-      int prev_start = st.lo;                                 // what a chunk's early loads may rely on: positions before this
+      // what a chunk's early loads may rely on: positions before the start of the chunk TWO before it (the kernel
+      // lets the x stores of a chunk drain during the next chunk's walk)
+      int prev_start = st.lo, prev2_start = st.lo;
       for (int cs = st.lo; cs < st.hi && ok;) {
         int ce = cs;
         while (ce < st.hi && ce - cs < PK_CH && peptr[ce + 1] - peptr[cs] <= PK_ECAP) ce++;
@@ -562,9 +566,10 @@ struct TriFactor {
           for (int e = peptr[i]; e < peptr[i + 1]; e++) {
             const int pp = pos_of[pcode[e]];
             if (pp >= st.lo && pp >= level_end - PK_RING) pcode[e] = PK_NEAR | (unsigned)pp;
-            else if (pp >= prev_start) { ok = false; break; }  // cannot happen while PK_RING >= 2 PK_CH + WIDE_LEVEL
+            else if (pp >= prev2_start) { ok = false; break; } // cannot happen while PK_RING >= 3 PK_CH + WIDE_LEVEL
           }
         }
+        prev2_start = prev_start;
         prev_start = cs;
         cs = ce;
       }
