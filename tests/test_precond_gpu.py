@@ -210,6 +210,30 @@ def test_packed_walk_edge_cases_match_the_oracle(case):
                                what=f"{case} upper")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_packed_walk_random_dependency_graphs(seed):
+    """Random lower-triangular systems: every row depends on 0-6 earlier rows at mixed distances (next door, a few
+    thousand rows back, anywhere), so that levels of every width occur and a row's dependencies come from the LDS ring,
+    from the chunk-ahead loads and from earlier launches alike.  Against the oracle, lower and (transposed) upper."""
+    rng = np.random.default_rng(seed)
+    n = 30_000 + 1000 * seed
+
+    def deps(i):
+        k = int(rng.integers(0, 7))
+        reach = rng.choice([3, 60, 2500, 6000, max(i, 1)], size=k)
+        return [i - 1 - int(rng.integers(0, max(1, min(int(r), i)))) for r in reach] if i else []
+
+    rp, ci, va = _lower_system(n, deps, seed=seed)
+    b = rng.standard_normal(n)
+    oracle.assert_almost_equal(capi.trsolve(n, rp, ci, va, b, lower=True), oracle.trsolve(rp, ci, va, b, lower=True),
+                               what="random lower")
+    at = sp.csr_matrix((va, ci, rp), shape=(n, n)).T.tocsr()
+    at.sort_indices()
+    urp, uci, uva = at.indptr.astype(np.int32), at.indices.astype(np.int32), at.data
+    oracle.assert_almost_equal(capi.trsolve(n, urp, uci, uva, b, lower=False), oracle.trsolve(urp, uci, uva, b, lower=False),
+                               what="random upper")
+
+
 def test_triangular_solve_schedules_agree_bit_for_bit():
     """Three schedules of the same triangular solve (cask_hip_precond.hip): the packed walk of narrow-level runs (the
     default), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
