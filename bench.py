@@ -52,7 +52,7 @@ HALO_FRACTION_FOR_ALLGATHER = 0.10   # a block that references more than this sh
 #   blocks reference 16 % of x scattered over every peer; stencil / banded blocks 0.1-2 % from their neighbours)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -71,7 +71,13 @@ def parse_args():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--items", type=int, default=0)
     ap.add_argument("--wg", type=int, default=0)
-    return ap.parse_args()
+    ap.add_argument("--no-others", action="store_true",
+                    help="headline workload only (the default cant run otherwise appends the other BASELINE configs "
+                         "under config.other_workloads)")
+    ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each appended workload")
+    ap.add_argument("--other-seconds", type=float, default=150.0,
+                    help="watchdog for the appended workloads as a whole: past it the headline line is printed without them")
+    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------- CPU baselines
@@ -291,14 +297,55 @@ def cpu_baseline_solver_port(kind, rp, ci, va, b, seconds):
 
 
 # ------------------------------------------------------------------------------------------------- main
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process -- which has not imported torch or
+    touched the GPU -- starts the N ranks as CHILD processes (never an exec), one per GPU, with the rendezvous
+    variables torch.distributed.run would set, relays rank 0's JSON line (rank 0 inherits stdout) and exits with the
+    children's status."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = list(procs)
+    try:
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:                       # one rank failed: the others would wait in a collective
+                        q.send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in pending:
+            q.kill()
+        rc = 130
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(or leave WORLD_SIZE unset and bench.py starts them itself)")
     # CASK_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all_gather, all_reduce) with a single
     # rank: the RCCL path on a 1-GPU box.
     use_dist = world > 1 or bool(os.environ.get("CASK_BENCH_FORCE_DIST"))
@@ -342,17 +389,86 @@ def main():
             dist.barrier()
     cx.all_reduce_scalar, cx.host_barrier = all_reduce_scalar, host_barrier
 
-    if args.solver:
-        rec = run_solver(cx)
-    elif args.workload in ("cant", "cant3"):
-        rec = run_spmv(cx, weak=True)
-    else:
-        rec = run_spmv(cx, weak=False)
+    def run_one(a):
+        c = Ctx()
+        c.__dict__.update(cx.__dict__)
+        c.args = a
+        if a.solver:
+            return run_solver(c)
+        return run_spmv(c, weak=a.workload in ("cant", "cant3"))
+
+    rec = run_one(args)
+    # ---- the other BASELINE configs next to the headline (default cant run only) ------------------------------
+    if args.workload == "cant" and not args.solver and not args.no_others:
+        import threading
+        state = {"done": False}
+        others = []
+        if rank == 0:
+            rec["config"]["other_workloads"] = others
+
+        def give_up():                                       # a hung collective in an appended workload must not
+            if state["done"]:                                # cost the headline: print what there is and leave
+                return
+            if rank == 0:
+                others.append({"error": f"watchdog: appended workloads exceeded {args.other_seconds:.0f} s"})
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.other_seconds, give_up)
+        dog.daemon = True
+        dog.start()
+        for spec in other_workload_specs(world):
+            a = argparse.Namespace(**vars(args))
+            a.workload, a.solver = spec["workload"], spec.get("solver")
+            a.steps, a.warmup = args.other_steps, max(2, args.other_steps // 10)
+            a.no_cpu_baseline, a.launch, a.copies = True, "auto", 0
+            a.variant, a.lanes, a.tile, a.items, a.wg = None, 0, 0, 0, 0
+            t0 = time.perf_counter()
+            try:
+                sub = run_one(a)
+                if rank == 0:
+                    others.append(summarise_other(spec, sub, time.perf_counter() - t0))
+            except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
+                if use_dist:
+                    raise                                     # a rank that drops out would strand its peers: fail loudly
+                others.append({"config": spec["config"], "workload": spec["workload"], "error": repr(e)})
+        state["done"] = True
+        dog.cancel()
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if use_dist:
         host_barrier()
         dist.destroy_process_group()
+
+
+def other_workload_specs(world):
+    """What the default run times after the headline: at N = 1 the other BASELINE configs in their 1-GPU form, at N > 1
+    the strong-scaling configs[3] and [4] (+ CG on G3_circuit, configs[2] sharded)."""
+    if world == 1:
+        return [{"config": "configs[1] second look-alike", "workload": "cant3"},
+                {"config": "configs[3] on 1 GPU", "workload": "webbase-1M"},
+                {"config": "configs[2]", "workload": "G3_circuit", "solver": "cg"},
+                {"config": "configs[4] on 1 GPU", "workload": "atmosmodd", "solver": "bicg"}]
+    return [{"config": "configs[3]", "workload": "webbase-1M"},
+            {"config": "configs[4]", "workload": "atmosmodd", "solver": "bicg"},
+            {"config": "configs[2] row-sharded", "workload": "G3_circuit", "solver": "cg"}]
+
+
+def summarise_other(spec, sub, seconds):
+    c, roof = sub["config"], sub["roofline"]
+    out = {"config": spec["config"], "workload": c["workload"], "metric": sub["metric"], "value": sub["value"],
+           "unit": sub["unit"], "usec": roof["launch_usec"], "steps": sub["steps"], "scaling": sub["scaling"],
+           "frac": roof["frac"], "hbm_gbs_algorithmic_per_gpu": roof["achieved"],
+           "algorithmic_bytes_per_step_per_gpu": roof["algorithmic_bytes_per_launch"],
+           "traffic": roof.get("traffic"), "exchange": c.get("exchange"), "design_point": c.get("design_point"),
+           "seconds_in_bench": round(seconds, 1)}
+    if "solve_check" in c:
+        out["solve_check"] = c["solve_check"]
+        out["collectives"] = c.get("collectives")
+    else:
+        out["rows_wrong"] = c.get("rows_wrong_vs_oracle_all_ranks")
+        out["matrix_copies_rotated"] = c.get("matrix_copies_rotated")
+        out["launch"] = c.get("launch")
+    return out
 
 
 def timed_region(cx, run_steps, lead_in=None):
@@ -630,15 +746,15 @@ def run_spmv(cx, weak):
         "(starting a graph on an idle stream costs ~15 us: 8 % of a 20-step region)" if graph is not None else
         "; an untimed sequence of K launches is queued in front of the first event" if sequence else "")
     y_gpu = y.cpu().numpy()
-    rows_wrong = None
+    # post-run check: every rank's whole block against the CPU oracle (the global x is a formula, nothing to gather)
+    import oracle
+    bad, _ = oracle.mismatches(y_gpu, oracle.csr_spmv(rp, ci, va, x_host))
     if use_dist:
         nnz_total = cx.all_reduce_scalar(nnz_local, dist.ReduceOp.SUM)
-        # every rank checks its whole block against the CPU oracle (the global x is a formula, nothing to gather)
-        import oracle
-        bad, _ = oracle.mismatches(y_gpu, oracle.csr_spmv(rp, ci, va, x_host))
         rows_wrong = int(cx.all_reduce_scalar(bad, dist.ReduceOp.SUM))
     else:
         nnz_total = float(nnz_local)
+        rows_wrong = int(bad)
 
     # ---- cache-warm rate of ONE copy (what a CG iteration on this matrix sees) ------
     warm_med, warm_min = mats[0].time(x_in, y, warmup=10, iters=200)        # eager launches, one event pair each
@@ -736,8 +852,8 @@ def run_solver(cx):
     n, rp, ci, va, source = synth.load_or_make(name)
     nnz = int(ci.size)
     x_true = np.random.default_rng(5).uniform(-1, 1, n)          # b = A x_true: the reference harness (test_utils.hpp:61-70)
-    import oracle
-    b = oracle.csr_spmv(rp, ci, va, x_true)
+    import scipy.sparse as sp
+    b = np.asarray(sp.csr_matrix((va, ci, rp), shape=(n, n)) @ x_true)      # set-up, not the checker's job
 
     forced = capi.make_params(variant=args.variant or 0, tile_width=args.tile, items_per_thread=args.items, wg_size=args.wg)
     bounds = cdist.partition_rows_by_nnz(rp, world)
@@ -794,6 +910,7 @@ def run_solver(cx):
         x_all = np.concatenate(parts)
     check = None
     if rank == 0:
+        import oracle                                               # post-run check only
         res = float(np.linalg.norm(b - oracle.csr_spmv(rp, ci, va, x_all)))
         want_x, want_it, want_conv = (oracle.cg_full if kind == "cg" else oracle.bicg)(rp, ci, va, b)
         check = {"iterations": it, "converged": conv, "oracle_iterations": want_it, "oracle_converged": want_conv,

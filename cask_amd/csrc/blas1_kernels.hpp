@@ -158,10 +158,10 @@ __global__ void k_cg_update_p(int64_t n, const double *__restrict__ part_rr, int
                               double *rsnew_out, double tol2, int iter, const double *__restrict__ r,
                               double *__restrict__ p, int *done, int *iters) {
   __shared__ double red[16];
-  if (*done) return;
+  if (done_by_earlier_launch(done, iter)) return;
   const double rsnew = partials_or_scalar(part_rr, n_part, red);
   if (rsnew <= tol2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *done = 1; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *rsnew_out = rsnew; *done = done_tag(iter); }
     return;
   }
   const double beta = rsnew / *rsold;
@@ -300,7 +300,7 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
                                const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x,
                                int *done, int *iters, int sys_scope, const double *__restrict__ dinv) {
   __shared__ double red[16];
-  if (*done) return;
+  if (done_by_earlier_launch(done, iter)) return;
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
   const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: p = z + beta p with z = dinv * r recomputed here
@@ -338,7 +338,7 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *rsnew_out = rsnew;
-    if (stop) *done = 1; else *iters = iter;
+    if (stop) *done = done_tag(iter); else *iters = iter;
   }
 }
 
@@ -349,7 +349,7 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
                                  double *__restrict__ p, double *__restrict__ pt, double *__restrict__ x, int *done,
                                  int *iters, int sys_scope) {
   __shared__ double red[16];
-  if (*done) return;
+  if (done_by_earlier_launch(done, iter)) return;
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt), *x2 = reinterpret_cast<dbl2 *>(x);
   const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
@@ -388,7 +388,7 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (stop) *done = 1; else { *rho_out = rho_new; *iters = iter; }
+    if (stop) *done = done_tag(iter); else { *rho_out = rho_new; *iters = iter; }
   }
 }
 

@@ -1856,7 +1856,7 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   if (iterations) *iterations = h_flags[1];
-  if (converged) *converged = h_flags[0];
+  if (converged) *converged = h_flags[0] != 0;          // the flag carries the pass that set it
   // passes launched after the converged one are no-ops: prefer the rate measured up to the last
   // checkpoint that had not converged yet
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
@@ -1989,7 +1989,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   if (iterations) *iterations = h_flags[1];
-  if (converged) *converged = h_flags[0];
+  if (converged) *converged = h_flags[0] != 0;          // the flag carries the pass that set it
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
   return cask_hip_precond_check(precond);
 }

@@ -200,7 +200,7 @@ __device__ __forceinline__ PassScalars pass_scalars(const SolverPass &sp, int lb
   if (chk <= sp.tol2) {                                       // SparseLinearSolvers.hpp:220-226: nothing after the test
     if (lb == 0 && threadIdx.x == 0 && !sp.secondary) {
       if (sp.part_num == sp.part_chk && sp.num_out) *sp.num_out = chk;
-      *sp.done = 1;
+      *sp.done = done_tag(sp.iter);                          // tagged: see blas1_kernels.hpp, done_by_earlier_launch
     }
     ps.stop = true;
     return ps;
@@ -606,7 +606,8 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const SolverPass sp = pass_of(pass_arg);                    // EXT < 2: all zeros, every use folds away
   PassScalars ps{0.0, 0.0, false, false};
   if (EXT == 2) {
-    if (*sp.done) return;                                     // a pass after the converged one: nothing happens
+    if (done_by_earlier_launch(sp.done, sp.iter)) return;     // a pass after the converged one: nothing happens (a flag set by a
+                                                              // workgroup of THIS launch must not stop the others: they owe x)
     ps = pass_scalars(sp, lb, prod);                          // LDS not in use yet
     __syncthreads();
     if (ps.stop) {                                            // workgroup-uniform (and the same in every workgroup)

@@ -207,4 +207,14 @@ constexpr int SKEW_SHORT = 8;
 constexpr int SKEW_MED_MAX = 512;
 __host__ __device__ constexpr int skew_short_max(int g) { return g <= 2 ? SKEW_SHORT * g : SKEW_FACTOR * g; }
 
+// The convergence flag is written by a workgroup of the launch that detects convergence while other workgroups
+// of the SAME launch may not have started yet (a grid is not guaranteed to be co-resident) -- and those still owe
+// their share of the pass (the solution update).  The flag therefore carries the pass that set it: a launch
+// returns early only on a flag some EARLIER launch wrote.  Non-zero = converged for everybody else.
+__device__ __forceinline__ int done_tag(int iter) { return iter + 1; }
+__device__ __forceinline__ bool done_by_earlier_launch(const int *done, int iter) {
+  const int d = *done;
+  return d != 0 && d != done_tag(iter);
+}
+
 }  // namespace caskhip

@@ -29,9 +29,12 @@ def last_json_line(text):
     return json.loads(lines[-1])
 
 
-def run_bench(extra, env=None, world=1, timeout=900):
+def run_bench(extra, env=None, world=1, timeout=900, launcher=True):
     cmd = [sys.executable]
-    if world > 1:
+    if "--solver" not in extra and "--workload" not in extra and "--with-others" not in extra:
+        extra = extra + ["--no-others"]                     # the appended workloads have their own test below
+    extra = [e for e in extra if e != "--with-others"]
+    if world > 1 and launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                 "--master-port", str(free_port())]
     cmd += [str(REPO / "bench.py"), "--gpus", str(world)] + extra
@@ -123,3 +126,54 @@ def test_config3_cg_full_size_single_gpu_line():
     assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
     assert chk["residual_2norm_by_oracle_product"] <= 2e-5
     assert rec["cpu_baseline"]["kind"] in ("mkl", "port") and rec["value"] > 100
+
+
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the form of the driver's recorded
+    command -- starts its two ranks itself (child processes), relays rank 0's line and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SHARE)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--copies", "2",
+           "--no-cpu-baseline", "--no-tune", "--no-others"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = last_json_line(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1     # ONE line, rank 0's
+
+
+def test_default_line_carries_the_other_baseline_configs():
+    """the N = 1 default run times cant3, webbase-1M, CG on G3_circuit and BiCG on atmosmodd after
+    the headline and reports them under config.other_workloads with their own checks."""
+    rec = run_bench(["--steps", "20", "--warmup", "4", "--copies", "3", "--cpu-seconds", "0.5", "--other-steps", "40",
+                     "--with-others"])
+    others = rec["config"]["other_workloads"]
+    assert [o.get("error") for o in others] == [None] * 4, others
+    names = [o["workload"] for o in others]
+    assert "cant" in names[0] and "webbase-1M" in names[1] and "G3_circuit" in names[2] and "atmosmodd" in names[3]
+    for o in others[:2]:
+        assert o["rows_wrong"] == 0 and 0 < o["frac"] < 1 and o["usec"] > 0
+    for o in others[2:]:
+        chk = o["solve_check"]
+        assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
+        assert chk["residual_2norm_by_oracle_product"] <= 5e-5 and 0 < o["frac"] < 1
+    # the headline is the cant line, on its own clock, unchanged by what follows
+    assert rec["config"]["workload"].startswith("cant-like") and rec["steps"] == 20
+
+
+def test_two_rank_line_appends_the_strong_scaling_configs():
+    """at N > 1 configs[3] (webbase-1M, all-gather) and configs[4] (BiCG on atmosmodd) follow the weak
+    cant headline; two ranks sharing the GPU, started by bench.py itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SHARE)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--copies", "2",
+           "--no-cpu-baseline", "--no-tune", "--other-steps", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = last_json_line(out.stdout)
+    others = rec["config"]["other_workloads"]
+    assert [o.get("error") for o in others] == [None] * 3, others
+    assert others[0]["rows_wrong"] == 0 and others[0]["scaling"] == "strong"
+    for o in others[1:]:
+        chk = o["solve_check"]
+        assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
