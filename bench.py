@@ -66,7 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--copies", type=int, default=0, help="matrix copies to rotate through (0 = auto)")
-    ap.add_argument("--variant", default=None, help="force a design point: vector|merge")
+    ap.add_argument("--variant", default=None, help="force a design point: vector|merge|merge_wave|scan")
+    ap.add_argument("--far", type=int, default=0, help="far_columns of the forced design point")
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--items", type=int, default=0)
@@ -421,7 +422,7 @@ def main():
             a.workload, a.solver = spec["workload"], spec.get("solver")
             a.steps, a.warmup = args.other_steps, max(2, args.other_steps // 10)
             a.no_cpu_baseline, a.launch, a.copies = True, "auto", 0
-            a.variant, a.lanes, a.tile, a.items, a.wg = None, 0, 0, 0, 0
+            a.variant, a.lanes, a.tile, a.items, a.wg, a.far = None, 0, 0, 0, 0, 0
             t0 = time.perf_counter()
             try:
                 sub = run_one(a)
@@ -588,7 +589,7 @@ def run_spmv(cx, weak):
     copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // max(matrix_bytes, 1)) + 1)
 
     forced = capi.make_params(variant=args.variant or 0, lanes_per_row=args.lanes, tile_width=args.tile,
-                              items_per_thread=args.items, wg_size=args.wg,
+                              items_per_thread=args.items, wg_size=args.wg, far_columns=args.far,
                               index16=int(os.environ.get("CASK_BENCH_INDEX16", "0")))   # development A/B only
     mats = []
     torch.cuda.synchronize()

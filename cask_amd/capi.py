@@ -14,9 +14,9 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
 
-VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN = 0, 1, 2, 3, 4
 VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge",
-                 VARIANT_MERGE_WAVE: "merge_wave"}
+                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan"}
 
 # Every symbol include/cask_hip.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = (

@@ -17,8 +17,10 @@
 #include "blas1_kernels.hpp"
 #include "cask_hip.h"
 #include "merge_launch.hpp"
+#include "scan_launch.hpp"
 #include "spmv_kernels.hpp"
 #ifdef CASK_UNITY   // single-translation-unit build (diagnostic builds: tools/stamps.py)
+#include "scan_launch.hip"
 #include "merge_launch_impl.hpp"
 namespace caskhip {
 template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
@@ -93,6 +95,13 @@ struct Plan {
   DevBuf<double> farx;
   // VECTOR
   DevBuf<int2v> xspan;
+  // SCAN (scan_kernel.hpp): per-thread row-end words, the row map of blocks that span empty rows, and -- far plans --
+  // the plan's own column stream with far references, the far columns panel-major and the buffer they are gathered into
+  DevBuf<unsigned> scan_meta;
+  DevBuf<int> scan_rowmap, scan_ci, scan_fcol;
+  DevBuf<double> scan_farx;
+  DevBuf<int> scan_sync, scan_needs;   // fused far pre-gather: producer flags + block epochs; producers each block waits for
+  ScanFar scan_far{};
 };
 
 // Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
@@ -149,7 +158,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
         out.wg_size == 1024))
     return fail(CASK_HIP_ERR_INVALID, "wg_size must be 64, 128, 256, 512 or 1024");
   if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE &&
-      out.variant != CASK_HIP_VARIANT_MERGE_WAVE)
+      out.variant != CASK_HIP_VARIANT_MERGE_WAVE && out.variant != CASK_HIP_VARIANT_SCAN)
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
   if (m.halo_addr && out.variant != CASK_HIP_VARIANT_MERGE)
     return fail(CASK_HIP_ERR_INVALID, "a matrix with halo sources runs the MERGE variant only");
@@ -172,7 +181,7 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
   if (out.far_columns < -1 || out.far_columns > 2) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0, 1 or 2");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
-  if (out.variant == CASK_HIP_VARIANT_MERGE) {
+  if (out.variant == CASK_HIP_VARIANT_MERGE || out.variant == CASK_HIP_VARIANT_SCAN) {
     const long cap = (long)out.wg_size * out.items_per_thread;
     if (8 * (cap + 2) + 8 * out.wg_size > MAX_LDS_BYTES)
       return fail(CASK_HIP_ERR_INVALID, "wg_size*items_per_thread needs more than 64 KiB of LDS");
@@ -184,14 +193,16 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
 // most `cap` items (and at most `max_rows` rows), snapped to row boundaries;
 // rows longer than cap/2 become long-row pieces of at most `piece` nonzeros.
 // Long pieces go to `longs` when it is given (pipelined plan), else inline.
+// `rows_are_items` = false (SCAN plans): only nonzeros count against `cap`, and a block that spans empty rows is
+// flagged KIND_HOLES.
 void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long piece, int threads,
                         std::vector<BlockDesc> &blocks, std::vector<BlockDesc> *longs,
-                        std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots) {
+                        std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots, bool rows_are_items = true) {
   const int *rp = m.h_rp.data();
   const int long_t = cap / 2;
   n_long = 0;
   n_partial_slots = 0;
-  int cur_start = 0, cur_rows = 0, cur_nnz = 0, cur_max = 0;
+  int cur_start = 0, cur_rows = 0, cur_nnz = 0, cur_max = 0, cur_empty = 0;
   auto close = [&](int next_row) {
     if (cur_rows == 0) return;
     BlockDesc d{};
@@ -216,11 +227,13 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
       d.aux = 0;
       (longs ? *longs : blocks).push_back(d);
     } else {
+      if (!rows_are_items) d.kind_g = cur_empty ? KIND_HOLES : 0;
       blocks.push_back(d);
     }
     cur_rows = 0;
     cur_nnz = 0;
     cur_max = 0;
+    cur_empty = 0;
     cur_start = next_row;
   };
   for (int r = 0; r < m.n_rows; r++) {
@@ -243,10 +256,11 @@ void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long pi
       cur_start = r + 1;
       continue;
     }
-    if (cur_rows > 0 && (cur_rows + 1 + cur_nnz + len > cap || cur_rows + 1 > max_rows)) close(r);
+    if (cur_rows > 0 && ((rows_are_items ? cur_rows + 1 : 0) + cur_nnz + len > cap || cur_rows + 1 > max_rows)) close(r);
     if (cur_rows == 0) cur_start = r;
     cur_rows++;
     cur_nnz += len;
+    cur_empty += len == 0;
     cur_max = std::max(cur_max, len);
   }
   close(m.n_rows);
@@ -484,6 +498,226 @@ const void *merge_wave_fn(int ipt, bool nt) {
   }
 }
 
+// SCAN plan (scan_kernel.hpp): blocks of at most cap nonzeros snapped to rows; one word per thread with the row
+// ends of its run; far nonzeros (tile_width = near margin) through the column-panel pre-gather.
+int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
+  Plan &pl = m.plan;
+  const int wg = prm.wg_size, ipt = prm.items_per_thread, cap = wg * ipt;
+  const int *rp = m.h_rp.data();
+  std::vector<BlockDesc> blocks;
+  std::vector<SplitRow> splits;
+  int n_long = 0, n_slots = 0;
+  // cap - 1 nonzeros per block: a block that starts on an odd nonzero streams one foreign element in front of its own
+  // (16-byte loads), and the workgroup loads exactly cap elements
+  build_merge_blocks(m, cap - 1, 1 << 30, (long)cap * LONG_PIECE_FACTOR, wg, blocks, nullptr, splits, n_long, n_slots, false);
+  pl.n_long_rows = n_long;
+  pl.n_split_rows = (int)splits.size();
+  pl.grid = pl.n_blocks = (int)blocks.size();
+  std::vector<unsigned> meta((size_t)blocks.size() * wg, 0u);
+  std::vector<int> rowmap;
+  std::vector<int> ends((size_t)wg);
+  for (size_t b = 0; b < blocks.size(); b++) {
+    BlockDesc &d = blocks[b];
+    d.cmin = d.cwidth = 0;
+    if (d.kind_g & KIND_LONG) continue;
+    unsigned *mw = meta.data() + b * (size_t)wg;
+    std::fill(ends.begin(), ends.end(), 0);
+    const bool holes = (d.kind_g & KIND_HOLES) != 0;
+    if (holes) {
+      d.aux = (int)rowmap.size();
+      rowmap.push_back(0);                                    // [number of non-empty rows, their local rows ...]
+    }
+    for (int r = 0; r < d.n_rows; r++) {
+      const int row = d.row_start + r;
+      if (rp[row + 1] == rp[row]) continue;
+      const int e = rp[row + 1] - 1 - d.nnz_start;            // the row's last nonzero, block-relative
+      mw[e / ipt] |= 1u << (e % ipt);
+      ends[e / ipt]++;
+      if (holes) {
+        rowmap.push_back(r);
+        rowmap[(size_t)d.aux]++;
+      }
+    }
+    int ord = 0;
+    for (int t = 0; t < wg; t++) {
+      mw[t] |= (unsigned)ord << 16;
+      ord += ends[t];
+    }
+  }
+  HIP_TRY(pl.scan_meta.upload(meta));
+  rowmap.push_back(0);                                        // never empty: the kernel forms rowmap + aux
+  HIP_TRY(pl.scan_rowmap.upload(rowmap));
+  if (!splits.empty()) {
+    HIP_TRY(pl.split_rows.upload(splits));
+    HIP_TRY(pl.partials.alloc(n_slots));
+  }
+  pl.prm.lanes_per_row = 0;
+  pl.prm.index16 = -1;
+  pl.prm.far_columns = -1;
+  pl.prm.tile_width = -1;
+  pl.xu = 0;
+  const int base_lds = 8 * (cap + wg + 4) + 24 * 8;
+  const int nb = (int)blocks.size();
+  // ---- x window (tile_width) and far nonzeros (far_columns) ----------------------------------------------------
+  // Window: per block the contiguous column range of at most W entries that covers most of its nonzeros, staged
+  // in LDS; a nonzero inside it streams an LDS slot instead of a column (the plan's own column stream).
+  // Far: a nonzero outside its block's window whose column also lies outside the rows its XCD walks (XCD j runs
+  // the logical blocks [j*q + min(j, rem), ...): one contiguous run of rows, whose x entries its L2 keeps through
+  // the window loads) -- served through the column-panel pre-gather.
+  int want_w = prm.tile_width > 0 ? prm.tile_width : 0;
+  int xp = 0;
+  if (want_w > 0 && m.nnz > 0 && m.n_cols < SCAN_LDS_BIT) {
+    xp = 2;
+    while (xp < 8 && 2 * xp * wg < want_w) xp *= 2;
+    while (xp >= 2 && (base_lds + 16 * xp * wg > MAX_LDS_BYTES || 2 * xp * wg > 65536)) xp /= 2;
+    if (xp < 2) xp = 0;
+  }
+  const int W = 2 * xp * wg;
+  // far_columns: 1 = pre-gather as its own launch, 2 = by producer workgroups of the product launch; 0 / -1 = off --
+  // measured on the webbase-like matrix (profiles/r03_webbase_anatomy.txt) both cut the product kernel's time and
+  // the fabric traffic, and both cost more than they save (the producers' two dependent round trips)
+  const bool want_far = prm.far_columns >= 1 && nb >= 8 && prm.xcd_remap > 0 && m.nnz > 0 && m.n_cols < SCAN_LDS_BIT;
+  if (xp > 0 || want_far) {
+    int rc = ensure_host_col_ind(m);
+    if (rc) return rc;
+    const int *ci = m.h_ci.data();
+    std::vector<int> sci(m.h_ci);
+    sci.push_back(0);                                         // the kernel's last 8-byte pair of an odd nnz
+    long in_window = 0;
+    if (xp > 0) {
+      std::vector<long> covered(nb, 0);
+      auto work = [&](int b0, int b1) {
+        std::vector<int> cols;
+        for (int b = b0; b < b1; b++) {
+          BlockDesc &d = blocks[b];
+          if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
+          cols.assign(ci + d.nnz_start, ci + d.nnz_start + d.nnz_count);
+          std::sort(cols.begin(), cols.end());
+          // densest range [s, s + W) with s even: two pointers over the sorted columns
+          size_t best_i = 0, best_n = 0, j = 0;
+          for (size_t i = 0; i < cols.size(); i++) {
+            const int s0 = cols[i] & ~1;
+            while (j < cols.size() && cols[j] < s0 + W) j++;
+            if (j - i > best_n) { best_n = j - i; best_i = i; }
+          }
+          if (best_n * 4 < cols.size()) continue;             // a window that serves under a quarter is not worth its loads
+          const int s0 = cols[best_i] & ~1, last_col = cols[best_i + best_n - 1];
+          d.cmin = s0;
+          d.cwidth = ((last_col - s0 + 2) & ~1);               // even, <= W
+          for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++)
+            if (ci[k] >= s0 && ci[k] < s0 + d.cwidth) sci[(size_t)k] = SCAN_LDS_BIT | (ci[k] - s0);
+          covered[b] = (long)best_n;
+        }
+      };
+      size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+      n_threads = std::min<size_t>(n_threads, std::max(nb, 1));
+      if (n_threads <= 1) {
+        work(0, nb);
+      } else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, (int)(nb * t / n_threads), (int)(nb * (t + 1) / n_threads));
+        for (auto &th : pool) th.join();
+      }
+      for (long c : covered) in_window += c;
+      if (in_window == 0) xp = 0;
+    }
+    int64_t n_far = 0;
+    std::vector<int> fcol;
+    if (want_far) {
+      const int panel_width = std::max(1, (m.n_cols + SCAN_PANELS - 1) / SCAN_PANELS);
+      const int q = nb >> 3, rem = nb & 7;
+      std::vector<int> lo(nb), hi(nb);                        // rows (= x entries) of every block's XCD
+      for (int j = 0; j < 8; j++) {
+        const int b0 = j * q + std::min(j, rem), b1 = b0 + q + (j < rem ? 1 : 0);
+        if (b0 >= b1) continue;
+        const int r0 = blocks[b0].row_start, r1 = blocks[b1 - 1].row_start + blocks[b1 - 1].n_rows;
+        for (int b = b0; b < b1; b++) { lo[b] = r0; hi[b] = r1; }
+      }
+      auto is_far = [&](int b, int64_t k) { return !(sci[(size_t)k] & SCAN_LDS_BIT) && (ci[k] < lo[b] || ci[k] >= hi[b]); };
+      // count per panel, then place: inside a panel in (block, nonzero) order
+      std::vector<int64_t> count(SCAN_PANELS + 1, 0);
+      for (int b = 0; b < nb; b++) {
+        const BlockDesc &d = blocks[b];
+        for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
+          if (is_far(b, k)) count[ci[k] / panel_width + 1]++;
+      }
+      // every panel's share of farx starts on a 128-byte line (16 entries): a chunk of a panel is then whole lines, so
+      // a line of farx is written by ONE producer -- a consumer that reads it after that producer's flag can never
+      // pull a half-written line into its L2 (fused pre-gather, scan_kernel.hpp)
+      int64_t n_real = 0;
+      for (int p = 0; p < SCAN_PANELS; p++) {
+        n_real += count[p + 1];
+        count[p + 1] = count[p] + ((count[p + 1] + 15) & ~(int64_t)15);
+      }
+      n_far = n_real ? count[SCAN_PANELS] : 0;
+      if (n_far > 0 && n_far < ((int64_t)1 << 30)) {
+        fcol.assign((size_t)n_far, 0);                        // (padding entries gather x[0])
+        std::vector<int64_t> fill(count.begin(), count.end() - 1);
+        for (int b = 0; b < nb; b++) {
+          const BlockDesc &d = blocks[b];
+          for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
+            if (is_far(b, k)) {
+              const int64_t at = fill[ci[k] / panel_width]++;
+              fcol[(size_t)at] = ci[k];
+              sci[(size_t)k] = ~(int)at;
+              blocks[b].kind_g |= KIND_FAR;                   // (long-row pieces test every reference themselves)
+            }
+        }
+        HIP_TRY(pl.scan_fcol.upload(fcol));
+        HIP_TRY(pl.scan_farx.alloc((size_t)n_far));
+        int per_panel = 0;
+        const int chunk = scan_far_chunk(wg);
+        for (int p = 0; p <= SCAN_PANELS; p++) pl.scan_far.panels.start[p] = (int)count[p];
+        for (int p = 0; p < SCAN_PANELS; p++) per_panel = std::max(per_panel, (int)((count[p + 1] - count[p] + chunk - 1) / chunk));
+        pl.scan_far.fcol = pl.scan_fcol.p;
+        pl.scan_far.n_far = (int)n_far;
+        pl.scan_far.grid = per_panel * SCAN_PANELS;
+        pl.prm.far_columns = prm.far_columns;
+        if (pl.prm.far_columns == 2) {
+          // the producers (hardware block ids: chunk index * 8 + panel) whose chunks hold a block's far entries
+          std::vector<int> needs((size_t)nb * SCAN_NEEDS, -1), mine;
+          for (int b = 0; b < nb; b++) {
+            BlockDesc &d = blocks[b];
+            if (!(d.kind_g & KIND_FAR)) continue;
+            mine.clear();
+            for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
+              if (sci[(size_t)k] < 0) {
+                const int at = ~sci[(size_t)k], p = ci[k] / panel_width;
+                const int h = (int)((at - count[p]) / chunk) * SCAN_PANELS + p;
+                if (std::find(mine.begin(), mine.end(), h) == mine.end()) mine.push_back(h);
+              }
+            if ((int)mine.size() > SCAN_NEEDS) {              // too scattered to wait for: this block gathers directly
+              for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
+                if (sci[(size_t)k] < 0) sci[(size_t)k] = ci[k];
+              d.kind_g &= ~KIND_FAR;
+              continue;
+            }
+            std::copy(mine.begin(), mine.end(), needs.begin() + (size_t)b * SCAN_NEEDS);
+          }
+          HIP_TRY(pl.scan_needs.upload(needs));
+          HIP_TRY(pl.scan_sync.alloc((size_t)pl.scan_far.grid + (size_t)nb));
+          HIP_TRY(hipMemset(pl.scan_sync.p, 0, ((size_t)pl.scan_far.grid + (size_t)nb) * sizeof(int)));
+        }
+        pl.n_far = (int)n_far;
+      } else {
+        n_far = 0;
+      }
+    }
+    if (xp > 0 || n_far > 0) HIP_TRY(pl.scan_ci.upload(sci));
+    if (xp > 0) {
+      pl.prm.tile_width = W;
+      pl.xu = xp;
+    } else {
+      for (BlockDesc &d : blocks)
+        if (!(d.kind_g & KIND_LONG)) d.cmin = d.cwidth = 0;
+    }
+  }
+  HIP_TRY(pl.blocks.upload(blocks));
+  pl.lds_bytes = base_lds + 16 * pl.xu * wg;
+  pl.ldsx = pl.xu > 0;
+  return CASK_HIP_OK;
+}
+
 int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   cask_hip_params prm;
   int rc = resolve_params(m, requested, prm);
@@ -509,6 +743,14 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.far_dst.release();
   pl.far_col_block.release();
   pl.farx.release();
+  pl.scan_meta.release();
+  pl.scan_rowmap.release();
+  pl.scan_ci.release();
+  pl.scan_fcol.release();
+  pl.scan_farx.release();
+  pl.scan_sync.release();
+  pl.scan_needs.release();
+  pl.scan_far = ScanFar{};
   pl.grid = 0;
   pl.lds_bytes = 0;
   pl.ldsx = false;
@@ -545,6 +787,9 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     pl.grid = std::max(1, std::min(want, occ * cus));
     if (pl.n_blocks == 0) pl.grid = 0;
     pl.ldsx = false;
+  } else if (prm.variant == CASK_HIP_VARIANT_SCAN) {
+    int rc2 = build_scan_plan(m, prm);
+    if (rc2) return rc2;
   } else if (prm.variant == CASK_HIP_VARIANT_MERGE) {
     const int cap = prm.wg_size * prm.items_per_thread;
     std::vector<BlockDesc> blocks;
@@ -855,6 +1100,33 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
       case 8:  launch_merge_wave_i<8>(m, x, y, s); break;
       default: launch_merge_wave_i<16>(m, x, y, s); break;
     }
+    HIP_TRY(hipGetLastError());
+    return CASK_HIP_OK;
+  }
+  if (pl.prm.variant == CASK_HIP_VARIANT_SCAN) {
+    ScanLaunch l{};
+    l.grid = pl.grid;
+    l.wg_size = pl.prm.wg_size;
+    l.lds_bytes = pl.lds_bytes;
+    l.remap = pl.prm.xcd_remap > 0;
+    l.nnz = (int)m.nnz;
+    l.n_cols = m.n_cols;
+    l.xp = pl.xu;
+    l.nontemporal = pl.prm.nontemporal > 0;
+    l.blocks = pl.blocks.p;
+    l.rp = m.d_rp;
+    l.ci = pl.scan_ci.p ? pl.scan_ci.p : m.d_ci;
+    l.val = m.d_val;
+    l.meta = pl.scan_meta.p;
+    l.rowmap = pl.scan_rowmap.p;
+    l.farx = pl.scan_farx.p;
+    l.sync = pl.scan_sync.p;
+    l.needs = pl.scan_needs.p;
+    l.partials = pl.partials.p;
+    launch_scan(l, pl.scan_far, pl.prm.items_per_thread, x, y, s);
+    if (pl.n_split_rows > 0)
+      hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
+                         pl.n_split_rows, pl.partials.p, y, DotEpilogue{nullptr, nullptr}, (const int *)nullptr);
     HIP_TRY(hipGetLastError());
     return CASK_HIP_OK;
   }
@@ -1326,12 +1598,13 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                   int32_t n_wg_sizes, const int32_t *items, int32_t n_items, int32_t warmup, int32_t iters,
                   cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
-  static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE};
+  static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE,
+                                         CASK_HIP_VARIANT_SCAN};
   static const int32_t def_lanes[] = {4, 8, 16, 32};
   static const int32_t def_tiles[] = {-1, 1024, 4096};
   static const int32_t def_wg[] = {256, 512};
   static const int32_t def_items[] = {4, 8};
-  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 3; }
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 4; }
   if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 4; }
   if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 3; }
   if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 2; }
@@ -1404,7 +1677,9 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
         for (int il = 0; il < n_lanes; il++)
           for (int iva = 0; iva < n_variants; iva++) {
             const int variant = variants[iva];
-            const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE;
+            // SCAN: items per thread like the merge kernels; its tile axis is the near margin of the far pre-gather
+            const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE ||
+                                  variant == CASK_HIP_VARIANT_SCAN;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
             if (is_merge && il != 0) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel

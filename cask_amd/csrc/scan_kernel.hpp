@@ -1,0 +1,417 @@
+// The segmented-scan kernel (variant SCAN): thread-owned runs of products + a segmented scan of the carries.
+//
+// Built for matrices whose rows are short and uneven (webbase-1M: mean 3 nonzeros, longest 4 700), where the
+// merge kernel's row phase -- lanes mapped to ROWS -- leaves most lanes idle behind the few that walk a long
+// row, needs the row offsets of ~700 rows per block in LDS, and keeps a workgroup alive for 10 us
+// (profiles/r02_webbase_anatomy.txt).  Here work is mapped to NONZEROS throughout:
+//
+//   * a block is a run of at most CAP = wg_size * items_per_thread nonzeros snapped to row boundaries (row ends
+//     are not items, so a block of 1-nonzero rows still carries CAP nonzeros);
+//   * phase 1 is the merge kernel's: the value / column streams in nonzero order with 16-byte loads, x gathered
+//     from L2, products parked in LDS (the transpose from the striped load order to thread-owned runs);
+//   * phase 2: thread t owns products [t*IPT, (t+1)*IPT).  One 32-bit word per thread, made by the planner, says
+//     which of them end a row (bits 0-15) and the ordinal of the thread's first row end among the block's
+//     non-empty rows (bits 16-31).  The thread adds its run in order and stores every row that ends AND starts
+//     inside the run directly; the sum in front of its first row end ("head") needs what earlier threads left
+//     ("carry"), the sum behind its last one ("tail") is what it leaves;
+//   * carries: a segmented inclusive scan of (has a row end, tail) over the workgroup -- six shuffle steps per
+//     wave, the wave aggregates through LDS.  A row of 500 nonzeros is 62 threads' tails joined by the scan in
+//     log steps: no second pass, no lanes-per-row choice, no skew flag.
+//
+// row_ptr is not read at all (4 bytes per row less than the CSR stream; the per-thread words are 0.5 byte per
+// nonzero at 8 items per thread), and the block needs (CAP + 2) * 8 bytes of LDS -- 16 KB at 256 x 8 -- so eight
+// workgroups fit a CU and the whole grid of a 3 M-nonzero matrix is resident at once.
+//
+// Every floating-point addition's operands are a function of the plan alone: results are bitwise reproducible.
+// The order differs from the merge kernel's (and from the sequential oracle's), like every parallel row sum here.
+//
+// Empty rows: a block that spans empty rows (KIND_HOLES) maps row-end ordinals to rows through `rowmap` and
+// zero-fills its empty rows from row_ptr; runs of empty rows between blocks are zero-fill pieces (as in the merge
+// plan).  Rows longer than CAP/2 are long-row pieces summed by the whole workgroup (+ the fix-up kernel when a row
+// has several).
+//
+// Far columns (FARX instantiation): the plan keeps its own column stream in which a far nonzero -- one whose column
+// lies outside the part of x its XCD keeps in L2 -- carries ~index into `farx` instead of a column; k_far_panels
+// fills farx column panel by column panel just before this launch (see below).
+//
+// Reference: the always-streaming multiply / reduce pipeline of src/spmv/src/SpmvKernel.java:18-309 and the
+// row-length driven read control of ParallelCsrReadControl.java:148-208 -- whose per-cycle "this entry ends a row"
+// control word is the same idea as the per-thread row-end word here.
+#pragma once
+#include "scan_launch.hpp"
+
+namespace caskhip {
+
+// ---- fused far pre-gather (FARX == 2): producer workgroups and the hand-off ----------------------------------
+// The far values a product block needs come from workgroups of the SAME launch (the first far.grid ones: dispatched
+// first, one chunk of one column panel each).  No global barrier and no atomics -- a counter every workgroup adds to
+// or polls serialises at the memory side (a first version with one "producers done" counter ran 127 us):
+//   * every producer h owns a word flag[h], every product block b a word epoch[b]; all start at 0 and every launch
+//     of the plan adds exactly 1 to each (launches of one plan are sequential: stream order), so in launch number E
+//     a block waits for flag[h] == E of the producers whose chunks hold its far entries -- inside a panel a block's
+//     far entries are one contiguous run, so that is one or two chunks per panel, at most SCAN_NEEDS words, each
+//     polled by its own lane of wave 0;
+//   * producer: chunk of farx stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup
+//     barrier, one lane stores flag[h] = E (sc1).  Consumer: sc1 polls, workgroup barrier, then plain loads of
+//     farx.  Plain loads are enough because a chunk is whole 128-byte lines (the planner aligns every panel's share
+//     of farx to a line and a chunk is a multiple of 16 entries): a line is written by one producer, nobody reads
+//     any part of it before that producer's flag says E, so neither an L1 nor an L2 can hold it from earlier in
+//     this launch -- and lines of the previous launch went with the kernel boundary.  (MI355X_MICROARCH "Workgroup
+//     dispatch, XCD placement & inter-workgroup visibility": the stale-line hazard is an L1/L2-resident line that
+//     another CU has since rewritten; here no such line can exist.)
+//   * the poll is bounded: a block that gives up (HIP promises no dispatch order: producers might not be resident
+//     while consumers hold every slot) gathers its far values from x itself through the far column list -- that
+//     costs time, never correctness.
+constexpr int SCAN_POLL_LIMIT = 1 << 12;
+struct ScanSync {
+  int *flag;                            // [far.grid]
+  int *epoch;                           // [n_blocks]
+  const int *needs;                     // [n_blocks][SCAN_NEEDS] producer ids, -1 = none
+};
+__device__ __forceinline__ bool scan_wait_far(const ScanSync &sy, int lb, int *lds_word) {
+  if (threadIdx.x < 64) {                                     // wave 0 polls, the others wait at the barrier
+    const int lane = threadIdx.x;
+    const int need = lane < SCAN_NEEDS ? sy.needs[(size_t)lb * SCAN_NEEDS + lane] : -1;
+    int e = 0;
+    if (lane == 0) {
+      e = sy.epoch[lb] + 1;                                   // this launch's number (own word: written by this block only)
+      sy.epoch[lb] = e;
+    }
+    e = __builtin_amdgcn_readfirstlane(e);
+    bool ok = need < 0;
+    int spins = 0;
+    while (true) {
+      if (!ok) ok = __hip_atomic_load(sy.flag + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - e >= 0;
+      if (__ballot(!ok) == 0 || ++spins >= SCAN_POLL_LIMIT) break;
+      __builtin_amdgcn_s_sleep(40);                           // ~1 us: pollers share the fabric with the streams
+    }
+    const bool all_in = __ballot(!ok) == 0;
+    if (lane == 0) *lds_word = all_in;
+  }
+  __syncthreads();
+  return *lds_word != 0;
+}
+__device__ __forceinline__ double far_value(const double *farx, const int *fcol, const double *x, int idx, bool ready) {
+  if (ready) return farx[idx];                                // plain: see "whole lines" above
+  return x[fcol[idx]];
+}
+
+// One piece of one long row (or a run of empty rows): the whole workgroup strides over it.
+template <bool NT, int FARX>
+__device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *__restrict__ ci,
+                                                const double *__restrict__ val, const double *__restrict__ x,
+                                                const double *__restrict__ farx, double *__restrict__ y,
+                                                double *__restrict__ partials, double *red, const int *fcol,
+                                                const ScanSync &sy, int lb) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  if (d.nnz_count == 0) {                                     // a run of empty rows
+    for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = 0.0;
+    return;
+  }
+  bool ready = true;
+  if (FARX == 2 && (d.kind_g & KIND_FAR)) {                   // workgroup-uniform
+    ready = scan_wait_far(sy, lb, reinterpret_cast<int *>(red + 20));
+    __syncthreads();
+  }
+  const int end = d.nnz_start + d.nnz_count;
+  double acc = 0.0;
+  for (int k = d.nnz_start + tid; k < end; k += 4 * WG) {
+    int c[4];
+    double v[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int kk = min(k + u * WG, end - 1);
+      c[u] = stream_load<NT>(ci + kk);
+      v[u] = stream_load<NT>(val + kk);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      xv[u] = (FARX && c[u] < 0) ? (FARX == 2 ? far_value(farx, fcol, x, ~c[u], ready) : farx[~c[u]]) : x[c[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k + u * WG < end) acc = fma(v[u], xv[u], acc);
+  }
+  acc = group_sum<64>(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (WG >> 6); w++) s += red[w];
+    if (d.kind_g & KIND_PARTIAL) partials[d.aux] = s;
+    else y[d.row_start] = s;
+  }
+}
+
+// Column references of the plan's own column stream (plans with an x window and/or far nonzeros; otherwise the
+// caller's col_ind is streamed as it is):  c >= 0 without SCAN_LDS_BIT: x[c];  with it: slot c & 0xffff of the block's
+// x window in LDS;  c < 0: farx[~c].
+template <int IPT, bool NT, int FARX, int XP>
+__device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__restrict__ blocks, int n_blocks, int remap,
+                                           int nnz, int n_cols, const int *__restrict__ rp, const int *__restrict__ ci,
+                                           const double *__restrict__ val, const unsigned *__restrict__ meta,
+                                           const int *__restrict__ rowmap, const double *__restrict__ x,
+                                           const double *__restrict__ farx, double *__restrict__ y,
+                                           double *__restrict__ partials, const int *__restrict__ fcol,
+                                           const ScanSync &sy) {
+  static_assert(IPT % 2 == 0 && IPT <= 16, "items per thread: even (16-byte loads), at most 16 (row-end bits)");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
+  double *prod = reinterpret_cast<double *>(smem);            // CAP + WG + 4 doubles (padded runs, see below)
+  double *wval = prod + CAP + WG + 4;                              // 16 wave aggregates: value ...
+  int *wflag = reinterpret_cast<int *>(wval + 16);            // ... and "holds a row end"
+  double *xs = wval + 24;                                     // XP > 0: the block's x window, 2 * XP * WG doubles
+
+  CASK_STAMP(0);
+  const int lb = logical_block(hw_block, n_blocks, remap);
+  const BlockDesc d = blocks[lb];
+  if (d.kind_g & KIND_LONG) {
+    scan_long_piece<NT, FARX>(d, ci, val, x, farx, y, partials, prod, fcol, sy, lb);
+    return;
+  }
+
+  // ---- phase 1: streams -> products in LDS (element base + i of the arrays lands in prod[i]) ----------------
+  // 16-byte loads need an even element index: start one element early if the block starts on an odd nonzero
+  const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;
+  const int npairs = (total + 1) >> 1, first = base >> 1;
+  const int last = min(first + max(npairs - 1, 0), ((nnz + 1) >> 1) - 1);
+  // the x window [cmin, cmin + cwidth) (cmin even) goes out first: vmcnt retires in order, so parking it in LDS
+  // waits for these loads only while the streams behind them are still in flight (merge_kernel.hpp, issue order)
+  dbl2 xw[XP > 0 ? XP : 1];
+  if (XP > 0) {
+    const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x);
+    const int p0 = d.cmin >> 1, plim = (n_cols - 1) >> 1;     // the last pair may reach one element past an odd n_cols:
+#pragma unroll                                                //   x is 16-byte aligned, the load cannot cross a page
+    for (int u = 0; u < XP; u++)
+      if ((u * WG + tid) * 2 < d.cwidth) xw[u] = x2[min(p0 + u * WG + tid, plim)];
+  }
+  const unsigned mw = stream_load<NT>(meta + (size_t)lb * WG + tid);
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  dbl2 v[IPT / 2];
+  int2v c[IPT / 2];
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
+    v[u] = stream_load<NT>(val2 + p);
+    c[u] = stream_load<NT>(ci2 + p);
+  }
+  CASK_STAMP(1);
+  if (XP > 0) {
+    dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
+#pragma unroll
+    for (int u = 0; u < XP; u++)
+      if ((u * WG + tid) * 2 < d.cwidth) xs2[u * WG + tid] = xw[u];
+    __syncthreads();
+  }
+  // foreign elements (the lead element of an odd start; the second half of the last pair of an odd total, which
+  // for the very last nonzero of an odd-nnz matrix is the 8 bytes behind the arrays): give them a column this
+  // block owns; their products land in slots no thread's run covers
+  if (lead && tid == 0) c[0].x = c[0].y;
+  if (total & 1) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++)
+      if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+  }
+  dbl2 xv[IPT / 2];
+  if (XP > 0 || FARX) {
+    // global sources first (all of a lane's loads go out back to back), then the window slots from LDS
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      const int cx = c[u].x, cy = c[u].y;
+      xv[u].x = 0.0;
+      xv[u].y = 0.0;
+      if (FARX == 2) {                                        // far values come later, behind the hand-off
+        if (cx >= 0 && (!(XP > 0) || !(cx & SCAN_LDS_BIT))) xv[u].x = x[cx];
+        if (cy >= 0 && (!(XP > 0) || !(cy & SCAN_LDS_BIT))) xv[u].y = x[cy];
+      } else {
+        const double *px = (FARX && cx < 0) ? farx + ~cx : x + cx;
+        const double *py = (FARX && cy < 0) ? farx + ~cy : x + cy;
+        if (!(XP > 0) || cx < 0 || !(cx & SCAN_LDS_BIT)) xv[u].x = *px;
+        if (!(XP > 0) || cy < 0 || !(cy & SCAN_LDS_BIT)) xv[u].y = *py;
+      }
+    }
+    if (FARX == 2 && (d.kind_g & KIND_FAR)) {                 // workgroup-uniform
+      const bool ready = scan_wait_far(sy, lb, wflag + 15);
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++) {
+        if (c[u].x < 0) xv[u].x = far_value(farx, fcol, x, ~c[u].x, ready);
+        if (c[u].y < 0) xv[u].y = far_value(farx, fcol, x, ~c[u].y, ready);
+      }
+    }
+    if (XP > 0) {
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++) {
+        const int cx = c[u].x, cy = c[u].y;
+        if (cx >= 0 && (cx & SCAN_LDS_BIT)) xv[u].x = xs[cx & 0xffff];
+        if (cy >= 0 && (cy & SCAN_LDS_BIT)) xv[u].y = xs[cy & 0xffff];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = x[c[u].x];
+      xv[u].y = x[c[u].y];
+    }
+  }
+#ifdef CASK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CASK_STAMP(2);
+#endif
+  // Products -> LDS, one pad double in front of every thread-owned run of IPT: element e (relative to `base`) sits in
+  // slot e + (e + IPT - lead) / IPT, so that thread t's run starts at lead + 1 + (IPT + 1) t -- the runs of a wave's
+  // lanes then start on different banks (stride 9 doubles at IPT = 8: no two lanes of a half-wave share a bank pair)
+  // and the phase-2 reads cost 2 cycles each instead of 16.
+  constexpr int SH = IPT == 2 ? 1 : IPT == 4 ? 2 : IPT == 8 ? 3 : 4;
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int e = 2 * (u * WG + tid);
+    const dbl2 pr = v[u] * xv[u];
+    prod[e + ((e + IPT - lead) >> SH)] = pr.x;
+    prod[e + 1 + ((e + 1 + IPT - lead) >> SH)] = pr.y;
+  }
+  __syncthreads();
+  CASK_STAMP(3);
+
+  // ---- phase 2: thread-owned runs ---------------------------------------------------------------------------
+  const unsigned flags = mw & 0xffffu;
+  const int ord = (int)(mw >> 16);
+  const int k0 = tid * IPT;
+  const bool holes = (d.kind_g & KIND_HOLES) != 0;            // workgroup-uniform
+  const int *rmap = rowmap + d.aux;                           // holes: [number of non-empty rows, their local rows ...]
+  double p[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; j++) p[j] = prod[lead + 1 + (IPT + 1) * tid + j];
+#pragma unroll
+  for (int j = 0; j < IPT; j++)
+    if (k0 + j >= d.nnz_count) p[j] = 0.0;                    // behind the block's last nonzero
+  __syncthreads();                                            // every run is in registers: the product area is free
+  // row sums go to rsum[ordinal] (the product area again) and leave for y in one coalesced sweep at the end:
+  // stored from here, lane by lane, a block's ~700 row sums were ~90 partly filled store instructions per wave
+  // (3.8 of the launch's 27 us on the webbase-like matrix)
+  double *rsum = prod;
+  double acc = 0.0, head = 0.0;
+  int i = 0;
+#pragma unroll
+  for (int j = 0; j < IPT; j++) {
+    acc += p[j];
+    if ((flags >> j) & 1u) {
+      if (i == 0) head = acc;                                 // completes a row earlier threads may have begun
+      else rsum[ord + i] = acc;
+      i++;
+      acc = 0.0;
+    }
+  }
+  // segmented inclusive scan over the wave, (f, s) = (a row ends in lanes [.., lane], sum of the tails since), all
+  // in DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source read the identity: bound_ctrl),
+  // then lane 15 of each row to the next row (row_bcast15, rows 1 and 3) and lane 31 to the upper half (row_bcast31)
+  const int lane = tid & 63, wave = tid >> 6;
+  int f = flags != 0;
+  double s = acc;
+#define CASK_SCAN_STEP(CTRL, ROWMASK)                                                                     \
+  do {                                                                                                    \
+    int lo = __double2loint(s), hi = __double2hiint(s);                                                   \
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);                                    \
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);                                    \
+    const int f2 = __builtin_amdgcn_update_dpp(0, f, CTRL, ROWMASK, 0xf, true);                           \
+    const double s2 = __hiloint2double(hi, lo);                                                           \
+    if (!f) s += s2;                                                                                      \
+    f |= f2;                                                                                              \
+  } while (0)
+  CASK_SCAN_STEP(0x111, 0xf);                                 // row_shr:1
+  CASK_SCAN_STEP(0x112, 0xf);                                 // row_shr:2
+  CASK_SCAN_STEP(0x114, 0xf);                                 // row_shr:4
+  CASK_SCAN_STEP(0x118, 0xf);                                 // row_shr:8
+  CASK_SCAN_STEP(0x142, 0xa);                                 // row_bcast15 -> rows 1, 3
+  CASK_SCAN_STEP(0x143, 0xc);                                 // row_bcast31 -> rows 2, 3
+#undef CASK_SCAN_STEP
+  if (lane == 63) {
+    wval[wave] = s;
+    wflag[wave] = f;
+  }
+  // what the lanes in front of this one leave (exclusive): lane - 1's inclusive pair (wave_shr:1; lane 0: identity)
+  const double es = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s), 0x138, 0xf, 0xf, true),
+                                     __builtin_amdgcn_update_dpp(0, __double2loint(s), 0x138, 0xf, 0xf, true));
+  const int ef = __builtin_amdgcn_update_dpp(0, f, 0x138, 0xf, 0xf, true);
+  __syncthreads();
+  if (flags) {                                                // this thread closes a row begun before its run
+    double carry = 0.0;                                       // what the waves in front leave
+    for (int w = 0; w < wave; w++) carry = wflag[w] ? wval[w] : carry + wval[w];
+    rsum[ord] = (ef ? es : carry + es) + head;
+  }
+  __syncthreads();
+  if (holes) {
+    const int n_ends = rmap[0];
+    for (int r = tid; r < n_ends; r += WG) y[d.row_start + rmap[1 + r]] = rsum[r];
+    for (int r = tid; r < d.n_rows; r += WG)                  // the block's empty rows (every y entry is written once)
+      if (rp[d.row_start + r] == rp[d.row_start + r + 1]) y[d.row_start + r] = 0.0;
+  } else {
+    for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = rsum[r];
+  }
+  CASK_STAMP(4);
+}
+
+// farx[k] = x[fcol[k]] for one chunk of U * blockDim.x far entries of one column panel (panel = chunk index mod 8:
+// hardware deals workgroups round-robin over the XCDs, so one XCD's L2 sees one panel of x).  SC1: the fused form,
+// whose stores must be in memory before the hand-off counter moves.
+template <int U, bool SC1>
+__device__ __forceinline__ void far_chunk(int chunk, const ScanPanels &panels, const int *__restrict__ fcol,
+                                          const double *__restrict__ x, double *__restrict__ farx) {
+  const int WG = blockDim.x;
+  const int panel = chunk & (SCAN_PANELS - 1), idx = chunk >> 3;
+  const int k0 = panels.start[panel] + idx * (U * WG), k1 = min(k0 + U * WG, panels.start[panel + 1]);
+  if (k0 >= k1) return;
+  int c[U];
+  double v[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) c[u] = __builtin_nontemporal_load(fcol + min(k0 + u * WG + (int)threadIdx.x, k1 - 1));
+#pragma unroll
+  for (int u = 0; u < U; u++) v[u] = x[c[u]];
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (k0 + u * WG + (int)threadIdx.x < k1) {
+      if (SC1) __hip_atomic_store(farx + k0 + u * WG + threadIdx.x, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else farx[k0 + u * WG + threadIdx.x] = v[u];
+    }
+}
+
+constexpr int SCAN_FAR_U = 4;           // far entries per lane of a producer workgroup
+
+template <int IPT, bool NT, int FARX, int XP>
+__global__ void k_spmv_scan(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int nnz, int n_cols,
+                            const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                            const unsigned *__restrict__ meta, const int *__restrict__ rowmap,
+                            const double *__restrict__ x, double *__restrict__ farx, double *__restrict__ y,
+                            double *__restrict__ partials, ScanFar far, ScanSync sy) {
+  if (FARX == 2) {
+    if ((int)blockIdx.x < far.grid) {                         // producer workgroups: the lowest ids, dispatched first
+      const int e = sy.flag[blockIdx.x] + 1;                  // own word; the previous launch's value came with the boundary
+      far_chunk<SCAN_FAR_U, true>(blockIdx.x, far.panels, far.fcol, x, farx);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave, before the barrier
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(sy.flag + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    scan_block<IPT, NT, FARX, XP>(blockIdx.x - far.grid, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x,
+                                  farx, y, partials, far.fcol, sy);
+  } else {
+    scan_block<IPT, NT, FARX, XP>(blockIdx.x, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x, farx, y,
+                                  partials, nullptr, sy);
+  }
+}
+
+// ------------------------------------------------------------------ far columns, column panel by column panel
+// The scattered part of a power-law matrix: 0.9 M of the webbase-like matrix's gathers hit uniformly random
+// entries of an 8 MB x.  With rows dealt to XCDs every one of the eight L2s ends up fetching most lines of x
+// (128-byte fills for 8 useful bytes: 131 MB moved for 57 MB of algorithmic traffic, profiles/traffic_webbase-1M.json).
+// The reference meets scattered columns by column blocking (SparseMatrix.hpp:459-482, Spmv.cpp:42-107); here only
+// the far nonzeros are column-blocked: sorted by column panel (8 panels of x, one per XCD: workgroup b works on
+// panel b % 8, and hardware deals workgroups round-robin over the XCDs), so a line of x is filled from memory once.
+// farx is PANEL-major, inside a panel in (block, nonzero) order: this kernel's stores are one coalesced stream, and
+// the far values one product block needs from one panel are one contiguous run.  Placement is for speed only.
+template <int U>
+__global__ void k_far_panels(ScanPanels panels, const int *__restrict__ fcol, const double *__restrict__ x,
+                             double *__restrict__ farx) {
+  far_chunk<U, false>(blockIdx.x, panels, fcol, x, farx);
+}
+
+}  // namespace caskhip

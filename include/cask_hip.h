@@ -38,6 +38,12 @@ extern "C" {
 #define CASK_HIP_VARIANT_VECTOR   1   /* lanes_per_row lanes of a wavefront per row (1 = thread per row) */
 #define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, products and x tile in LDS */
 #define CASK_HIP_VARIANT_MERGE_WAVE 3 /* merge-based, persistent software-pipelined waves (no workgroup barrier, x from L2) */
+#define CASK_HIP_VARIANT_SCAN     4   /* nonzero-mapped: equal nonzeros per workgroup, thread-owned runs of products and a
+                                       * segmented scan of the carries; no row_ptr stream.  tile_width = x window staged in
+                                       * LDS (per block: the densest column range of that width); far_columns = 1 / 2:
+                                       * nonzeros outside the window and outside the rows their XCD walks are served by a
+                                       * column-panel pre-gather (1: its own launch, 2: producer workgroups of the product
+                                       * launch); 0 / -1 = off */
 
 typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launch plan */
 

@@ -92,7 +92,7 @@ def test_preconditioning_client_known_answers(plain_mtx_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["vector", "merge_wave"])
+@pytest.mark.parametrize("variant", ["vector", "merge_wave", "scan"])
 def test_env_override_selects_the_variant(plain_mtx_dir, variant):
     """CASK_HIP_VARIANT reaches the engine through the unchanged client (the reference picks designs by implId)."""
     make("clients")

@@ -38,6 +38,16 @@ DESIGN_POINTS = [
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
     dict(variant="merge_wave", items_per_thread=16, wg_size=128),
+    dict(variant="scan", items_per_thread=8, wg_size=256),                                     # nonzero-mapped, segmented scan
+    dict(variant="scan", items_per_thread=2, wg_size=64, nontemporal=-1),
+    dict(variant="scan", items_per_thread=4, wg_size=128, xcd_remap=-1),
+    dict(variant="scan", items_per_thread=16, wg_size=256),
+    dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=4096, far_columns=1),     # x window in LDS + far panels
+    dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=2048, far_columns=-1),    # window only
+    dict(variant="scan", items_per_thread=4, wg_size=64, tile_width=-1, far_columns=1, nontemporal=-1),   # far panels only
+    dict(variant="scan", items_per_thread=16, wg_size=128, tile_width=300, far_columns=1, xcd_remap=-1),
+    dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=-1, far_columns=2),       # far panels by producer workgroups
+    dict(variant="scan", items_per_thread=2, wg_size=64, tile_width=128, far_columns=2, nontemporal=-1),
     dict(),   # AUTO / all defaults
 ]
 DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
@@ -90,7 +100,8 @@ def test_baseline_configs_full_size(name):
     colsum = oracle.csr_spmv_t(n, rp, ci, va, np.ones(n))
     for dp in (dict(variant="merge"), dict(variant="vector"), dict(variant="merge", tile_width=-1),
                dict(variant="merge_wave"), dict(variant="merge", wg_size=512, items_per_thread=8),
-               dict(variant="vector", lanes_per_row=8, tile_width=-1)):
+               dict(variant="vector", lanes_per_row=8, tile_width=-1), dict(variant="scan"),
+               dict(variant="scan", tile_width=-1, far_columns=-1), dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=4096, far_columns=1)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         y1, y2 = m.spmv(x1), m.spmv(x2)
         y12 = m.spmv(2.0 * x1 - 0.5 * x2)
@@ -108,7 +119,7 @@ def test_edge_shapes():
     assert m.spmv(np.zeros(0)).size == 0
     m.close()
     # rows but no nonzeros (test_large_empty-like)
-    for dp in (dict(variant="merge"), dict(variant="vector", lanes_per_row=2)):
+    for dp in (dict(variant="merge"), dict(variant="vector", lanes_per_row=2), dict(variant="scan")):
         y = run_host(1000, 7, np.zeros(1001, dtype=np.int32), [], [], np.ones(7), dp)
         assert y.shape == (1000,) and not y.any()
     # rectangular, wider than tall and taller than wide
@@ -142,7 +153,9 @@ def test_long_rows_split_across_workgroups():
                dict(variant="merge", wg_size=64, items_per_thread=2, tile_width=256),
                dict(variant="merge", wg_size=256, items_per_thread=8),
                dict(variant="merge_wave", items_per_thread=2), dict(variant="merge_wave", items_per_thread=16, wg_size=64),
-               dict(variant="vector", lanes_per_row=64), dict(variant="vector", lanes_per_row=1)):
+               dict(variant="vector", lanes_per_row=64), dict(variant="vector", lanes_per_row=1),
+               dict(variant="scan", wg_size=64, items_per_thread=2), dict(variant="scan", wg_size=256, items_per_thread=8),
+               dict(variant="scan", wg_size=64, items_per_thread=4, tile_width=512, far_columns=1)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         info = m.info
         got = m.spmv(x)
@@ -419,3 +432,103 @@ def test_sequence_of_products_from_one_call():
         capi.spmv_sequence_device([mats[0], other], xt, yt, 2)
     for m in mats + [other]:
         m.close()
+
+
+def test_scan_kernel_rows_that_span_threads_waves_and_holes():
+    """The segmented-scan kernel (variant SCAN) where its carries matter: rows that span many threads and several
+    waves, rows that end exactly on a thread's / a wave's last product, 1-nonzero rows, empty rows between them
+    (KIND_HOLES blocks: row map + zero fill), and a run of empty rows at either end.  Against the oracle, and
+    bitwise reproducible."""
+    rng = np.random.default_rng(31)
+    for wg, ipt in ((64, 2), (256, 8), (128, 16)):
+        cap = wg * ipt
+        lens = []
+        for _ in range(40):
+            lens += [ipt] * 3 + [0] + [1] * (2 * ipt + 1) + [64 * ipt] + [0, 0] + [64 * ipt - 1, 1] + [3, 0, 5]
+            lens += [int(v) for v in rng.integers(0, 4, size=50)] + [cap // 2, cap // 2 - 1, 1, cap // 4 + 3]
+        lens = np.array([0] * 9 + lens + [0] * 5, dtype=np.int64)
+        n = lens.size
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        m_cols = max(n, int(lens.max()) + 1)
+        ci = np.concatenate([np.sort(rng.choice(m_cols, size=l, replace=False)) for l in lens]).astype(np.int32)
+        va = rng.standard_normal(ci.size)
+        x = rng.standard_normal(m_cols)
+        want = oracle.csr_spmv(rp, ci, va, x)
+        for extra in (dict(tile_width=-1, far_columns=-1), dict(tile_width=1024, far_columns=1)):
+            m = capi.CsrMatrix.from_host(n, m_cols, rp, ci, va, capi.make_params(variant="scan", wg_size=wg,
+                                                                                 items_per_thread=ipt, **extra))
+            assert m.params.as_dict()["variant"] == "scan"
+            got, again = m.spmv(x), m.spmv(x)
+            m.close()
+            oracle.assert_almost_equal(got, want, what=f"scan {wg}x{ipt} {extra}")
+            assert np.array_equal(got, again)
+
+
+def test_scan_window_and_far_panels_are_taken_and_exact():
+    """SCAN on the power-law family with its x window (LDS slots instead of columns) and its far nonzeros (columns
+    outside the window and outside the rows their XCD walks) served by the column-panel pre-gather: the same products
+    in the same order whichever way x arrives => identical bits."""
+    n, rp, ci, va = synth.webbase_like()
+    x = np.random.default_rng(22).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    ys = {}
+    for tile, far in ((-1, -1), (4096, -1), (-1, 1), (4096, 0), (2048, 1), (-1, 2), (4096, 2)):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=tile, far_columns=far))
+        prm = m.params.as_dict()
+        ys[(tile, far)] = (m.spmv(x), prm["tile_width"], prm["far_columns"])
+        assert np.array_equal(ys[(tile, far)][0], m.spmv(x))
+        m.close()
+        oracle.assert_almost_equal(ys[(tile, far)][0], want, what=f"scan tile {tile} far {far}")
+    assert ys[(-1, -1)][1:] == (-1, -1) and ys[(4096, -1)][1:] == (4096, -1) and ys[(-1, 1)][1:] == (-1, 1)
+    assert ys[(4096, 0)][1:] == (4096, -1)                   # far panels are opt-in (measured: they do not pay)
+    assert ys[(-1, 2)][1:] == (-1, 2) and ys[(4096, 2)][1:] == (4096, 2)
+    for key in ys:
+        assert np.array_equal(ys[key][0], ys[(-1, -1)][0]), key
+
+
+def test_scan_fused_far_handoff_with_a_changing_operand():
+    """far_columns = 2: the far values are produced by workgroups of the product launch itself and handed to the
+    product blocks through counters (scan_kernel.hpp).  What could go wrong is a product block reading a far value
+    one launch late (a stale line, a counter that did not reset): 60 back-to-back products -- eager and as a replayed
+    HIP graph -- each on a different x, every result compared with the separately launched pre-gather's bits."""
+    import torch
+    n, rp, ci, va = synth.webbase_like()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(33)
+    m2 = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=-1, far_columns=2))
+    m0 = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=-1, far_columns=-1))
+    assert m2.params.as_dict()["far_columns"] == 2
+    xs = [torch.from_numpy(rng.uniform(-1, 1, n)).to(dev) for _ in range(6)]
+    x = torch.zeros(n, dtype=torch.float64, device=dev)
+    y2 = torch.zeros(n, dtype=torch.float64, device=dev)
+    y0 = torch.zeros(n, dtype=torch.float64, device=dev)
+    for it in range(30):
+        x.copy_(xs[it % 6])
+        m2.spmv_device(x, y2)
+        m0.spmv_device(x, y0)
+        assert torch.equal(y2, y0), f"eager product {it}"
+    # the same inside a graph: copy, product, copy, product ... replayed
+    outs = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(6)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m2.spmv_device(x, y2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(6):
+            x.copy_(xs[k])
+            m2.spmv_device(x, outs[k])
+    for _ in range(5):
+        for o in outs:
+            o.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(6):
+            m0.spmv_device(xs[k], y0)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[k], y0), f"graph product {k}"
+    oracle.assert_almost_equal(y0.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xs[5].cpu().numpy()), what="scan fused")
+    m2.close()
+    m0.close()

@@ -17,12 +17,14 @@ def main():
     wg, ipt = int(sys.argv[1]) if len(sys.argv) > 1 else 512, int(sys.argv[2]) if len(sys.argv) > 2 else 4
     name = sys.argv[3] if len(sys.argv) > 3 else "cant"           # any BASELINE look-alike
     tile = int(sys.argv[4]) if len(sys.argv) > 4 else 1024        # 0 = AUTO, -1 = untiled
+    variant = sys.argv[5] if len(sys.argv) > 5 else "merge"       # "scan": phases 0 entry, 1 loads issued, 2 stream + gathers
+    #   landed, 3 products in LDS (barrier), 4 rows stored
     n, rp, ci, va, _ = synth.load_or_make(name)
     dev = torch.device("cuda", 0)
     copies = 13 if name == "cant" else 5
     rp_t = torch.from_numpy(rp).to(dev)
-    prm = capi.make_params(variant="merge", wg_size=wg, items_per_thread=ipt, tile_width=tile)
-    print(name, "wg", wg, "items", ipt, "tile", tile)
+    prm = capi.make_params(variant=variant, wg_size=wg, items_per_thread=ipt, tile_width=tile)
+    print(name, variant, "wg", wg, "items", ipt, "tile", tile)
     mats = [capi.CsrMatrix.from_device(n, n, rp_t, torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), prm)
             for _ in range(copies)]
     x = torch.from_numpy(np.arange(n) * 0.25 / n).to(dev)
@@ -38,6 +40,10 @@ def main():
     torch.cuda.synchronize()
     lib.cask_hip_debug_set_stamps(None)
     t = buf.cpu().numpy().reshape(grid, 8)[:, :6].astype(np.float64) * 0.01   # us
+    if variant == "scan":
+        t[:, 5] = t[:, 4]
+        t = t[t[:, 4] > 0]                                        # long-row pieces leave no stamps
+        grid = t.shape[0]
     t0 = t[:, 0].min()
     print(f"grid {grid}  launch span {t[:, 5].max() - t0:.2f} us")
     names = ["entry->issued(desc)", "issued->bar1(window,rp)", "bar1->stream+gathers", "->bar2(products)", "->reduced"]

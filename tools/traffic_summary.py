@@ -17,6 +17,8 @@ from pathlib import Path
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 workload = sys.argv[2] if len(sys.argv) > 2 else "cant"
+point = sys.argv[3] if len(sys.argv) > 3 else ""            # design point label ("" = AUTO): keys the output file
+suffix = f"_{point}" if point else ""
 root = Path(__file__).resolve().parent.parent
 out = root / "gpurun_out"
 
@@ -43,9 +45,9 @@ res = {"tag": tag, "calibration": {"kernel": "k_oneshot<8,true> (tools/membench.
                                                                         64 * cal_sizes["TCC_EA0_RDREQ_64B_sum"] +
                                                                         128 * cal_sizes["TCC_EA0_RDREQ_128B_sum"])
                                                                   if all(v is not None for v in cal_sizes.values()) else None)}}
-for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
-    f, nf = counter(f"pmc_{tag}_{workload}_FETCH_SIZE", kern, "FETCH_SIZE")
-    w, nw = counter(f"pmc_{tag}_{workload}_WRITE_SIZE", kern, "WRITE_SIZE")
+for kern in ("k_spmv_merge<", "k_spmv_scan<", "k_spmv_vector2<", "k_spmv_vector<", "k_spmv_merge_wave<"):
+    f, nf = counter(f"pmc_{tag}_{workload}{suffix}_FETCH_SIZE", kern, "FETCH_SIZE")
+    w, nw = counter(f"pmc_{tag}_{workload}{suffix}_WRITE_SIZE", kern, "WRITE_SIZE")
     if f is None:
         continue
     res["kernel"] = kern.rstrip("<")
@@ -57,7 +59,7 @@ for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
     # cross-check: L2 -> memory read requests by size (exact, no correction)
     sizes = {}
     for name, nbytes in (("TCC_EA0_RDREQ_32B_sum", 32), ("TCC_EA0_RDREQ_64B_sum", 64), ("TCC_EA0_RDREQ_128B_sum", 128)):
-        v, _ = counter(f"pmc_{tag}_{workload}_RDREQ", kern, name)
+        v, _ = counter(f"pmc_{tag}_{workload}{suffix}_RDREQ", kern, name)
         if v is not None:
             sizes[name] = v
     if sizes:
@@ -69,4 +71,5 @@ for kern in ("k_spmv_merge<", "k_spmv_vector<", "k_spmv_merge_wave<"):
     break
 print(json.dumps(res, indent=1))
 res["workload"] = workload
-(root / "gpurun_out" / f"traffic_{workload}_{tag}.json").write_text(json.dumps(res, indent=1))
+res["design_point"] = point or "auto"
+(root / "gpurun_out" / f"traffic_{workload}{suffix}_{tag}.json").write_text(json.dumps(res, indent=1))
