@@ -582,9 +582,50 @@ def run_spmv(cx, weak):
                 if peer is not None:
                     peer.close()
                     peer = None
+    gather, push, push_error = None, None, None
+    n_cols_alg = n_cols_dev
+    if exchange == "all_gather":
+        # the gathered vector has a padded stride (rank g's slice at g*S): one collective per product whatever the
+        # partition; the block's columns are remapped to it here, once
+        gather = cdist.ShardedSpmv(bounds, rank, world, None, dev)
+        ci_dev, n_cols_dev = gather.pad_columns(ci), gather.n_full
+        # ... or no collective at all: slices pushed peer to peer (cask_hip_push_allgather), checked against the formula
+        # for x on every rank first; any rank that cannot sends every rank back to RCCL
+        if os.environ.get("CASK_BENCH_EXCHANGE", "auto") in ("auto", "push") and not os.environ.get("CASK_BENCH_NO_P2P"):
+            from cask_amd import p2p
+
+            def gather_objects(obj):
+                out = [None] * world
+                dist.all_gather_object(out, obj)
+                return out
+            try:
+                push = p2p.PushExchange(rank, world, gather.S, dev, gather_objects)
+                push.x_slot[:n_local].copy_(torch.from_numpy(x_slice).to(dev))
+                ok = True
+                for _ in range(3):                                   # both gathered vectors, and a wrap-around
+                    xf = push.allgather()
+                    torch.cuda.synchronize()
+                    ok = ok and bool(torch.equal(gather.unpad(xf), torch.from_numpy(x_host).to(dev)))
+                push.check()
+            except Exception as e:  # noqa: BLE001 - construction is collective: raised on every rank or on none
+                ok, push_error = False, repr(e)
+            ok = cx.all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            if ok:
+                exchange = "push"
+            else:
+                if rank == 0:
+                    print(f"[bench] push all-gather unavailable ({push_error or 'gathered vector mismatch'}); using RCCL",
+                          file=sys.stderr)
+                if push is not None:
+                    for ptr in push.peers.values():
+                        p2p.close_peer(ptr)
+                    push.peers = {}
+                    cx.host_barrier()
+                    push.close()
+                    push = None
     gen_seconds = time.perf_counter() - t_gen
     # bytes the local kernel must move: x entries = the columns this block can reference
-    alg_bytes = synth.algorithmic_bytes(n_local, n_cols_dev, nnz_local)
+    alg_bytes = synth.algorithmic_bytes(n_local, n_cols_alg, nnz_local)
     matrix_bytes = 12 * nnz_local + 4 * (n_local + 1)
     copies = args.copies or max(2, -(-2 * INFINITY_CACHE_BYTES // max(matrix_bytes, 1)) + 1)
 
@@ -635,9 +676,12 @@ def run_spmv(cx, weak):
                 for m in mats:
                     m.set_halo_sources(n_local, None)
                 peer.pull()
+    elif exchange == "push":
+        x_local = push.x_slot[:n_local]
+        x_in = push.allgather()
     elif exchange == "all_gather":
-        gather = cdist.ShardedSpmv(bounds, rank, world, None, dev)
-        x_local = torch.from_numpy(x_slice).to(dev)
+        x_local = gather.x_slot[:n_local]                        # the slice lives where the collective reads it
+        x_local.copy_(torch.from_numpy(x_slice).to(dev))
         x_in = gather.x_full
         native = gather.native_comm()                            # the engine's own RCCL communicator (nccl backend), else None
         gather.gather_x(x_local)
@@ -662,13 +706,16 @@ def run_spmv(cx, weak):
     info = mats[0].info
 
     def step(i):
+        if exchange == "push":
+            mats[i % copies].spmv_device(push.allgather(), y)    # one exchange launch + the product (vectors alternate)
+            return
         if exchange == "p2p":
             peer.pull()                                          # remote loads over xGMI, on the launch stream
         elif exchange == "all_gather":
             if native is not None:
-                native.allgather(x_local, x_in)                  # ncclAllGather (uneven slices: grouped broadcasts) on this stream
+                native.allgather(gather.x_slot, x_in)            # ONE ncclAllGather (padded stride) on this stream
             else:
-                gather.gather_x(x_local)                         # torch.distributed all_gather_into_tensor (uneven slices padded)
+                gather.gather_x(x_local)                         # torch.distributed all_gather_into_tensor, in place
         mats[i % copies].spmv_device(x_in, y)
 
     # ---- warm-up (eager) -------------------------------------------------------
@@ -676,7 +723,7 @@ def run_spmv(cx, weak):
         step(i)
     torch.cuda.synchronize()
 
-    launch_mode = args.launch if exchange != "all_gather" else "eager"
+    launch_mode = args.launch if exchange not in ("all_gather", "push") else "eager"
     if launch_mode == "auto":
         # measured (one box): graph 8.65 / 8.27 us per step at 20 / 1000 steps, sequence 8.47 / 8.51: a graph start
         # costs ~9 us even queued behind another replay, which only a long region amortises
@@ -801,7 +848,9 @@ def run_spmv(cx, weak):
                                                  "(one launch per step, no collective)",
                                     "p2p": f"per step: pull of {peer.n_halo if peer else 0} halo entries over xGMI from the "
                                            "neighbours' shared x slices (one kernel, no collective)",
-                                    "all_gather": "per step: RCCL all_gather(x)" + (
+                                    "push": "per step: every rank stores its x slice into every peer's gathered vector "
+                                            "over xGMI + one flag per peer (cask_hip_push_allgather: one launch, no collective)",
+                                    "all_gather": "per step: RCCL all_gather(x), padded stride: one collective" + (
                                         " issued by the engine (cask_hip_rccl_allgather)" if native is not None else "")}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
@@ -831,6 +880,14 @@ def run_spmv(cx, weak):
             rec["cpu_baseline"] = None
     if use_dist:
         cx.host_barrier()
+        if push is not None:
+            from cask_amd import p2p
+            push.check()
+            for ptr in push.peers.values():
+                p2p.close_peer(ptr)
+            push.peers = {}
+            cx.host_barrier()                                       # owners free only after every peer has unmapped
+            push.close()
         if peer is not None:
             from cask_amd import p2p
             for ptr in peer.peers.values():

@@ -366,7 +366,7 @@ class CsrMatrix:
 
 
 RCCL_SYMBOLS = ("cask_hip_rccl_unique_id", "cask_hip_rccl_comm_create", "cask_hip_rccl_comm_destroy",
-                "cask_hip_rccl_allreduce", "cask_hip_rccl_allgather")
+                "cask_hip_rccl_allreduce", "cask_hip_rccl_allgather", "cask_hip_rccl_comm_set_stride")
 
 
 class NativeComm:
@@ -383,6 +383,7 @@ class NativeComm:
             L.cask_hip_rccl_comm_destroy.argtypes = [c_void_p]
             L.cask_hip_rccl_allreduce.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
             L.cask_hip_rccl_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+            L.cask_hip_rccl_comm_set_stride.argtypes = [c_void_p, c_int64]
             for name in RCCL_SYMBOLS:
                 getattr(L, name).restype = ctypes.c_int
             L._rccl_bound = True
@@ -394,13 +395,17 @@ class NativeComm:
         _check(NativeComm._lib().cask_hip_rccl_unique_id(buf))
         return bytes(buf)
 
-    def __init__(self, uid: bytes, rank: int, world: int, bounds=None):
+    def __init__(self, uid: bytes, rank: int, world: int, bounds=None, stride: int = 0):
+        """``stride`` > 0: the gathered vector is laid out with that padded stride (rank g's slice at g*stride) and
+        the all-gather is ONE ncclAllGather of ``stride`` doubles per rank whatever the row partition."""
         L = self._lib()
         b = np.ascontiguousarray(bounds, dtype=np.int64) if bounds is not None else None
         h = c_void_p()
         idbuf = (ctypes.c_ubyte * 128).from_buffer_copy(uid)
         _check(L.cask_hip_rccl_comm_create(idbuf, rank, world, _p(b) if b is not None else None, byref(h)))
         self.handle = h
+        if stride:
+            _check(L.cask_hip_rccl_comm_set_stride(h, int(stride)))
 
     def allreduce(self, t, stream=None):
         _check(self._lib().cask_hip_rccl_allreduce(c_void_p(t.data_ptr()), t.numel(), c_void_p(_stream_ptr(stream)), self.handle))

@@ -1901,8 +1901,14 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   double *base = cfg.d_shared_base;
   st.S = cfg.stride;
   if (!base) {
-    st.S = (n + 31) / 32 * 32;
-    if (st.S == 0) st.S = 32;
+    // private vectors: rows rounded up to 32 -- or, with an exchange callback, the caller's stride: the padded
+    // all-gather (cask_hip_rccl_comm_set_stride) reads `stride` doubles from every operand slot
+    if (st.exchange && cfg.stride > 0) {
+      if (cfg.stride < n || (cfg.stride & 1)) return fail(CASK_HIP_ERR_INVALID, "stride must be even and at least the block's row count");
+    } else {
+      st.S = (n + 31) / 32 * 32;
+      if (st.S == 0) st.S = 32;
+    }
   } else {
     if (st.S < n || (st.S & 1)) return fail(CASK_HIP_ERR_INVALID, "stride must be even and at least the block's row count");
     if (reinterpret_cast<uintptr_t>(base) & 15) return fail(CASK_HIP_ERR_INVALID, "shared base must be 16-byte aligned");
@@ -1914,7 +1920,12 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   if (ws.n != n || ws.S != st.S || ws.n_slots != n_slots || ws.shared_vec != (cfg.d_shared_base != nullptr) ||
       ws.n_full != want_full) {
     ws.n = -1;                                                // (re)build; a failed allocation leaves it invalid
-    if (!cfg.d_shared_base) HIP_TRY(ws.own_vec.alloc((size_t)(st.S * n_slots))); else ws.own_vec.release();
+    if (!cfg.d_shared_base) {
+      HIP_TRY(ws.own_vec.alloc((size_t)(st.S * n_slots)));
+      HIP_TRY(hipMemsetAsync(ws.own_vec.p, 0, (size_t)(st.S * n_slots) * sizeof(double), static_cast<hipStream_t>(stream)));   // padded tails stay finite
+    } else {
+      ws.own_vec.release();
+    }
     HIP_TRY(ws.q.alloc(n));
     if (bicg) HIP_TRY(ws.qt.alloc(n)); else ws.qt.release();
     HIP_TRY(ws.part_a.alloc(BLAS_MAX_PARTIALS)); HIP_TRY(ws.part_b.alloc(BLAS_MAX_PARTIALS));

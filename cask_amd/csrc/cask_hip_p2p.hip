@@ -2,12 +2,14 @@
 // (hipIpc handles between the per-GPU processes) and the halo pull kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 
 #include "cask_hip.h"
 #include "cask_hip_p2p.h"
 #include "internal.hpp"
+#include "spmv_common.hpp"
 
 namespace {
 
@@ -21,26 +23,162 @@ namespace {
 static_assert(sizeof(hipIpcMemHandle_t) == CASK_HIP_SHARED_HANDLE_BYTES, "handle size is part of the ABI");
 
 // A halo is a few hundred to a few hundred thousand scattered 8-byte entries; each lane issues
-// its remote loads back to back (4 in flight) so one round trip over xGMI covers them.
+// its remote loads back to back (4 in flight) so one round trip over xGMI covers them.  The entries live in a peer
+// GPU's memory and change between products: they are read with system-scope loads (sc0 sc1, like the seam loads of
+// the product kernel, merge_kernel.hpp load_at) -- served by the owner's memory, never by a line this GPU's L2 kept
+// from the previous product.
+__device__ __forceinline__ double pull_at(uint64_t addr) {
+  typedef __attribute__((address_space(1))) const double gdouble;
+  return __hip_atomic_load(reinterpret_cast<gdouble *>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_halo_pull(int64_t n, const uint64_t *__restrict__ src, double *__restrict__ dst) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; j + 3 * stride < n; j += 4 * stride) {
-    const double a = *reinterpret_cast<const double *>(src[j]);
-    const double b = *reinterpret_cast<const double *>(src[j + stride]);
-    const double c = *reinterpret_cast<const double *>(src[j + 2 * stride]);
-    const double d = *reinterpret_cast<const double *>(src[j + 3 * stride]);
+    const double a = pull_at(src[j]);
+    const double b = pull_at(src[j + stride]);
+    const double c = pull_at(src[j + 2 * stride]);
+    const double d = pull_at(src[j + 3 * stride]);
     dst[j] = a;
     dst[j + stride] = b;
     dst[j + 2 * stride] = c;
     dst[j + 3 * stride] = d;
   }
-  for (; j < n; j += stride) dst[j] = *reinterpret_cast<const double *>(src[j]);
+  for (; j < n; j += stride) dst[j] = pull_at(src[j]);
+}
+
+// ---- push all-gather ------------------------------------------------------------------------------------------
+// The exchange SURVEY section 5 asked for at latency-bound sizes: every rank stores its slice of x straight into
+// every peer's gathered vector through the IPC mappings (xGMI is point-to-point: one hop per peer), then one flag
+// per peer; a rank's product may start when all world flags of this exchange have arrived.  ONE launch per
+// exchange, no collective library on the data path.
+//   * data: 16-byte write-through stores at system scope (sc0 sc1): the bytes are in the owner's memory when the
+//     storing wave's vmcnt drains;
+//   * the workgroup that arrives last at the launch's local counter knows every store of the launch has drained; it
+//     takes the next sequence number (a device-resident counter: the same launch may be replayed from a graph),
+//     stores it into slot [rank] of every peer's flag array (system scope), then polls its own flag array until
+//     every slot has reached that number, and leaves through a system-scope acquire.  Sequence numbers only grow,
+//     so a flag never needs a reset and a peer that is a whole exchange ahead reads as "arrived";
+//   * gathered vectors are double-buffered by the parity of the sequence number: a peer may push exchange k+1 while
+//     this rank's product still reads the buffer of exchange k; it cannot push k+2 before this rank has pushed
+//     k+1, i.e. after that product (stream order);
+//   * every poll is bounded: on a timeout the launch raises the error word (cask_hip_push_check) and ends.
+struct PushTables {
+  double *full[2][CASK_HIP_PUSH_MAX_WORLD];     // every rank's two gathered vectors as mapped in this process
+  int *flags[CASK_HIP_PUSH_MAX_WORLD];          // every rank's flag array as mapped in this process
+};
+constexpr long long PUSH_POLL_LIMIT = 1ll << 24;              // x ~0.1 us sleep: about two seconds
+
+__device__ __forceinline__ void store16_sys(void *p, caskhip::dbl2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ void k_push_allgather(const double *__restrict__ src, int64_t stride, int rank, int world, PushTables t,
+                                 int *state /* [0] arrivals, [1] sequence number, [2] error */, int parity_of_next) {
+  __shared__ int s_last, s_seq;
+  const caskhip::dbl2 *s2 = reinterpret_cast<const caskhip::dbl2 *>(src);
+  const int64_t n2 = stride >> 1, step = (int64_t)gridDim.x * blockDim.x;
+  for (int g = 0; g < world; g++) {
+    caskhip::dbl2 *dst = reinterpret_cast<caskhip::dbl2 *>(t.full[parity_of_next][g] + (int64_t)rank * stride);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += step) store16_sys(dst + i, s2[i]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave, before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_seq = state[1] + 1;
+    state[1] = s_seq;
+  }
+  __syncthreads();
+  const int seq = s_seq;
+  if ((int)threadIdx.x < world) {
+    __hip_atomic_store(t.flags[threadIdx.x] + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int *mine = t.flags[rank] + threadIdx.x;
+    long long spins = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+      if (++spins > PUSH_POLL_LIMIT) {
+        state[2] = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");               // system scope: nothing cached of what the peers just wrote
 }
 
 }  // namespace
 
+struct cask_hip_push {
+  int rank = 0, world = 1;
+  int64_t stride = 0;
+  PushTables tables{};
+  int *d_state = nullptr;
+  int parity = 0;                  // buffer the NEXT exchange fills (host mirror of the device sequence number)
+};
+
 extern "C" {
+
+int cask_hip_push_create(int32_t rank, int32_t world, int64_t stride, const uint64_t *full_addr, const uint64_t *flag_addr,
+                         cask_hip_push **out) {
+  if (!out || !full_addr || !flag_addr || world < 1 || world > CASK_HIP_PUSH_MAX_WORLD || rank < 0 || rank >= world ||
+      stride <= 0 || (stride & 1))
+    return caskhip::report_failure(CASK_HIP_ERR_INVALID, "bad argument (stride must be even, world <= 64)");
+  cask_hip_push *p = new cask_hip_push;
+  p->rank = rank;
+  p->world = world;
+  p->stride = stride;
+  for (int g = 0; g < world; g++) {
+    p->tables.full[0][g] = reinterpret_cast<double *>(full_addr[g]);
+    p->tables.full[1][g] = reinterpret_cast<double *>(full_addr[world + g]);
+    p->tables.flags[g] = reinterpret_cast<int *>(flag_addr[g]);
+    if (!full_addr[g] || !full_addr[world + g] || !flag_addr[g] || (full_addr[g] & 15) || (full_addr[world + g] & 15)) {
+      delete p;
+      return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL or misaligned peer mapping");
+    }
+  }
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_state), 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(p->d_state, 0, 4 * sizeof(int));
+  if (e != hipSuccess) {
+    delete p;
+    return caskhip::report_failure(CASK_HIP_ERR_RUNTIME, std::string("push state: ") + hipGetErrorString(e));
+  }
+  *out = p;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_push_destroy(cask_hip_push *p) {
+  if (!p) return CASK_HIP_OK;
+  if (p->d_state) (void)hipFree(p->d_state);
+  delete p;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_full_out, void *stream) {
+  if (!p || !d_local || !d_full_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
+  if (reinterpret_cast<uintptr_t>(d_local) & 15) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "d_local must be 16-byte aligned");
+  // a few workgroups are enough to keep world links busy; the slice is stride*8 bytes (1 MB at webbase-1M / 8)
+  const int64_t pairs = p->stride >> 1;
+  const int grid = (int)std::min<int64_t>(64, std::max<int64_t>(1, (pairs + 1023) / 1024));
+  const int parity = p->parity;
+  hipLaunchKernelGGL(k_push_allgather, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_local, p->stride, p->rank,
+                     p->world, p->tables, p->d_state, parity);
+  P2P_TRY(hipGetLastError());
+  *d_full_out = p->tables.full[parity][p->rank];
+  p->parity ^= 1;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_push_check(cask_hip_push *p) {
+  if (!p) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
+  int st[4] = {0, 0, 0, 0};
+  P2P_TRY(hipMemcpy(st, p->d_state, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[2]) return caskhip::report_failure(CASK_HIP_ERR_RUNTIME, "push all-gather: a peer's flag did not arrive within the poll limit");
+  return CASK_HIP_OK;
+}
 
 int cask_hip_shared_alloc(int64_t bytes, void **d_ptr_out, unsigned char *handle_out) {
   if (bytes <= 0 || !d_ptr_out || !handle_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "bad argument");

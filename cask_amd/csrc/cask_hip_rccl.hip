@@ -72,6 +72,7 @@ struct cask_hip_comm {
   int rank = 0, world = 1;
   std::vector<int64_t> bounds;
   bool even = false;
+  int64_t stride = 0;              // > 0: padded layout of the gathered vector, one ncclAllGather of `stride` doubles
 };
 
 extern "C" {
@@ -126,6 +127,15 @@ int cask_hip_rccl_comm_destroy(cask_hip_comm *c) {
   return CASK_HIP_OK;
 }
 
+int cask_hip_rccl_comm_set_stride(cask_hip_comm *c, int64_t stride) {
+  if (!c || stride < 0) return report_failure(CASK_HIP_ERR_INVALID, "bad argument");
+  for (int g = 0; g < c->world && !c->bounds.empty(); g++)
+    if (stride && c->bounds[g + 1] - c->bounds[g] > stride)
+      return report_failure(CASK_HIP_ERR_INVALID, "stride is shorter than a rank's slice");
+  c->stride = stride;
+  return CASK_HIP_OK;
+}
+
 int cask_hip_rccl_allreduce(double *d_values, int32_t count, void *stream, void *comm) {
   cask_hip_comm *c = static_cast<cask_hip_comm *>(comm);
   if (!c || !d_values || count < 0) return report_failure(CASK_HIP_ERR_INVALID, "bad argument");
@@ -140,6 +150,10 @@ int cask_hip_rccl_allgather(const double *d_local, double *d_full, void *stream,
   if (!d_local && c->bounds[c->rank + 1] > c->bounds[c->rank]) return report_failure(CASK_HIP_ERR_INVALID, "d_local is NULL");
   RcclApi &a = api();
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c->stride > 0) {                                        // padded layout: one collective whatever the partition
+    ncclResult_t r = a.AllGather(d_local, d_full, (size_t)c->stride, ncclDouble, c->comm, s);
+    return r == ncclSuccess ? CASK_HIP_OK : rccl_fail("ncclAllGather", r);
+  }
   if (c->even) {
     ncclResult_t r = a.AllGather(d_local, d_full, (size_t)(c->bounds[1] - c->bounds[0]), ncclDouble, c->comm, s);
     return r == ncclSuccess ? CASK_HIP_OK : rccl_fail("ncclAllGather", r);

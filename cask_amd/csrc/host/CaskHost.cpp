@@ -479,3 +479,53 @@ void unittrsolve(const double *values, const int *row_ptr, const int *col_ind, c
 }  // namespace mkl
 
 }  // namespace cask
+
+// ---- the product's MatrixMarket reader for callers without a C++ toolchain (bench.py: $CASK_MATRIX_DIR files) ----
+// cask::io::readMatrix / readMatrixCached (include/cask/IO.hpp; the reference's io::readMatrix, IO.hpp:151-163) behind
+// three C entry points: arrays are malloc'ed here and released with cask_host_free.
+#include <cstring>
+
+#include "cask/IO.hpp"
+
+namespace {
+thread_local std::string g_host_error;
+}
+
+extern "C" {
+
+const char *cask_host_last_error(void) { return g_host_error.c_str(); }
+
+void cask_host_free(void *p) { std::free(p); }
+
+int cask_host_read_matrix(const char *path, int use_cache, int32_t *n_rows, int32_t *n_cols, int64_t *nnz, int32_t **row_ptr,
+                          int32_t **col_ind, double **values) {
+  if (!path || !n_rows || !n_cols || !nnz || !row_ptr || !col_ind || !values) {
+    g_host_error = "NULL argument";
+    return 1;
+  }
+  try {
+    const cask::CsrMatrix a = use_cache ? cask::io::readMatrixCached(path) : cask::io::readMatrix(path);
+    *n_rows = a.n;
+    *n_cols = a.m;
+    *nnz = a.nnzs;
+    *row_ptr = static_cast<int32_t *>(std::malloc(sizeof(int32_t) * ((size_t)a.n + 1)));
+    *col_ind = static_cast<int32_t *>(std::malloc(sizeof(int32_t) * std::max<size_t>(1, (size_t)a.nnzs)));
+    *values = static_cast<double *>(std::malloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnzs)));
+    if (!*row_ptr || !*col_ind || !*values) {
+      std::free(*row_ptr); std::free(*col_ind); std::free(*values);
+      g_host_error = "out of memory";
+      return 1;
+    }
+    std::memcpy(*row_ptr, a.row_ptr.data(), sizeof(int32_t) * ((size_t)a.n + 1));
+    if (a.nnzs) {
+      std::memcpy(*col_ind, a.col_ind.data(), sizeof(int32_t) * (size_t)a.nnzs);
+      std::memcpy(*values, a.values.data(), sizeof(double) * (size_t)a.nnzs);
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    g_host_error = e.what();
+    return 1;
+  }
+}
+
+}  // extern "C"

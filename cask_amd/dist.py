@@ -8,8 +8,13 @@ precedent is the per-pipe contiguous row split of Spmv::preprocess
 nnz-balanced, each rank owns rows [r_g, r_{g+1}) with global column indices,
 the matching slice of every vector, and one exchange per product:
 
-    x_full = all_gather(x_local)          (RCCL; 8*n bytes in total)
+    x_full = all_gather(x_local)          (RCCL; ONE collective whatever the partition)
     y_local = A_g @ x_full                (local HIP kernel)
+
+nnz-balanced blocks are always uneven and RCCL's all-gather wants equal counts, so the gathered vector is laid
+out with a PADDED STRIDE: rank g's slice sits at [g*S, g*S + n_g), S = the longest slice rounded up to 32, and a
+block's column indices are remapped to that layout once, at plan time (``pad_columns``).  No pad / copy kernels
+and no grouped broadcasts per product (round 2: 8 ncclBroadcasts or 1 + 8 copy kernels).
 
 Dot products are a local two-stage reduction plus a one-element all_reduce.
 
@@ -72,11 +77,24 @@ class ShardedSpmv:
         self.sizes = [self.bounds[g + 1] - self.bounds[g] for g in range(world)]
         self.n_local = self.sizes[rank]
         self.max_local = max(self.sizes) if self.sizes else 0
-        self.even = all(s == self.max_local for s in self.sizes)
-        self.x_full = torch.zeros(self.n, dtype=torch.float64, device=device)
-        if not self.even:
-            self._pad_in = torch.zeros(self.max_local, dtype=torch.float64, device=device)
-            self._pad_out = torch.zeros(self.max_local * world, dtype=torch.float64, device=device)
+        # padded stride of the gathered vector: every slice fits S entries, S a multiple of 32 (16-byte pairs, lines)
+        self.S = max(32, -(-self.max_local // 32) * 32)
+        self.n_full = self.S * world
+        self.x_full = torch.zeros(self.n_full, dtype=torch.float64, device=device)
+        # this rank's slice in a buffer the collective can read S entries from (the tail stays zero)
+        self.x_slot = torch.zeros(self.S, dtype=torch.float64, device=device)
+
+    def pad_columns(self, col_ind):
+        """Global column indices -> positions in the padded gathered vector (owner * S + offset in its slice)."""
+        c = np.asarray(col_ind, dtype=np.int64)
+        b = np.asarray(self.bounds, dtype=np.int64)
+        owner = np.searchsorted(b, c, side="right") - 1
+        owner = np.clip(owner, 0, self.world - 1)
+        return (owner * self.S + (c - b[owner])).astype(np.int32)
+
+    def unpad(self, x_full):
+        """The n global entries out of a padded gathered vector (tests, debugging)."""
+        return self.torch.cat([x_full[g * self.S: g * self.S + self.sizes[g]] for g in range(self.world)])
 
     @classmethod
     def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None,
@@ -146,9 +164,21 @@ class ShardedSpmv:
                         obj.close()
                     raise capi.CaskHipError("solver slots / shared vectors need the in-kernel halo, and some rank's block "
                                             "cannot run the MERGE kernel (fewer than 2 nonzeros)")
-        elif exchange == "all_gather":
-            mat = capi.CsrMatrix.from_host(n_local, n_cols, rp, ci, va, params)
-            obj = cls(bounds, rank, world, lambda xf, yl: mat.spmv_device(xf, yl), dev, group)
+        elif exchange in ("all_gather", "push"):
+            obj = cls(bounds, rank, world, None, dev, group)
+            mat = capi.CsrMatrix.from_host(n_local, obj.n_full, rp, obj.pad_columns(ci), va, params)
+            obj.local_product = lambda xf, yl: mat.spmv_device(xf, yl)
+            if exchange == "push":
+                # the hand-written exchange (include/cask_hip_p2p.h): same padded layout, slices pushed over xGMI
+                import torch.distributed as dist
+                from . import p2p
+
+                def gather_objects(o):
+                    out = [None] * world
+                    dist.all_gather_object(out, o, group=group)
+                    return out
+                obj.push = p2p.PushExchange(rank, world, obj.S, dev, gather_objects)
+                obj.x_slot = obj.push.x_slot
         else:
             raise ValueError(f"unknown exchange {exchange!r}")
         obj.matrix = mat
@@ -156,20 +186,19 @@ class ShardedSpmv:
 
     # -- exchange ---------------------------------------------------------------
     def gather_x(self, x_local, out=None):
-        """all-gather of the x slices into ``out`` (default: self.x_full); uneven slices are padded to the longest."""
+        """all-gather of the x slices into ``out`` (default: self.x_full), padded layout: ONE collective.  A slice
+        that already lives at the head of ``self.x_slot`` (``sh.x_slot[:n_local]``) is gathered in place; any other
+        is copied there first."""
         import torch.distributed as dist
+        if x_local.data_ptr() != self.x_slot.data_ptr():
+            self.x_slot[: self.n_local].copy_(x_local)
+        if getattr(self, "push", None) is not None and out is None:
+            return self.push.allgather()                         # one launch; the gathered vectors alternate
         out = self.x_full if out is None else out
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            out.copy_(x_local)
+            out[: self.S].copy_(self.x_slot)
             return out
-        if self.even:
-            dist.all_gather_into_tensor(out, x_local.contiguous(), group=self.group)
-            return out
-        self._pad_in[: self.n_local].copy_(x_local)
-        dist.all_gather_into_tensor(self._pad_out, self._pad_in, group=self.group)
-        for g in range(self.world):
-            out[self.bounds[g]: self.bounds[g + 1]].copy_(
-                self._pad_out[g * self.max_local: g * self.max_local + self.sizes[g]])
+        dist.all_gather_into_tensor(out, self.x_slot, group=self.group)
         return out
 
     def spmv(self, x_local, y_local=None, fence_before=True, fence_after=True):
@@ -201,6 +230,17 @@ class ShardedSpmv:
 
     def close(self):
         """Collective: unmap the peers' slices, then free the own one."""
+        push, self.push = getattr(self, "push", None), None
+        if push is not None:
+            import torch.distributed as dist
+            self.torch.cuda.synchronize()
+            for g, p in list(push.peers.items()):
+                from . import p2p
+                p2p.close_peer(p)
+            push.peers = {}
+            if dist.is_initialized():
+                dist.barrier(group=self.group)                  # owners free only after every peer has unmapped
+            push.close()
         ex, self.exchange = self.exchange, None
         if ex is not None:
             for g, p in list(ex.peers.items()):
@@ -250,7 +290,7 @@ class ShardedSpmv:
         comm = None
         if uid[0] is not None:
             try:
-                comm = capi.NativeComm(uid[0], self.rank, self.world, self.bounds)
+                comm = capi.NativeComm(uid[0], self.rank, self.world, self.bounds, stride=self.S)
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
         ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=self.device)
@@ -296,14 +336,18 @@ class ShardedSpmv:
         views = {}
 
         def exchange(local_ptr, full_ptr, stream):
+            # the engine's operand slot holds S entries (stride of the solver vectors = self.S): gathered as it is
             key = (local_ptr, full_ptr)
             if key not in views:
-                views[key] = (tensor_from_ptr(local_ptr, self.n_local, self.device),
-                              tensor_from_ptr(full_ptr, self.n, self.device))
+                views[key] = (tensor_from_ptr(local_ptr, self.S, self.device),
+                              tensor_from_ptr(full_ptr, self.n_full, self.device))
             src, dst = views[key]
             if not stream_ordered and self.device.type == "cuda":
                 self.torch.cuda.synchronize()
-            self.gather_x(src, out=dst)
+            if self.world == 1 and not dist.is_initialized():
+                dst[: self.S].copy_(src)
+            else:
+                dist.all_gather_into_tensor(dst, src, group=self.group)
             if not stream_ordered and self.device.type == "cuda":
                 self.torch.cuda.synchronize()
             return 0
@@ -340,7 +384,8 @@ class ShardedSpmv:
                 raise RuntimeError("A and A^T must share one PeerExchange (from_global(..., share_with=...))")
             kw.update(shared_base=ex.shared.ptr, stride=ex.stride)
         elif collective:
-            kw.update(exchange=native if native is not None else self._exchange_callback(), n_full=self.n)
+            kw.update(exchange=native if native is not None else self._exchange_callback(), n_full=self.n_full,
+                      stride=self.S)
         self.last_collectives = "native RCCL (issued by the engine)" if native is not None else (
             "torch.distributed callbacks" if collective else "none")
         it, conv, us = self.matrix.solve_device(b_local.contiguous(), x, kind=kind,

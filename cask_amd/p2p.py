@@ -40,7 +40,8 @@ from . import capi
 HANDLE_BYTES = 64
 P2P_SYMBOLS = ("cask_hip_shared_alloc", "cask_hip_shared_free", "cask_hip_shared_open", "cask_hip_shared_close",
                "cask_hip_copy_to_device", "cask_hip_copy_to_host", "cask_hip_halo_pull_device",
-               "cask_hip_csr_set_halo_sources")
+               "cask_hip_csr_set_halo_sources", "cask_hip_push_create", "cask_hip_push_destroy",
+               "cask_hip_push_allgather", "cask_hip_push_check")
 
 
 def _lib():
@@ -55,6 +56,10 @@ def _lib():
         L.cask_hip_copy_to_host.argtypes = [vp, vp, i64]
         L.cask_hip_halo_pull_device.argtypes = [i64, vp, vp, vp]
         L.cask_hip_csr_set_halo_sources.argtypes = [vp, ctypes.c_int32, vp]
+        L.cask_hip_push_create.argtypes = [ctypes.c_int32, ctypes.c_int32, i64, vp, vp, ctypes.POINTER(vp)]
+        L.cask_hip_push_destroy.argtypes = [vp]
+        L.cask_hip_push_allgather.argtypes = [vp, vp, ctypes.POINTER(vp), vp]
+        L.cask_hip_push_check.argtypes = [vp]
         for s in P2P_SYMBOLS:
             getattr(L, s).restype = ctypes.c_int
         L._p2p_bound = True
@@ -263,6 +268,85 @@ class PeerExchange:
             close_peer(p)
         self.peers = {}
         self.x_ext = self.x_local = None
+        if self.shared is not None:
+            self.shared.free()
+            self.shared = None
+
+
+class PushExchange:
+    """The push all-gather of ``include/cask_hip_p2p.h``: every rank stores its slice into every peer's gathered
+    vector over xGMI (one launch per exchange, no collective library on the data path).  Collective construction:
+    each rank allocates one shared region -- two gathered vectors of ``world * stride`` doubles and a flag array --
+    and opens every peer's.  Raises on every rank or on none (agreed through ``exchange_objects``).
+
+        ex = PushExchange(rank, world, stride, device, exchange_objects)
+        ex.x_slot[:n_local] = ...            # this rank's slice (stride doubles, tail zero)
+        x_full = ex.allgather()              # the tensor the product that follows must read (alternates)
+    """
+
+    FLAG_DOUBLES = 64                         # room for 128 ints behind the vectors, on a line of its own
+
+    def __init__(self, rank, world, stride, device, exchange_objects):
+        import torch
+        self.rank, self.world, self.stride, self.device = rank, world, int(stride), device
+        self.peers, self.shared, self._h = {}, None, None
+        n_vec = world * self.stride
+        err = None
+        try:
+            self.shared = SharedVector(2 * n_vec + self.FLAG_DOUBLES)
+            self.shared.write([rank + 0.5])
+        except Exception as e:  # noqa: BLE001 - reported to every rank below
+            err = repr(e)
+        infos = exchange_objects({"handle": self.shared.handle if self.shared else None, "error": err})
+        err = next((f"rank {g}: {i['error']}" for g, i in enumerate(infos) if i["error"]), None)
+        if err is None:
+            try:
+                for g in range(world):
+                    if g == rank:
+                        continue
+                    self.peers[g] = open_peer(infos[g]["handle"])
+                    if peek(self.peers[g]) != g + 0.5:
+                        raise capi.CaskHipError(f"mapping of rank {g}'s region does not show its signature")
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        oks = exchange_objects(err)
+        bad = [f"rank {g}: {e}" for g, e in enumerate(oks) if e]
+        if bad:
+            self.close()
+            raise capi.CaskHipError("push all-gather setup failed (" + "; ".join(bad) + ")")
+        self.shared.write([0.0])
+        bases = [self.shared.ptr if g == rank else self.peers[g] for g in range(world)]
+        full = np.array([b for b in bases] + [b + 8 * n_vec for b in bases], dtype=np.uint64)
+        flags = np.array([b + 16 * n_vec for b in bases], dtype=np.uint64)
+        h = c_void_p()
+        capi._check(_lib().cask_hip_push_create(rank, world, self.stride, full.ctypes.data_as(c_void_p),
+                                                flags.ctypes.data_as(c_void_p), ctypes.byref(h)))
+        self._h = h
+        region = self.shared.tensor(device)
+        self._full = [region[:n_vec], region[n_vec: 2 * n_vec]]
+        self._ptr = {int(self._full[0].data_ptr()): 0, int(self._full[1].data_ptr()): 1}
+        self.x_slot = torch.zeros(self.stride, dtype=torch.float64, device=device)
+
+    def allgather(self, x_slot=None, stream=None):
+        """One exchange (asynchronous on ``stream``); returns the gathered vector this rank's next product reads."""
+        src = self.x_slot if x_slot is None else x_slot
+        out = c_void_p()
+        capi._check(_lib().cask_hip_push_allgather(self._h, c_void_p(src.data_ptr()), ctypes.byref(out),
+                                                   c_void_p(capi._stream_ptr(stream))))
+        return self._full[self._ptr[int(out.value)]]
+
+    def check(self):
+        """Synchronous: raises if a poll of an earlier exchange timed out."""
+        capi._check(_lib().cask_hip_push_check(self._h))
+
+    def close(self):
+        if self._h:
+            _lib().cask_hip_push_destroy(self._h)
+            self._h = None
+        for g, p in list(self.peers.items()):
+            close_peer(p)
+        self.peers = {}
+        self._full = None
         if self.shared is not None:
             self.shared.free()
             self.shared = None

@@ -231,11 +231,12 @@ def load_or_make(name):
     if d:
         p = Path(d) / f"{name}.mtx"
         if p.exists():
-            import scipy.io
-            import scipy.sparse as sp
-            a = sp.csr_matrix(scipy.io.mmread(str(p)))
-            a.sort_indices()
-            return a.shape[0], a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64), str(p)
+            # the product's own reader (cask::io::readMatrixCached: symmetric expansion, binary cache), not scipy's
+            from . import hostio
+            n, m, rp, ci, va = hostio.read_matrix(p, cached=True)
+            if n != m:
+                raise ValueError(f"{p}: the BASELINE workloads are square, this file is {n} x {m}")
+            return n, rp, ci, va, str(p)
     n, rp, ci, va = GENERATORS[name]()
     return n, rp, ci, va, "synthetic"
 

@@ -235,8 +235,12 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
  *   allreduce  sums `count` doubles at d_values over all ranks, in place, ordered on `stream` (RCCL
  *              all-reduce of the dot products).  NULL = single rank.
  *   exchange   classic mode only: gathers the operand slices of all ranks into d_full (RCCL all-gather
- *              of x), for blocks stored with GLOBAL column indices.  NULL = the block reads its halo
- *              itself (cask_hip_csr_set_halo_sources) or has none.
+ *              of x; n_full entries), for blocks whose column indices address the gathered vector.  With
+ *              d_shared_base == NULL and stride > 0 the solver's private vector slots are `stride` doubles
+ *              long, so that the callback may read `stride` doubles from d_local: the padded-stride layout
+ *              (rank g's slice at g*stride; cask_hip_rccl_comm_set_stride) makes the gather ONE collective
+ *              whatever the row partition.  NULL = the block reads its halo itself
+ *              (cask_hip_csr_set_halo_sources) or has none.
  *   d_shared_base / stride   sharded, in-kernel halo: the vectors peers read (r, p, rt, pt) live in this
  *              rank's shared allocation (cask_hip_shared_alloc), slot k at base + k*stride doubles; 3
  *              slots for CG, 6 for BiCG; the halo tables of A and A^T point at slot 0 of the peers'

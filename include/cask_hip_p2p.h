@@ -62,6 +62,29 @@ int cask_hip_halo_pull_device(int64_t n_halo, const uint64_t *d_src_addr, double
  * its own copy of x through dramWrite, here a rank reads the entries it needs where they live. */
 int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint64_t *d_src_addr);
 
+/* ---- push all-gather: the operand exchange of BASELINE configs[3] without a collective library ---------------
+ * Every rank owns TWO gathered vectors (world * stride doubles each; rank g's slice at g*stride: the padded
+ * layout of cask_hip_rccl_comm_set_stride) and a flag array (world ints) in shared allocations
+ * (cask_hip_shared_alloc) that every peer has opened.  One exchange = one launch on `stream`: this rank's
+ * `stride` doubles at d_local are stored into slot [rank] of EVERY rank's gathered vector (16-byte write-through
+ * stores over xGMI, own copy included), then a sequence number into slot [rank] of every rank's flag array; the
+ * launch ends when all world flags of this exchange have arrived here.  *d_full_out is the local gathered vector
+ * the product that follows must read -- the two alternate, so that a peer may already push the next exchange
+ * while this rank's product still runs.  Stream order on every rank (exchange k, product k, exchange k+1, ...) is
+ * all the cross-rank ordering needed.  Polls are bounded (about two seconds); cask_hip_push_check (synchronous)
+ * reports a timeout.  All ranks must issue the same sequence of exchanges.
+ *   full_addr   [2 * world] this process's mappings of every rank's first, then second gathered vector
+ *               (own entries: the local pointers)
+ *   flag_addr   [world] likewise for the flag arrays (zero-initialised: cask_hip_shared_alloc does that)
+ * Replaces, like the RCCL all-gather, the per-pipe x upload of Spmv::spmv (src/runtime/Spmv.cpp:144-183). */
+#define CASK_HIP_PUSH_MAX_WORLD 64
+typedef struct cask_hip_push cask_hip_push;
+int cask_hip_push_create(int32_t rank, int32_t world, int64_t stride, const uint64_t *full_addr, const uint64_t *flag_addr,
+                         cask_hip_push **out);
+int cask_hip_push_destroy(cask_hip_push *p);
+int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_full_out, void *stream);
+int cask_hip_push_check(cask_hip_push *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,12 @@ int cask_hip_rccl_unique_id(unsigned char *id_out /* CASK_HIP_RCCL_ID_BYTES */);
 int cask_hip_rccl_comm_create(const unsigned char *id, int32_t rank, int32_t world, const int64_t *bounds,
                               cask_hip_comm **out);
 int cask_hip_rccl_comm_destroy(cask_hip_comm *comm);
+/* Padded layout of the gathered vector: rank g's slice at [g*stride, g*stride + its rows), stride >= the longest slice.
+ * cask_hip_rccl_allgather is then ONE ncclAllGather of `stride` doubles per rank whatever the row partition --
+ * nnz-balanced blocks are always uneven, and the unpadded form is one broadcast per rank -- and d_local must hold
+ * `stride` doubles (cask_hip_solve_device lays its vector slots out with cask_hip_solver_config.stride).  The
+ * block's column indices are remapped to the layout by the caller at plan time.  0 restores the contiguous layout. */
+int cask_hip_rccl_comm_set_stride(cask_hip_comm *comm, int64_t stride);
 
 /* cask_hip_allreduce_fn / cask_hip_exchange_fn with user = the communicator: in-place sum of `count` doubles over
  * the ranks; gather of every rank's slice (uneven: one broadcast per rank inside a group) into d_full.  Both are

@@ -83,7 +83,8 @@ def test_rccl_collectives_run_at_world_one():
            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
                      "--no-cpu-baseline"], env)
-    assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x) issued by the engine") and rec["config"]["launch"] == "eager"
+    assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)") and "issued by the engine" in rec["config"]["exchange"]
+    assert rec["config"]["launch"] == "eager"
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     env["MASTER_PORT"] = str(free_port())
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
@@ -100,12 +101,16 @@ def test_rccl_collectives_run_at_world_one():
 
 def test_config4_webbase_row_partitioned_dry_run():
     """BASELINE configs[3] as bench.py runs it on N GPUs, here 4 ranks sharing the GPU (gloo): one global matrix,
-    nnz-balanced row blocks, the all-gather exchange its halo fraction selects, every rank's rows against the oracle."""
-    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
-                     "--no-cpu-baseline"], SHARE, world=4)
+    nnz-balanced row blocks, the gathered x its halo fraction selects -- pushed peer to peer (the default) and through
+    the collective (forced) -- every rank's rows against the oracle."""
+    args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
+    rec = run_bench(args, SHARE, world=4)
     assert rec["n_gpus"] == 4 and rec["scaling"] == "strong" and rec["config"]["rows"] == 1_000_005
-    assert rec["config"]["exchange"] == "per step: RCCL all_gather(x)"          # gloo dry run: torch.distributed collectives
+    assert rec["config"]["exchange"].startswith("per step: every rank stores its x slice"), rec["config"]["exchange"]
     assert rec["config"]["halo_fraction_max"] > 0.10
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    rec = run_bench(args, dict(SHARE, CASK_BENCH_EXCHANGE="all_gather"), world=4)
+    assert rec["config"]["exchange"] == "per step: RCCL all_gather(x), padded stride: one collective"   # gloo dry run
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
 
 

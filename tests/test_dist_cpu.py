@@ -30,10 +30,14 @@ def _worker(rank, world, port, case, out):
         bounds = case["bounds"]
         lrp, lci, lva = cdist.slice_rows(rp, ci, va, bounds[rank], bounds[rank + 1])
 
-        def local_product(x_full, y_local):
-            y_local.copy_(torch.from_numpy(oracle.csr_spmv(lrp, lci, lva, x_full.numpy())))
+        sh = cdist.ShardedSpmv(bounds, rank, world, None, torch.device("cpu"))
+        lci_pad = sh.pad_columns(lci)                            # columns address the padded gathered vector
 
-        sh = cdist.ShardedSpmv(bounds, rank, world, local_product, torch.device("cpu"))
+        def local_product(x_full, y_local):
+            assert x_full.numel() == sh.n_full == world * sh.S
+            y_local.copy_(torch.from_numpy(oracle.csr_spmv(lrp, lci_pad, lva, x_full.numpy())))
+
+        sh.local_product = local_product
         x = torch.from_numpy(case["x"][bounds[rank]:bounds[rank + 1]].copy())
         y = sh.spmv(x)
         res = {"y": y.numpy().copy(), "dot": float(sh.dot(x, x))}
@@ -47,11 +51,14 @@ def _worker(rank, world, port, case, out):
             nl = bounds[rank + 1] - bounds[rank]
             b = case["b"][bounds[rank]:bounds[rank + 1]].copy()
             ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p).value          # noqa: E731
-            full, scal = np.zeros(n), np.zeros(4)
+            full, scal = np.zeros(sh.n_full), np.zeros(4)
+            slot = np.zeros(sh.S)                                # the engine's operand slot: stride doubles
 
             def product(v):
-                assert exchange(ptr(v), ptr(full), 0) == 0
-                return oracle.csr_spmv(lrp, lci, lva, full)
+                slot[:nl] = v
+                assert exchange(ptr(slot), ptr(full), 0) == 0    # ONE all_gather_into_tensor, no pad / copy steps
+                np.testing.assert_array_equal(sh.unpad(torch.from_numpy(full)).numpy()[bounds[rank]:bounds[rank + 1]], v)
+                return oracle.csr_spmv(lrp, lci_pad, lva, full)
 
             def allsum(v):
                 scal[0] = v

@@ -300,3 +300,31 @@ def synth_small_spd(n=400, seed=6):
     a = sp.csr_matrix(a)
     a.sort_indices()
     return n, a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
+
+
+def test_matrix_dir_files_go_through_the_products_reader(tmp_path, monkeypatch):
+    """$CASK_MATRIX_DIR/<name>.mtx (real SuiteSparse inputs for bench.py / the tools) is read by the product's own
+    reader -- cask::io::readMatrixCached behind libCaskHip.so (cask_amd/hostio.py) -- not by scipy: one committed
+    SuiteSparse fixture (OPF_6000, symmetric, stored lower triangle) stands in for a BASELINE file.  Same CSR as the
+    oracle's reader, the golden product reproduced, and the binary cache written and reused."""
+    import gzip
+    import shutil
+    from cask_amd import hostio, synth
+    from oracle import mmio
+    src = GOLDEN / "matrices" / "OPF_6000.mtx.gz"
+    dst = tmp_path / "cant.mtx"
+    with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+        shutil.copyfileobj(f, g)
+    monkeypatch.setenv("CASK_MATRIX_DIR", str(tmp_path))
+    n, rp, ci, va, source = synth.load_or_make("cant")
+    assert source == str(dst) and n == 29902 and ci.size == 302418          # 166 160 stored entries, mirrored
+    want = mmio.read_matrix(dst)
+    assert np.array_equal(rp, want.row_ptr) and np.array_equal(ci, want.col_ind) and np.array_equal(va, want.values)
+    expected = np.load(GOLDEN / "spmv_expected.npz")
+    key = [k for k in expected.files if "OPF_6000" in k][0]
+    oracle.assert_almost_equal(oracle.csr_spmv(rp, ci, va, mmio.test_vector(n)), expected[key], what="OPF_6000 through IO.hpp")
+    assert (tmp_path / "cant.mtx.csrbin").exists()
+    again = hostio.read_matrix(dst, cached=True)                             # served by the cache
+    assert np.array_equal(again[2], rp) and np.array_equal(again[4], va)
+    with pytest.raises(ValueError):
+        hostio.read_matrix(tmp_path / "missing.mtx")
