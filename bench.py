@@ -724,6 +724,11 @@ def run_spmv(cx, weak):
     torch.cuda.synchronize()
 
     launch_mode = args.launch if exchange not in ("all_gather", "push") else "eager"
+    if exchange == "push" and args.launch in ("auto", "graph") and args.steps % 2 == 0:
+        # the push exchange is plain kernel launches: capturable.  Its two gathered vectors alternate per exchange and
+        # the product's operand pointer is frozen into the graph, so a replay must return to the parity it started
+        # with: an even number of steps
+        launch_mode = "graph"
     if launch_mode == "auto":
         # measured (one box): graph 8.65 / 8.27 us per step at 20 / 1000 steps, sequence 8.47 / 8.51: a graph start
         # costs ~9 us even queued behind another replay, which only a long region amortises
@@ -757,6 +762,9 @@ def run_spmv(cx, weak):
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph, launch_mode = None, "eager"
+        if use_dist and exchange == "push":
+            # every rank must issue the same number of exchanges: agree on the pre-roll (it comes from a local clock)
+            preroll = int(cx.all_reduce_scalar(preroll, dist.ReduceOp.MAX))
     if use_dist and launch_mode == "graph":
         # ranks must agree on the launch mode only for reporting; the timed region has no collective in p2p mode
         launch_mode = "graph" if cx.all_reduce_scalar(1.0 if graph is not None else 0.0, dist.ReduceOp.MIN) > 0.5 \
@@ -920,7 +928,7 @@ def run_solver(cx):
     trp = tci = tva = None
     if kind == "bicg":
         trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
-    if world > 1:
+    if world > 1 or use_dist:                                       # (one forced rank: the sharded code path at world 1)
         from cask_amd import p2p
         lci = cdist.slice_rows(rp, ci, va, bounds[rank], bounds[rank + 1])[1]
         _, halo_cols, _, _ = p2p.plan_halo(lci, bounds, rank)
@@ -994,9 +1002,10 @@ def run_solver(cx):
             "config": {"workload": f"{kind} on the {name}-like system, {n} rows, {nnz} nnz, b = A x0, one step = one pass",
                        "rows": n, "nnz": nnz, "parallelism": f"row-blocks x{world} (nnz-balanced)",
                        "exchange": {"none": "none", "p2p_fused": "halos read inside the product kernels over xGMI; dot products: "
-                                    "RCCL all_reduce of device scalars (2 collectives per pass)",
-                                    "all_gather": "per product: RCCL all_gather of the operand; dot products: RCCL all_reduce"}[exchange],
+                                    "all-reduced device scalars (2 reductions per pass: config.collectives says how)",
+                                    "all_gather": "per product: RCCL all_gather of the operand (padded stride); dot products all-reduced"}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if world > 1 else None,
+                       "pass_form": getattr(sh, "last_pass_form", None),
                        "solve_check": check, "design_point": sh.matrix.params.as_dict(),
                        "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3),
                        "collectives": getattr(sh, "last_collectives", "none")},
@@ -1006,7 +1015,7 @@ def run_solver(cx):
                          "algorithmic_bytes_per_launch": b_it // world, "launch_usec": round(step_us, 3)},
         }
         rec["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_solver(kind, rp, ci, va, b, args.cpu_seconds)
-    if world > 1:
+    if world > 1 or use_dist:
         cx.host_barrier()
         if sht is not None and sht.exchange is sh.exchange:
             sht.exchange = None

@@ -341,6 +341,9 @@ class CsrMatrix:
         if isinstance(allreduce, NativeComm):                  # RCCL issued by the engine itself (include/cask_hip_rccl.h)
             cfg.allreduce = ctypes.cast(load().cask_hip_rccl_allreduce, ALLREDUCE_FN)
             cfg.allreduce_user = allreduce.handle
+        elif type(allreduce).__name__ == "PushExchange":       # peer-store reduction (include/cask_hip_p2p.h): no library
+            cfg.allreduce = ctypes.cast(load().cask_hip_push_allreduce, ALLREDUCE_FN)
+            cfg.allreduce_user = allreduce.handle
         elif allreduce is not None:
             cb = ALLREDUCE_FN(lambda p, c, s, u: int(allreduce(p, c, s) or 0))
             cfg.allreduce = cb

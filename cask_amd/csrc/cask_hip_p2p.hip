@@ -78,9 +78,22 @@ __global__ void k_push_allgather(const double *__restrict__ src, int64_t stride,
   __shared__ int s_last, s_seq;
   const caskhip::dbl2 *s2 = reinterpret_cast<const caskhip::dbl2 *>(src);
   const int64_t n2 = stride >> 1, step = (int64_t)gridDim.x * blockDim.x;
-  for (int g = 0; g < world; g++) {
-    caskhip::dbl2 *dst = reinterpret_cast<caskhip::dbl2 *>(t.full[parity_of_next][g] + (int64_t)rank * stride);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += step) store16_sys(dst + i, s2[i]);
+  // few workgroups, many bytes in flight each: every workgroup ends with an atomic arrival on one counter, and those
+  // serialise at ~12 ns apiece (977 workgroups: 12 us of arrivals for a 2 us copy)
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n2; i0 += 4 * step) {
+    caskhip::dbl2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = s2[min(i0 + u * step, n2 - 1)];
+    for (int g = 0; g < world; g++) {
+      caskhip::dbl2 *dst = reinterpret_cast<caskhip::dbl2 *>(t.full[parity_of_next][g] + (int64_t)rank * stride);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + u * step < n2) {
+          // the own copy is read by this GPU's next launch only: plain stores
+          if (g == rank) dst[i0 + u * step] = v[u];
+          else store16_sys(dst + i0 + u * step, v[u]);
+        }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave, before the barrier
   __syncthreads();
@@ -108,6 +121,66 @@ __global__ void k_push_allgather(const double *__restrict__ src, int64_t stride,
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");               // system scope: nothing cached of what the peers just wrote
+}
+
+// ---- push all-reduce of a few scalars (the dot products of a row-sharded solver pass) --------------------------
+// Same transport as the push all-gather, for 1-4 doubles, and ONE trip per reduction: a contribution travels as a
+// 16-byte granule {value, sequence number} written by one 16-byte system-scope store, so the value's arrival IS its
+// flag (a separate flag costs a second dependent round trip: stores, drain, flag, poll, table loads measured 8 us
+// per reduction on one GPU, more than the 6 us of an RCCL all-reduce).  Thread (g, c) stores this rank's value c
+// into slot [rank][c] of peer g's table and polls slot [g][c] of its own table until the tag is this reduction's
+// number; then one thread per value adds the world contributions IN RANK ORDER -- every rank adds the same numbers
+// in the same order, so every rank holds the same bits and takes the same decisions.  Tables are double-buffered by
+// sequence parity: a peer that is one reduction ahead writes the other half.  (16-byte stores arriving untorn is what
+// MI355X_MICROARCH observes for gfx950; the tag is the second 8 bytes, so a torn granule reads as "not yet".)
+constexpr int PUSH_SCALARS = 4;
+struct alignas(16) PushGranule {
+  double value;
+  long long tag;
+};
+__global__ void k_push_allreduce(double *__restrict__ vals, int count, int rank, int world, PushTables t, int *state) {
+  __shared__ double got[CASK_HIP_PUSH_MAX_WORLD][PUSH_SCALARS];
+  const int g = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const long long seq = (long long)state[3] + 1;
+  const int parity = (int)(seq & 1);
+  // a rank's flag region: int vec_flags[64]; int reserved[64]; PushGranule table[2][64][PUSH_SCALARS]
+  if (g < world && c < count) {
+    const double mine = vals[c];
+    if (g == rank) {
+      got[g][c] = mine;
+    } else {
+      PushGranule *peer = reinterpret_cast<PushGranule *>(t.flags[g] + 2 * CASK_HIP_PUSH_MAX_WORLD) +
+                          ((size_t)parity * CASK_HIP_PUSH_MAX_WORLD + rank) * PUSH_SCALARS + c;
+      caskhip::dbl2 gr;
+      gr.x = mine;
+      gr.y = __longlong_as_double(seq);
+      store16_sys(peer, gr);
+      const PushGranule *own = reinterpret_cast<const PushGranule *>(t.flags[rank] + 2 * CASK_HIP_PUSH_MAX_WORLD) +
+                               ((size_t)parity * CASK_HIP_PUSH_MAX_WORLD + g) * PUSH_SCALARS + c;
+      long long spins = 0;
+      while (true) {
+        caskhip::dbl2 in;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(in) : "v"(own) : "memory");
+        if (__double_as_longlong(in.y) == seq) {
+          got[g][c] = in.x;
+          break;
+        }
+        if (++spins > PUSH_POLL_LIMIT) {
+          state[2] = 1;
+          got[g][c] = 0.0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < count) {
+    double sum = 0.0;
+    for (int r = 0; r < world; r++) sum += got[r][threadIdx.x];
+    vals[threadIdx.x] = sum;
+  }
+  if (threadIdx.x == 0) state[3] = (int)seq;
 }
 
 }  // namespace
@@ -160,15 +233,25 @@ int cask_hip_push_destroy(cask_hip_push *p) {
 int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_full_out, void *stream) {
   if (!p || !d_local || !d_full_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
   if (reinterpret_cast<uintptr_t>(d_local) & 15) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "d_local must be 16-byte aligned");
-  // a few workgroups are enough to keep world links busy; the slice is stride*8 bytes (1 MB at webbase-1M / 8)
+  // stride*8 bytes to each of world destinations (1 MB each at webbase-1M / 8), four 16-byte pairs per lane in flight
   const int64_t pairs = p->stride >> 1;
-  const int grid = (int)std::min<int64_t>(64, std::max<int64_t>(1, (pairs + 1023) / 1024));
+  const int grid = (int)std::min<int64_t>(128, std::max<int64_t>(1, (pairs + 1023) / 1024));
   const int parity = p->parity;
   hipLaunchKernelGGL(k_push_allgather, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_local, p->stride, p->rank,
                      p->world, p->tables, p->d_state, parity);
   P2P_TRY(hipGetLastError());
   *d_full_out = p->tables.full[parity][p->rank];
   p->parity ^= 1;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_push_allreduce(double *d_values, int32_t count, void *stream, void *push) {
+  cask_hip_push *p = static_cast<cask_hip_push *>(push);
+  if (!p || !d_values || count < 1 || count > PUSH_SCALARS)
+    return caskhip::report_failure(CASK_HIP_ERR_INVALID, "push all-reduce takes 1 to 4 doubles");
+  hipLaunchKernelGGL(k_push_allreduce, dim3(1), dim3(4 * CASK_HIP_PUSH_MAX_WORLD), 0, static_cast<hipStream_t>(stream), d_values, (int)count, p->rank,
+                     p->world, p->tables, p->d_state);
+  P2P_TRY(hipGetLastError());
   return CASK_HIP_OK;
 }
 

@@ -166,7 +166,8 @@ class ShardedSpmv:
                                             "cannot run the MERGE kernel (fewer than 2 nonzeros)")
         elif exchange in ("all_gather", "push"):
             obj = cls(bounds, rank, world, None, dev, group)
-            mat = capi.CsrMatrix.from_host(n_local, obj.n_full, rp, obj.pad_columns(ci), va, params)
+            # (one rank: the padded layout is the plain one, and the block stays square for the single-GPU solvers)
+            mat = capi.CsrMatrix.from_host(n_local, obj.n_full if world > 1 else n, rp, obj.pad_columns(ci), va, params)
             obj.local_product = lambda xf, yl: mat.spmv_device(xf, yl)
             if exchange == "push":
                 # the hand-written exchange (include/cask_hip_p2p.h): same padded layout, slices pushed over xGMI
@@ -230,6 +231,18 @@ class ShardedSpmv:
 
     def close(self):
         """Collective: unmap the peers' slices, then free the own one."""
+        sp = getattr(self, "_spush", None)
+        if sp is not None and getattr(self, "_spush_owned", False):
+            import torch.distributed as dist
+            from . import p2p
+            self.torch.cuda.synchronize()
+            for g, p in list(sp.peers.items()):
+                p2p.close_peer(p)
+            sp.peers = {}
+            if dist.is_initialized() and self.world > 1:
+                dist.barrier(group=self.group)
+            sp.close()
+        self._spush = None
         push, self.push = getattr(self, "push", None), None
         if push is not None:
             import torch.distributed as dist
@@ -306,6 +319,42 @@ class ShardedSpmv:
         return comm
 
 
+    def scalar_push(self):
+        """The peer-store all-reduce of the solvers' dot products (include/cask_hip_p2p.h, cask_hip_push_allreduce):
+        a one-wave launch per reduction that stores this rank's partial sums into every peer's scalar table over
+        xGMI and adds the world contributions in rank order -- no collective library in a pass.  OPT-IN
+        (CASK_PEER_ALLREDUCE=1): with the one rank a 1-GPU box allows it measured 3 us per pass SLOWER than the
+        RCCL call it replaces (profiles/r03_solver_collectives.txt: a one-rank RCCL all-reduce has nothing to do), and
+        what it saves over xGMI cannot be measured here.  Created on first use, collectively (every rank must come
+        here); None when some rank cannot map its peers (the solvers then use RCCL)."""
+        import os
+        import torch.distributed as dist
+        if getattr(self, "_spush_tried", False):
+            return self._spush
+        self._spush_tried, self._spush = True, None
+        if not os.environ.get("CASK_PEER_ALLREDUCE") or self.device.type != "cuda":
+            return None
+        if getattr(self, "push", None) is not None:               # the vector exchange's region has the tables too
+            self._spush = self.push
+            return self._spush
+        from . import p2p
+
+        def gather_objects(o):
+            if self.world == 1 and not dist.is_initialized():
+                return [o]
+            out = [None] * self.world
+            dist.all_gather_object(out, o, group=self.group)
+            return out
+        try:
+            self._spush = p2p.PushExchange(self.rank, self.world, 2, self.device, gather_objects)
+            self._spush_owned = True
+        except Exception as e:  # noqa: BLE001 - collective: raised on every rank or on none
+            if self.rank == 0:
+                import sys
+                print(f"[cask_amd.dist] peer-store all-reduce unavailable ({e!r}); using RCCL", file=sys.stderr)
+            self._spush = None
+        return self._spush
+
     def _allreduce_callback(self):
         """``allreduce(ptr, count, stream) -> 0`` for cask_hip_solve_device: sums ``count`` doubles at a device
         address over the ranks of ``self.group``, ordered on torch's current stream (the one the solver runs
@@ -366,8 +415,9 @@ class ShardedSpmv:
         # nccl backend is exercised on a 1-GPU box
         collective = self.world > 1 or (bool(os.environ.get("CASK_FORCE_COLLECTIVES")) and dist.is_initialized())
         native = self.native_comm() if collective else None
+        spush = self.scalar_push() if collective else None
         if collective:
-            kw["allreduce"] = native if native is not None else self._allreduce_callback()
+            kw["allreduce"] = spush if spush is not None else (native if native is not None else self._allreduce_callback())
             if mode == capi.SOLVER_AUTO:
                 # every rank must run the same form of pass (same collectives): composed only if every rank's
                 # design points have the fused dot epilogue (a block with < 2 nonzeros runs the VECTOR kernel)
@@ -375,6 +425,7 @@ class ShardedSpmv:
                 flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
                 mode = capi.SOLVER_COMPOSED if (float(flag[0]) > 0.5 and self.exchange is not None) else capi.SOLVER_CLASSIC
+        self.last_pass_form = {capi.SOLVER_COMPOSED: "composed", capi.SOLVER_CLASSIC: "classic"}.get(mode, "auto")
         ex = self.exchange
         if ex is not None:
             if not getattr(self, "fused_halo", False) or ex.n_slots < (6 if kind == "bicg" else 3):
@@ -386,8 +437,11 @@ class ShardedSpmv:
         elif collective:
             kw.update(exchange=native if native is not None else self._exchange_callback(), n_full=self.n_full,
                       stride=self.S)
-        self.last_collectives = "native RCCL (issued by the engine)" if native is not None else (
-            "torch.distributed callbacks" if collective else "none")
+        self.last_collectives = "none" if not collective else (
+            ("peer-store all-reduce (cask_hip_push_allreduce)" if spush is not None else
+             "native RCCL all-reduce (issued by the engine)" if native is not None else "torch.distributed all-reduce") +
+            ("" if self.exchange is not None else
+             "; operand: native RCCL all-gather" if native is not None else "; operand: torch.distributed all-gather"))
         it, conv, us = self.matrix.solve_device(b_local.contiguous(), x, kind=kind,
                                                 transposed=transposed.matrix if transposed is not None else None,
                                                 mode=mode, maxiters=maxiters, tol=tol, **kw)

@@ -41,7 +41,7 @@ HANDLE_BYTES = 64
 P2P_SYMBOLS = ("cask_hip_shared_alloc", "cask_hip_shared_free", "cask_hip_shared_open", "cask_hip_shared_close",
                "cask_hip_copy_to_device", "cask_hip_copy_to_host", "cask_hip_halo_pull_device",
                "cask_hip_csr_set_halo_sources", "cask_hip_push_create", "cask_hip_push_destroy",
-               "cask_hip_push_allgather", "cask_hip_push_check")
+               "cask_hip_push_allgather", "cask_hip_push_check", "cask_hip_push_allreduce")
 
 
 def _lib():
@@ -60,6 +60,7 @@ def _lib():
         L.cask_hip_push_destroy.argtypes = [vp]
         L.cask_hip_push_allgather.argtypes = [vp, vp, ctypes.POINTER(vp), vp]
         L.cask_hip_push_check.argtypes = [vp]
+        L.cask_hip_push_allreduce.argtypes = [vp, ctypes.c_int32, vp, vp]
         for s in P2P_SYMBOLS:
             getattr(L, s).restype = ctypes.c_int
         L._p2p_bound = True
@@ -284,7 +285,7 @@ class PushExchange:
         x_full = ex.allgather()              # the tensor the product that follows must read (alternates)
     """
 
-    FLAG_DOUBLES = 64                         # room for 128 ints behind the vectors, on a line of its own
+    FLAG_DOUBLES = (2 * 64 * 4 + 2 * 64 * 4 * 16) // 8    # CASK_HIP_PUSH_FLAG_BYTES behind the vectors
 
     def __init__(self, rank, world, stride, device, exchange_objects):
         import torch
@@ -334,6 +335,15 @@ class PushExchange:
         capi._check(_lib().cask_hip_push_allgather(self._h, c_void_p(src.data_ptr()), ctypes.byref(out),
                                                    c_void_p(capi._stream_ptr(stream))))
         return self._full[self._ptr[int(out.value)]]
+
+    def allreduce(self, t, stream=None):
+        """In-place sum of a 1..4-element float64 CUDA tensor over the ranks (one launch, rank-order sum)."""
+        capi._check(_lib().cask_hip_push_allreduce(c_void_p(t.data_ptr()), t.numel(), c_void_p(capi._stream_ptr(stream)),
+                                                   self._h))
+
+    @property
+    def handle(self):
+        return self._h
 
     def check(self):
         """Synchronous: raises if a poll of an earlier exchange timed out."""

@@ -75,15 +75,24 @@ int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint6
  * reports a timeout.  All ranks must issue the same sequence of exchanges.
  *   full_addr   [2 * world] this process's mappings of every rank's first, then second gathered vector
  *               (own entries: the local pointers)
- *   flag_addr   [world] likewise for the flag arrays (zero-initialised: cask_hip_shared_alloc does that)
+ *   flag_addr   [world] likewise for the flag regions: CASK_HIP_PUSH_FLAG_BYTES each, zero-initialised
+ *               (cask_hip_shared_alloc does that), 8-byte aligned
  * Replaces, like the RCCL all-gather, the per-pipe x upload of Spmv::spmv (src/runtime/Spmv.cpp:144-183). */
 #define CASK_HIP_PUSH_MAX_WORLD 64
+/* vector flags [64 ints], reserved [64 ints], scalar tables [2][64][4] of 16-byte {value, sequence} granules */
+#define CASK_HIP_PUSH_FLAG_BYTES (2 * 64 * 4 + 2 * 64 * 4 * 16)
 typedef struct cask_hip_push cask_hip_push;
 int cask_hip_push_create(int32_t rank, int32_t world, int64_t stride, const uint64_t *full_addr, const uint64_t *flag_addr,
                          cask_hip_push **out);
 int cask_hip_push_destroy(cask_hip_push *p);
 int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_full_out, void *stream);
 int cask_hip_push_check(cask_hip_push *p);
+/* In-place sum of 1..4 doubles over the ranks of `push` (a cask_hip_push *), same transport: one one-wave launch on
+ * `stream` stores the values into every peer's scalar table (16-byte {value, sequence number} granules: one trip),
+ * waits for all world contributions and adds them in rank order (every rank ends with the same bits).  Has the type of cask_hip_allreduce_fn: pass it with
+ * allreduce_user = the cask_hip_push to cask_hip_solve_device and a row-sharded CG / BiCG pass needs no collective
+ * library at all (SparseLinearSolvers.hpp:200-232: the dot products of a pass). */
+int cask_hip_push_allreduce(double *d_values, int32_t count, void *stream, void *push);
 
 #ifdef __cplusplus
 }

@@ -86,17 +86,24 @@ def test_rccl_collectives_run_at_world_one():
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)") and "issued by the engine" in rec["config"]["exchange"]
     assert rec["config"]["launch"] == "eager"
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
-    env["MASTER_PORT"] = str(free_port())
+    env.update(MASTER_PORT=str(free_port()))
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
     chk = rec["config"]["solve_check"]
     assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
     assert chk["residual_2norm_by_oracle_product"] <= 2e-5
-    assert rec["config"]["collectives"].startswith("native RCCL")          # ncclAllReduce / ncclAllGather from the engine
-    # ... and the same through the torch.distributed callbacks
+    assert rec["config"]["collectives"].startswith("native RCCL all-reduce")      # ncclAllReduce / ncclAllGather from the engine
+    assert rec["config"]["collectives"].endswith("operand: native RCCL all-gather")
+    # ... the same through the torch.distributed callbacks
     env.update(MASTER_PORT=str(free_port()), CASK_NO_NATIVE_RCCL="1")
     rec2 = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
-    assert rec2["config"]["collectives"] == "torch.distributed callbacks"
+    assert rec2["config"]["collectives"].startswith("torch.distributed all-reduce")
     assert rec2["config"]["solve_check"]["iterations"] == chk["iterations"]
+    # ... and with the dot products reduced by peer stores (opt-in): no all-reduce call in a pass
+    env.pop("CASK_NO_NATIVE_RCCL")
+    env.update(MASTER_PORT=str(free_port()), CASK_PEER_ALLREDUCE="1")
+    rec3 = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
+    assert rec3["config"]["collectives"].startswith("peer-store all-reduce")
+    assert rec3["config"]["solve_check"]["iterations"] == chk["iterations"]
 
 
 def test_config4_webbase_row_partitioned_dry_run():

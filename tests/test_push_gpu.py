@@ -103,3 +103,56 @@ def test_full_size_webbase_in_five_blocks_push():
     matrix = ("full", "webbase-1M")
     res = run_world(5, {"matrix": matrix, "exchange": "push", "products": 3})
     check(res, matrix, 3)
+
+
+def _reduce_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from cask_amd import p2p
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def gather_objects(o):
+            res = [None] * world
+            dist.all_gather_object(res, o)
+            return res
+        ex = p2p.PushExchange(rank, world, 2, torch.device("cuda", 0), gather_objects)
+        rng = np.random.default_rng(100 + rank)
+        got = []
+        for k in range(40):                                    # chained reductions of 1..4 values, values change every time
+            cnt = 1 + k % 4
+            t = torch.from_numpy(rng.standard_normal(cnt) * 10.0 ** (k % 7)).cuda()
+            ex.allreduce(t)
+            got.append(t.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        ex.check()
+        out[rank] = got
+        dist.barrier()
+        for p in ex.peers.values():
+            p2p.close_peer(p)
+        ex.peers = {}
+        dist.barrier()
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 3, 5])
+def test_peer_store_allreduce_same_bits_on_every_rank(world):
+    """cask_hip_push_allreduce: 40 chained reductions; every rank ends with the SAME bits (rank-order sum), equal to
+    the rank-order sum computed on the host."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reduce_worker, args=(world, free_port(), out), nprocs=world, join=True)
+    rngs = [np.random.default_rng(100 + r) for r in range(world)]
+    for k in range(40):
+        cnt = 1 + k % 4
+        parts = [rng.standard_normal(cnt) * 10.0 ** (k % 7) for rng in rngs]
+        want = np.zeros(cnt)
+        for p in parts:                                        # rank order
+            want = want + p
+        for r in range(world):
+            assert np.array_equal(out[r][k], want), (k, r)
