@@ -337,7 +337,18 @@ class CsrMatrix:
         cfg.d_shared_base = shared_base or None
         cfg.stride = stride
         cfg.n_full = n_full
-        keep = []
+        keep, raised = [], []
+
+        def guard(fn):
+            # an exception inside a ctypes callback is printed and swallowed, and C would see 0 = success: the solve
+            # would go on with un-reduced scalars.  Report failure to the engine and re-raise after the call.
+            def wrapped(*a):
+                try:
+                    return int(fn(*a) or 0)
+                except BaseException as e:  # noqa: BLE001
+                    raised.append(e)
+                    return 1
+            return wrapped
         if isinstance(allreduce, NativeComm):                  # RCCL issued by the engine itself (include/cask_hip_rccl.h)
             cfg.allreduce = ctypes.cast(load().cask_hip_rccl_allreduce, ALLREDUCE_FN)
             cfg.allreduce_user = allreduce.handle
@@ -345,21 +356,24 @@ class CsrMatrix:
             cfg.allreduce = ctypes.cast(load().cask_hip_push_allreduce, ALLREDUCE_FN)
             cfg.allreduce_user = allreduce.handle
         elif allreduce is not None:
-            cb = ALLREDUCE_FN(lambda p, c, s, u: int(allreduce(p, c, s) or 0))
+            cb = ALLREDUCE_FN(guard(lambda p, c, s, u: allreduce(p, c, s)))
             cfg.allreduce = cb
             keep.append(cb)
         if isinstance(exchange, NativeComm):
             cfg.exchange = ctypes.cast(load().cask_hip_rccl_allgather, EXCHANGE_FN)
             cfg.exchange_user = exchange.handle
         elif exchange is not None:
-            cb2 = EXCHANGE_FN(lambda a, b, s, u: int(exchange(a, b, s) or 0))
+            cb2 = EXCHANGE_FN(guard(lambda a, b, s, u: exchange(a, b, s)))
             cfg.exchange = cb2
             keep.append(cb2)
         it, conv, us = c_int32(0), c_int32(0), c_double(0)
-        _check(load().cask_hip_solve_device(self._h, transposed._h if transposed is not None else None, byref(cfg),
-                                            c_void_p(b_t.data_ptr()), c_void_p(x_t.data_ptr()), int(maxiters), float(tol),
-                                            byref(it), byref(conv), byref(us), c_void_p(_stream_ptr(stream))))
+        rc = load().cask_hip_solve_device(self._h, transposed._h if transposed is not None else None, byref(cfg),
+                                          c_void_p(b_t.data_ptr()), c_void_p(x_t.data_ptr()), int(maxiters), float(tol),
+                                          byref(it), byref(conv), byref(us), c_void_p(_stream_ptr(stream)))
         del keep
+        if raised:
+            raise raised[0]
+        _check(rc)
         return it.value, bool(conv.value), us.value
 
     def pcg(self, precond, rhs, x0=None, maxiters=2000, tol=1e-5):

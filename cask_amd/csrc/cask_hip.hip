@@ -1668,6 +1668,14 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
   int count = 0, best = -1;
   double best_us = 0.0;
   cask_hip_params best_params{};
+  // Pruning: a family whose two first measured points are both more than 1.5x behind the incumbent is not measured
+  // further (its remaining points are reported with valid = 0, usec = -1).  Round 2: the row-mapped VECTOR family was
+  // 24 of the 40 points and 77-91 % of the sweep's launch time, and wins on no matrix.  CASK_HIP_TUNE_NO_PRUNE=1
+  // measures everything.
+  const bool prune = std::getenv("CASK_HIP_TUNE_NO_PRUNE") == nullptr;
+  int fam_points[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double fam_best[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool fam_pruned[8] = {false, false, false, false, false, false, false, false};
   // Odometer over the ranges, first range fastest (Utils.hpp:173-192); unlike
   // Dse.cpp:40-47 the last point is evaluated too.  lanes only matter for
   // VECTOR and items only for MERGE: irrelevant repeats are skipped.
@@ -1690,6 +1698,13 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             pt.params.items_per_thread = is_merge ? items[iv] : 0;
             pt.params.tile_width = tiles[it];
             pt.params.wg_size = wg_sizes[iw];
+            if (prune && fam_pruned[variant & 7]) {
+              pt.valid = 0;
+              pt.usec = -1.0;                                 // pruned, not measured
+              if (results && count < max_results) results[count] = pt;
+              count++;
+              continue;
+            }
             int rc = CASK_HIP_OK;
             for (cask_hip_matrix *h : rot) {
               rc = build_plan(*h, pt.params);
@@ -1712,6 +1727,10 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                 pt.gbytes_per_s = cold > 0 ? info.algorithmic_bytes / cold * 1e-3 : 0.0;
                 pt.valid = 1;
                 if (best < 0 || cold < best_us) { best = count; best_us = cold; best_params = pt.params; }
+                const int f = variant & 7;
+                fam_points[f]++;
+                if (fam_points[f] == 1 || cold < fam_best[f]) fam_best[f] = cold;
+                if (fam_points[f] >= 2 && fam_best[f] > 1.5 * best_us) fam_pruned[f] = true;
               }
             }
             if (results && count < max_results) results[count] = pt;
@@ -1845,6 +1864,9 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
                           int32_t *converged, double *usec_per_iteration, void *stream) {
   if (!m || !d_rhs || !d_x) return fail(CASK_HIP_ERR_INVALID, "NULL argument");
   if (maxiters < 0 || !(tol >= 0)) return fail(CASK_HIP_ERR_INVALID, "bad maxiters/tol");
+  // the update kernels read and write x and the right-hand side in 16-byte pairs
+  if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_rhs)) & 15)
+    return fail(CASK_HIP_ERR_INVALID, "d_x and d_rhs must be 16-byte aligned");
   cask_hip_solver_config cfg{};
   if (cfg_in) cfg = *cfg_in;
   if (cfg.kind == 0) cfg.kind = CASK_HIP_SOLVER_CG;

@@ -207,6 +207,7 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
     // way: only the stores of chunk k-2 and everything older must have landed before anybody issues chunk k+1's early
     // loads below -- the factor's builder lets a chunk's early loads rely on chunks at least three back.  (Waiting for
     // the write-through stores themselves cost 1.2 us per chunk.)  Both barriers order LDS traffic only.
+    static_assert(PK_PJ == 4, "the vmcnt immediate below counts the PK_PJ = 4 x stores per thread of the previous chunk");
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     lds_barrier();
     store_chunk(cnt, ecnt, scnt);
@@ -607,10 +608,21 @@ struct TriFactor {
     PC_TRY(pk_diag.upload(pdiag));
     PC_TRY(pk_hdr.upload(hdr));
     PC_TRY(pk_seg.upload(seg));
-    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES));
-    PC_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES));
+    // The packed walk needs PK_LDS_BYTES (116 KB) of dynamic LDS: fine on gfx950 (160 KB per CU).  On a device -- or
+    // under an ARCH override -- that cannot give a workgroup that much, every step falls back to the row-indexed walk
+    // (c0 = -1: k_trsv_levels, 5-10x slower, same bits) instead of failing the factorisation.
+    int dev = 0, lds_max = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess &&
+              hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+              lds_max >= (int)PK_LDS_BYTES;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      for (Step &st : steps) st.c0 = -1;
+    }
     return CASK_HIP_OK;
   }
 

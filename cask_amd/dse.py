@@ -119,7 +119,7 @@ def explore(mats, x_t=None, y_t=None, points=None, steps=0, reps=3):
     rows, best = [], None
     for i, pt in enumerate(pts):
         if not pt["valid"]:
-            rows.append({**pt["params"], "valid": False})
+            rows.append({**pt["params"], "valid": False, "pruned": pt["usec"] < 0})
             continue
         us = pt["usec"]
         row = {**pt["params"], "valid": True, "usec": round(us, 3), "usec_warm": round(pt["usec_warm"], 3),

@@ -247,8 +247,10 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
  *              allocations (same stride on every rank).  NULL = private vectors.
  * mode: composed = the product launch composes p = r + beta*p on the fly (2 launches per CG pass, 3 per
  * BiCG pass; needs MERGE plans), classic = product, x/r update and p update are separate launches.
- * d_x holds the initial guess and receives the solution (n_rows entries of this rank).  Every rank takes
- * the same decisions from the same all-reduced scalars. */
+ * d_x holds the initial guess and receives the solution (n_rows entries of this rank); d_x and d_rhs are
+ * 16-byte aligned.  Every rank takes the same decisions from the same all-reduced scalars.  A handle carries ONE
+ * solver workspace (and, per launch, the halo offset of the operand): one solve or product per handle at a time --
+ * distinct handles may be used from distinct threads / streams. */
 #define CASK_HIP_SOLVER_CG        1
 #define CASK_HIP_SOLVER_BICG      2
 #define CASK_HIP_SOLVER_AUTO      0

@@ -229,7 +229,8 @@ def test_size_mismatch_raises_like_the_reference():
     m.close()
 
 
-def test_tune_sweeps_in_reference_order_and_keeps_the_best():
+def test_tune_sweeps_in_reference_order_and_keeps_the_best(monkeypatch):
+    monkeypatch.setenv("CASK_HIP_TUNE_NO_PRUNE", "1")          # every point measured (pruning: the test below)
     n, rp, ci, va = synth.small("cant", factor=8)
     x = mmio.test_vector(n)
     want = oracle.csr_spmv(rp, ci, va, x)
@@ -245,6 +246,20 @@ def test_tune_sweeps_in_reference_order_and_keeps_the_best():
     assert pts[best]["usec"] == min(p["usec"] for p in pts)
     assert m.params.as_dict() == pts[best]["params"]
     oracle.assert_almost_equal(m.spmv(x), want, what="after tune")
+    m.close()
+
+
+def test_tune_prunes_a_family_that_is_far_behind():
+    """a family whose first two measured points are both > 1.5x behind the incumbent is not measured
+    further; its remaining points come back as valid = 0 / usec = -1, the order of the list is unchanged."""
+    n, rp, ci, va = synth.small("cant", factor=4)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[1, 2, 4, 8], tiles=[-1], wg_sizes=[256], items=[8])
+    assert len(pts) == 4 + 1
+    vec = [p for p in pts if p["params"]["variant"] == "vector"]
+    assert [p["valid"] for p in vec[:2]] == [True, True]        # thread / two lanes per 64-nonzero row: far behind merge
+    assert not any(p["valid"] for p in vec[2:]) and all(p["usec"] == -1.0 for p in vec[2:])
+    assert pts[best]["params"]["variant"] == "merge"
     m.close()
 
 
