@@ -14,9 +14,10 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
 
-VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN = 0, 1, 2, 3, 4
+VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN, VARIANT_MERGE_PAIR = 0, 1, 2, 3, 4, 5
+# (merge_pair is a spelling of merge with xcd_remap = 2: handles report "merge")
 VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge",
-                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan"}
+                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan", VARIANT_MERGE_PAIR: "merge_pair"}
 
 # Every symbol include/cask_hip.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = (

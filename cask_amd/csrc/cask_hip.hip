@@ -21,6 +21,7 @@
 #include "spmv_kernels.hpp"
 #ifdef CASK_UNITY   // single-translation-unit build (diagnostic builds: tools/stamps.py)
 #include "scan_launch.hip"
+#include "merge_pair.hip"
 #include "merge_launch_impl.hpp"
 namespace caskhip {
 template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
@@ -84,6 +85,7 @@ struct Plan {
   bool one_window = false;         // every tiled block's chunks are consecutive (KIND_CONTIG): paired window loads
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
+  bool pair_ok = false;            // MERGE: every block is a tiled, 12-bit packed block: the paired-block kernel may run it
   int n_long_rows = 0, n_split_rows = 0;
   DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y
   // far columns (MERGE with slot indices): x values of the nonzeros outside their block's tile, pre-gathered
@@ -152,6 +154,10 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     // Measured on all four BASELINE families (profiles/r01_dse_out.json): the workgroup-level merge
     // kernel wins everywhere; the DSE (cask_hip_tune / cask_amd.dse) refines the shape per matrix.
     out.variant = CASK_HIP_VARIANT_MERGE;
+  }
+  if (out.variant == CASK_HIP_VARIANT_MERGE_PAIR) {           // a spelling of MERGE with paired blocks
+    out.variant = CASK_HIP_VARIANT_MERGE;
+    out.xcd_remap = 2;
   }
   if (out.wg_size == 0) out.wg_size = 256;
   if (!(out.wg_size == 64 || out.wg_size == 128 || out.wg_size == 256 || out.wg_size == 512 ||
@@ -732,6 +738,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.xchunk.release();
   pl.maxch = 0;
   pl.any_skew = false;
+  pl.pair_ok = false;
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
@@ -936,6 +943,11 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       HIP_TRY(pl.blocks.upload(blocks));
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
+    pl.pair_ok = pl.packed12 && !pl.any_skew && pl.n_far == 0 && pl.n_split_rows == 0 && !m.halo_addr &&
+                 prm.nontemporal > 0 && pl.xu > 0 && prm.items_per_thread == 8;
+    for (const BlockDesc &d : blocks)
+      pl.pair_ok = pl.pair_ok && !(d.kind_g & KIND_LONG) && d.cwidth > 0 && d.cwidth <= pl.xu * prm.wg_size;
+    if (pl.prm.xcd_remap == 2 && !pl.pair_ok) pl.prm.xcd_remap = 1;   // reported: the ordinary kernel runs this plan
     // shares of a fused dot (a few KB): allocated with the plan, so that a product with the dot epilogue
     // never allocates -- it may be running under stream capture
     HIP_TRY(pl.dot_part.alloc((size_t)pl.grid + (size_t)pl.n_split_rows));
@@ -1036,7 +1048,10 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.partials = pl.partials.p;
   l.halo = XHalo{m.halo_n_own, m.halo_addr, m.halo_shift};
   l.dot = dot;
-  launch_merge_blocks<IPT>(l, x, y, s);
+  if (IPT == 8 && pl.prm.xcd_remap == 2 && pl.pair_ok && !dot.w && !dot.dot_part && !pass && !m.halo_addr)
+    launch_merge_pair(l, x, y, s);
+  else
+    launch_merge_blocks<IPT>(l, x, y, s);
   if (pl.n_split_rows > 0) {
     // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
     // launch stored (b_new), or the plain vector the pass names (wa without wb)
@@ -1599,12 +1614,12 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                   cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE,
-                                         CASK_HIP_VARIANT_SCAN};
+                                         CASK_HIP_VARIANT_SCAN, CASK_HIP_VARIANT_MERGE_PAIR};
   static const int32_t def_lanes[] = {4, 8, 16, 32};
   static const int32_t def_tiles[] = {-1, 1024, 4096};
   static const int32_t def_wg[] = {256, 512};
   static const int32_t def_items[] = {4, 8};
-  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 4; }
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 5; }
   if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 4; }
   if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 3; }
   if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 2; }
@@ -1687,13 +1702,16 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             const int variant = variants[iva];
             // SCAN: items per thread like the merge kernels; its tile axis is the near margin of the far pre-gather
             const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE ||
-                                  variant == CASK_HIP_VARIANT_SCAN;
+                                  variant == CASK_HIP_VARIANT_SCAN || variant == CASK_HIP_VARIANT_MERGE_PAIR;
+            // the paired-block kernel exists for 8 items per thread and a tile
+            if (variant == CASK_HIP_VARIANT_MERGE_PAIR && (items[iv] != 8 || tiles[it] <= 0)) continue;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
             if (is_merge && il != 0) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel
             cask_hip_tune_point pt{};
             pt.params = saved;
             pt.params.variant = variant;
+            if (variant != CASK_HIP_VARIANT_MERGE_PAIR && pt.params.xcd_remap == 2) pt.params.xcd_remap = 1;
             pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
             pt.params.items_per_thread = is_merge ? items[iv] : 0;
             pt.params.tile_width = tiles[it];

@@ -32,6 +32,8 @@ struct MergeLaunch {
 
 template <int IPT>
 void launch_merge_blocks(const MergeLaunch &l, const double *x, double *y, hipStream_t s);
+// two blocks per workgroup, software-pipelined (merge_pair_kernel.hpp): plans of tiled, 12-bit packed blocks only
+void launch_merge_pair(const MergeLaunch &l, const double *x, double *y, hipStream_t s);
 
 extern template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
 extern template void launch_merge_blocks<4>(const MergeLaunch &, const double *, double *, hipStream_t);

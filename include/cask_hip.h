@@ -38,6 +38,10 @@ extern "C" {
 #define CASK_HIP_VARIANT_VECTOR   1   /* lanes_per_row lanes of a wavefront per row (1 = thread per row) */
 #define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, products and x tile in LDS */
 #define CASK_HIP_VARIANT_MERGE_WAVE 3 /* merge-based, persistent software-pipelined waves (no workgroup barrier, x from L2) */
+#define CASK_HIP_VARIANT_MERGE_PAIR 5 /* MERGE with two blocks per workgroup, the second one's loads in flight while the first
+                                       * one's rows are reduced (half the grid, one round).  A spelling of MERGE with
+                                       * xcd_remap = 2: the handle reports variant MERGE; plans that are not all tiled,
+                                       * 12-bit packed blocks run the ordinary MERGE kernel */
 #define CASK_HIP_VARIANT_SCAN     4   /* nonzero-mapped: equal nonzeros per workgroup, thread-owned runs of products and a
                                        * segmented scan of the carries; no row_ptr stream.  tile_width = x window staged in
                                        * LDS (per block: the densest column range of that width); far_columns = 1 / 2:
@@ -57,7 +61,7 @@ typedef struct cask_hip_params {
   int32_t tile_width;       /* doubles of x staged in LDS per workgroup; -1 = no tile */
   int32_t wg_size;          /* threads per workgroup: 64,128,256,512,1024            */
   int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
-  int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off                 */
+  int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off, 2 = 1 + MERGE_PAIR */
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
   int32_t index16;          /* MERGE with an x tile: 1 = stream tile-relative slot indices instead of 32-bit columns
                              * (12 bits each, packed per thread, where the kernel has that layout; else 16 bits),

@@ -48,6 +48,9 @@ DESIGN_POINTS = [
     dict(variant="scan", items_per_thread=16, wg_size=128, tile_width=300, far_columns=1, xcd_remap=-1),
     dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=-1, far_columns=2),       # far panels by producer workgroups
     dict(variant="scan", items_per_thread=2, wg_size=64, tile_width=128, far_columns=2, nontemporal=-1),
+    dict(variant="merge_pair", tile_width=1024),                                               # two blocks per workgroup
+    dict(variant="merge_pair", tile_width=4096, wg_size=512),
+    dict(variant="merge_pair", tile_width=2048, wg_size=128, xcd_remap=2),
     dict(),   # AUTO / all defaults
 ]
 DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
@@ -547,3 +550,28 @@ def test_scan_fused_far_handoff_with_a_changing_operand():
     oracle.assert_almost_equal(y0.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xs[5].cpu().numpy()), what="scan fused")
     m2.close()
     m0.close()
+
+
+def test_paired_block_kernel_is_taken_and_bit_identical_to_merge():
+    """two merge blocks per workgroup (merge_pair_kernel.hpp) on the plans it exists for -- the
+    cant-like and cant3-like matrices at full size: the handle reports MERGE with xcd_remap = 2, and the product has the
+    bits of the ordinary MERGE kernel on the same plan (same arithmetic, same order).  A plan that does not qualify
+    (power-law rows: untiled and long-row blocks) falls back to the ordinary kernel and says so (xcd_remap = 1)."""
+    for gen in (synth.cant_like, synth.cant3_like):
+        n, rp, ci, va = gen()
+        x = np.random.default_rng(41).uniform(-1, 1, n)
+        want = oracle.csr_spmv(rp, ci, va, x)
+        ys = {}
+        for variant in ("merge", "merge_pair"):
+            m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant=variant, tile_width=1024 if gen is synth.cant_like else 4096))
+            prm = m.params.as_dict()
+            assert prm["variant"] == "merge" and prm["xcd_remap"] == (2 if variant == "merge_pair" else 1), prm
+            ys[variant] = m.spmv(x)
+            assert np.array_equal(ys[variant], m.spmv(x))
+            m.close()
+        oracle.assert_almost_equal(ys["merge_pair"], want, what=gen.__name__)
+        assert np.array_equal(ys["merge"], ys["merge_pair"])
+    n, rp, ci, va = synth.small("webbase-1M", factor=16)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge_pair", tile_width=2048))
+    assert m.params.as_dict()["xcd_remap"] == 1
+    m.close()

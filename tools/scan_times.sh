@@ -1,4 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python tools/family_times.py webbase-1M 'variant=scan,tile_width=4096,far_columns=-1' 'variant=scan,tile_width=-1,far_columns=2' 'variant=scan,tile_width=-1,far_columns=3' 'variant=scan,tile_width=4096,far_columns=3' 'variant=scan,tile_width=-1,far_columns=3,items_per_thread=4' 'variant=scan,tile_width=-1,far_columns=3,wg_size=512' 2>&1 | cut -c1-140
-python tools/family_times.py G3_circuit 'variant=scan,tile_width=-1,far_columns=-1'  'variant=scan,tile_width=-1,far_columns=3' 2>&1 | cut -c1-130
+python tools/family_times.py cant 'variant=merge,tile_width=1024' 'variant=merge_pair,tile_width=1024' 'variant=merge,tile_width=1024' 'variant=merge_pair,tile_width=1024' 'variant=merge_pair,tile_width=1024,wg_size=512' 2>&1 | cut -c1-150
+python tools/family_times.py G3_circuit 'variant=merge' 'variant=merge_pair' 2>&1 | cut -c1-150
+python tools/family_times.py atmosmodd 'variant=merge' 'variant=merge_pair' 2>&1 | cut -c1-150
