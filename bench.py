@@ -429,9 +429,15 @@ def main():
                 if rank == 0:
                     others.append(summarise_other(spec, sub, time.perf_counter() - t0))
             except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
-                if use_dist:
-                    raise                                     # a rank that drops out would strand its peers: fail loudly
                 others.append({"config": spec["config"], "workload": spec["workload"], "error": repr(e)})
+                print(f"[bench] rank {rank}: appended workload {spec['workload']} failed: {e!r}", file=sys.stderr, flush=True)
+                if use_dist:
+                    # this rank has left a collective sequence its peers are still in: it must not enter another one.
+                    # Its line (rank 0) goes out now; the peers' watchdogs end them with the headline intact.
+                    state["done"] = True
+                    if rank == 0:
+                        print(json.dumps(rec), flush=True)
+                    os._exit(0)
         state["done"] = True
         dog.cancel()
     if rank == 0:
