@@ -21,7 +21,7 @@ make build/membench > /dev/null 2>&1
 python3 bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
 cat $out/bench_$tag.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline > $out/prof_$tag.json 2> $out/prof_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline --no-others > $out/prof_$tag.json 2> $out/prof_$tag.err
 # three separate counter passes: FETCH_SIZE, WRITE_SIZE, and the L2->memory read requests split by size
 # (32/64/128 bytes: an exact byte count that needs no correction; the cross-check of the corrected FETCH_SIZE)
 for c in FETCH_SIZE WRITE_SIZE RDREQ; do
@@ -29,7 +29,7 @@ for c in FETCH_SIZE WRITE_SIZE RDREQ; do
   if [ $c = RDREQ ]; then ctr="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; fi
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
   for w in $workloads; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline --no-tune > /dev/null 2> $out/pmc_${tag}_${w}_$c.err
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline --no-tune --no-others > /dev/null 2> $out/pmc_${tag}_${w}_$c.err
   done
 done
 for w in $workloads; do python3 $root/tools/traffic_summary.py $tag $w; done
