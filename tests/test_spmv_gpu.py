@@ -210,13 +210,14 @@ def test_transpose_product():
     n, rp, ci, va = synth.small("webbase-1M", factor=8)
     x = np.random.default_rng(9).uniform(-1, 1, n)
     want = oracle.csr_spmv_t(n, rp, ci, va, x)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
-    xt = torch.from_numpy(x).cuda()
-    yt = torch.empty(n, dtype=torch.float64, device="cuda")
-    m.spmv_transpose_device(xt, yt)
-    torch.cuda.synchronize()
-    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="A^T x")
-    m.close()
+    for dp in (dict(), dict(variant="scan", tile_width=2048), dict(variant="merge_pair", tile_width=1024)):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
+        xt = torch.from_numpy(x).cuda()
+        yt = torch.empty(n, dtype=torch.float64, device="cuda")
+        m.spmv_transpose_device(xt, yt)          # the transpose handle is planned with the same design point
+        torch.cuda.synchronize()
+        oracle.assert_almost_equal(yt.cpu().numpy(), want, what=f"A^T x {dp}")
+        m.close()
 
 
 def test_size_mismatch_raises_like_the_reference():

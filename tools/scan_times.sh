@@ -1,5 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python tools/family_times.py cant 'variant=merge,tile_width=1024' 'variant=merge_pair,tile_width=1024' 'variant=merge,tile_width=1024' 'variant=merge_pair,tile_width=1024' 'variant=merge_pair,tile_width=1024,wg_size=512' 2>&1 | cut -c1-150
-python tools/family_times.py G3_circuit 'variant=merge' 'variant=merge_pair' 2>&1 | cut -c1-150
-python tools/family_times.py atmosmodd 'variant=merge' 'variant=merge_pair' 2>&1 | cut -c1-150
+specs=""
+for wg in 64 128 256 512; do for it in 4 8 16; do specs="$specs variant=merge,tile_width=1024,wg_size=$wg,items_per_thread=$it"; done; done
+python tools/family_times.py cant $specs 2>&1 | grep -v amdgpu | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        r=json.loads(l); p=r['resolved']; print(p['wg_size'], p['items_per_thread'], p['tile_width'], p['index16'], r['usec_cold'], r['grid'], r['lds'])
+    else: print(l.strip()[:200])
+"
