@@ -983,6 +983,34 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   return CASK_HIP_OK;
 }
 
+// The plan of `src` for `dst`, a handle over the SAME matrix in other device arrays (the rotating copies of the
+// DSE's cold timing): every plan array is a function of the sparsity pattern alone, so it is copied device to device
+// instead of being planned again on the host (13 of the 14 plans per design point: most of a sweep's wall time).
+int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
+  Plan &d = dst.plan;
+  const Plan &s = src.plan;
+  if (dst.n_rows != src.n_rows || dst.n_cols != src.n_cols || dst.nnz != src.nnz)
+    return fail(CASK_HIP_ERR_INVALID, "clone_plan: different matrices");
+  d.prm = s.prm; d.grid = s.grid; d.lds_bytes = s.lds_bytes; d.ldsx = s.ldsx; d.xu = s.xu;
+  d.n_blocks = s.n_blocks; d.n_long_blocks = s.n_long_blocks; d.packed12 = s.packed12; d.one_window = s.one_window;
+  d.maxch = s.maxch; d.any_skew = s.any_skew; d.pair_ok = s.pair_ok; d.n_long_rows = s.n_long_rows;
+  d.n_split_rows = s.n_split_rows; d.n_far = s.n_far; d.far_grid = s.far_grid; d.far_panels = s.far_panels;
+  d.scan_far = s.scan_far;
+  HIP_TRY(d.blocks.copy_from(s.blocks)); HIP_TRY(d.long_blocks.copy_from(s.long_blocks));
+  HIP_TRY(d.split_rows.copy_from(s.split_rows)); HIP_TRY(d.partials.copy_from(s.partials));
+  HIP_TRY(d.ci16.copy_from(s.ci16)); HIP_TRY(d.xchunk.copy_from(s.xchunk)); HIP_TRY(d.dot_part.copy_from(s.dot_part));
+  HIP_TRY(d.far_col.copy_from(s.far_col)); HIP_TRY(d.far_dst.copy_from(s.far_dst));
+  HIP_TRY(d.far_col_block.copy_from(s.far_col_block)); HIP_TRY(d.farx.copy_from(s.farx));
+  HIP_TRY(d.xspan.copy_from(s.xspan));
+  HIP_TRY(d.scan_meta.copy_from(s.scan_meta)); HIP_TRY(d.scan_rowmap.copy_from(s.scan_rowmap));
+  HIP_TRY(d.scan_ci.copy_from(s.scan_ci)); HIP_TRY(d.scan_fcol.copy_from(s.scan_fcol));
+  HIP_TRY(d.scan_farx.copy_from(s.scan_farx)); HIP_TRY(d.scan_needs.copy_from(s.scan_needs));
+  HIP_TRY(d.scan_sync.copy_from(s.scan_sync));
+  if (d.scan_sync.p) HIP_TRY(hipMemset(d.scan_sync.p, 0, d.scan_sync.n * sizeof(int)));   // its own hand-off counters
+  d.scan_far.fcol = d.scan_fcol.p;
+  return CASK_HIP_OK;
+}
+
 // ------------------------------------------------------------------ dispatch
 template <int L>
 int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s) {
@@ -1723,11 +1751,8 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
               count++;
               continue;
             }
-            int rc = CASK_HIP_OK;
-            for (cask_hip_matrix *h : rot) {
-              rc = build_plan(*h, pt.params);
-              if (rc) break;
-            }
+            int rc = build_plan(*m, pt.params);
+            for (size_t c = 1; c < rot.size() && rc == CASK_HIP_OK; c++) rc = clone_plan(*rot[c], *m);
             if (rc == CASK_HIP_OK && m->plan.prm.variant == CASK_HIP_VARIANT_VECTOR &&
                 m->plan.prm.wg_size < m->plan.prm.lanes_per_row)
               rc = CASK_HIP_ERR_INVALID;

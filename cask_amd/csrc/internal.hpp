@@ -32,6 +32,16 @@ struct DevBuf {
     return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
   }
   hipError_t upload(const std::vector<T> &h) { return upload(h.data(), h.size()); }
+  // a device copy of another buffer (an empty source leaves this one empty)
+  hipError_t copy_from(const DevBuf<T> &src) {
+    if (!src.p) {
+      release();
+      return hipSuccess;
+    }
+    hipError_t e = alloc(src.n);
+    if (e != hipSuccess || src.n == 0) return e;
+    return hipMemcpy(p, src.p, src.n * sizeof(T), hipMemcpyDeviceToDevice);
+  }
 };
 
 // Owning event (the timing paths return early on errors).
