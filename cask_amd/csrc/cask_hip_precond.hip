@@ -706,11 +706,174 @@ int check_sorted_csr(int32_t n, int64_t nnz, const int32_t *rp, const int32_t *c
 
 }  // namespace
 
+// ---- multicolour ILU(0) (CASK_HIP_PRECOND_ILU0_MC: opt-in, NOT the reference's factors) ----------------------
+// The reference's ILU(0) in natural order chains the rows of a grid-like matrix into tens of thousands of
+// dependency levels (57 436 on the G3_circuit-like system: 32 ms per application, section 8 of DESIGN.md).  A greedy
+// colouring of the matrix graph and the symmetric permutation "colour by colour" make every colour a set of mutually
+// independent rows: ILU(0) of the PERMUTED matrix then solves in 2 x (number of colours) wide launches, one thread
+// per row.  It is a different (usually weaker) preconditioner than natural-order ILU(0) -- a trade of iterations for
+// width -- and is labelled as such everywhere.  Unit lower diagonal (the textbook factorisation).
+struct McFactor {
+  int n = 0, n_colors = 0;
+  std::vector<int> color_ptr;           // rows [color_ptr[c], color_ptr[c+1]) of the permuted order have colour c
+  DevBuf<int> perm;                     // permuted position -> original row
+  DevBuf<int> lrp, lci, urp, uci;       // strict lower / strict upper parts, permuted indices, CSR over permuted rows
+  DevBuf<double> lval, uval, udiag, t, zp;
+};
+
+// forward sweep of one colour: t[i] = r[perm[i]] - sum_k L[i,k] t[k]   (k in earlier colours)
+__global__ void k_mc_forward(int lo, int hi, const int *__restrict__ perm, const int *__restrict__ rp,
+                             const int *__restrict__ ci, const double *__restrict__ val, const double *__restrict__ r,
+                             double *t) {
+  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  double s = r[perm[i]];
+  for (int k = rp[i]; k < rp[i + 1]; k++) s -= val[k] * t[ci[k]];
+  t[i] = s;
+}
+// backward sweep of one colour: zp[i] = (t[i] - sum_k U[i,k] zp[k]) / U[i,i]   (k in later colours); z in natural order
+__global__ void k_mc_backward(int lo, int hi, const int *__restrict__ perm, const int *__restrict__ rp,
+                              const int *__restrict__ ci, const double *__restrict__ val, const double *__restrict__ diag,
+                              const double *__restrict__ t, double *zp, double *__restrict__ z) {
+  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  double s = t[i];
+  for (int k = rp[i]; k < rp[i + 1]; k++) s -= val[k] * zp[ci[k]];
+  s /= diag[i];
+  zp[i] = s;
+  z[perm[i]] = s;
+}
+
+// Greedy colouring in natural order (pattern must be structurally symmetric), permutation, ILU(0) of P A P^T.
+int build_mc(int n, const int *rp, const int *ci, const double *va, McFactor &f) {
+  // structural symmetry (pcg's systems are symmetric; a one-sided edge would make a "colour" dependent inside)
+  {
+    std::vector<int> cnt((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++)
+      for (int k = rp[r]; k < rp[r + 1]; k++) cnt[ci[k] + 1]++;
+    for (int r = 0; r < n; r++) cnt[r + 1] += cnt[r];
+    std::vector<int> tci((size_t)rp[n]), fill(cnt.begin(), cnt.end() - 1);
+    for (int r = 0; r < n; r++)
+      for (int k = rp[r]; k < rp[r + 1]; k++) tci[fill[ci[k]]++] = r;
+    for (int r = 0; r < n; r++) {
+      if (cnt[r + 1] - cnt[r] != rp[r + 1] - rp[r] || !std::equal(tci.begin() + cnt[r], tci.begin() + cnt[r + 1], ci + rp[r]))
+        return report_failure(CASK_HIP_ERR_INVALID, "the multicolour ILU needs a structurally symmetric matrix");
+    }
+  }
+  std::vector<int> color((size_t)n, -1);
+  int n_colors = 0;
+  {
+    std::vector<int> mark;                                     // mark[c] == r: colour c is taken by a neighbour of row r
+    for (int r = 0; r < n; r++) {
+      for (int k = rp[r]; k < rp[r + 1]; k++) {
+        const int c = ci[k] != r ? color[ci[k]] : -1;
+        if (c >= 0) {
+          if ((int)mark.size() <= c) mark.resize(c + 1, -1);
+          mark[c] = r;
+        }
+      }
+      int c = 0;
+      while (c < (int)mark.size() && mark[c] == r) c++;
+      color[r] = c;
+      n_colors = std::max(n_colors, c + 1);
+    }
+  }
+  f.n = n;
+  f.n_colors = n_colors;
+  f.color_ptr.assign((size_t)n_colors + 1, 0);
+  for (int r = 0; r < n; r++) f.color_ptr[color[r] + 1]++;
+  for (int c = 0; c < n_colors; c++) f.color_ptr[c + 1] += f.color_ptr[c];
+  std::vector<int> perm((size_t)n), inv((size_t)n), fill(f.color_ptr.begin(), f.color_ptr.end() - 1);
+  for (int r = 0; r < n; r++) {                                // stable inside a colour: natural order
+    perm[fill[color[r]]] = r;
+    inv[r] = fill[color[r]]++;
+  }
+  // P A P^T in CSR with ascending columns
+  std::vector<int> prp((size_t)n + 1, 0), pci((size_t)rp[n]);
+  std::vector<double> pva((size_t)rp[n]);
+  for (int i = 0; i < n; i++) prp[i + 1] = prp[i] + (rp[perm[i] + 1] - rp[perm[i]]);
+  {
+    std::vector<std::pair<int, double>> row;
+    for (int i = 0; i < n; i++) {
+      const int r = perm[i];
+      row.clear();
+      for (int k = rp[r]; k < rp[r + 1]; k++) row.emplace_back(inv[ci[k]], va[k]);
+      std::sort(row.begin(), row.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+      for (size_t j = 0; j < row.size(); j++) {
+        pci[(size_t)prp[i] + j] = row[j].first;
+        pva[(size_t)prp[i] + j] = row[j].second;
+      }
+    }
+  }
+  // ILU(0), IKJ (the sweep of SparseLinearSolvers.hpp:92-113 on the permuted pattern)
+  std::vector<int> diag((size_t)n, -1);
+  for (int i = 0; i < n; i++)
+    for (int k = prp[i]; k < prp[i + 1]; k++)
+      if (pci[k] == i) diag[i] = k;
+  for (int i = 0; i < n; i++)
+    if (diag[i] < 0) return report_failure(CASK_HIP_ERR_INVALID, "the multicolour ILU needs a stored diagonal in every row");
+  for (int i = 1; i < n; i++) {
+    for (int kk = prp[i]; kk < prp[i + 1]; kk++) {
+      const int k = pci[kk];
+      if (k >= i) break;
+      pva[kk] = pva[kk] / pva[diag[k]];
+      const double beta = pva[kk];
+      int pi = kk + 1, pk = diag[k] + 1;
+      const int ei = prp[i + 1], ek = prp[k + 1];
+      while (pi < ei && pk < ek) {
+        if (pci[pi] < pci[pk]) pi++;
+        else if (pci[pi] > pci[pk]) pk++;
+        else {
+          pva[pi] = pva[pi] - pva[pk] * beta;
+          pi++;
+          pk++;
+        }
+      }
+    }
+  }
+  std::vector<int> lrp((size_t)n + 1, 0), urp((size_t)n + 1, 0), lci, uci;
+  std::vector<double> lval, uval, udiag((size_t)n);
+  for (int i = 0; i < n; i++) {
+    for (int k = prp[i]; k < prp[i + 1]; k++) {
+      if (pci[k] < i) { lci.push_back(pci[k]); lval.push_back(pva[k]); }
+      else if (pci[k] > i) { uci.push_back(pci[k]); uval.push_back(pva[k]); }
+      else udiag[i] = pva[k];
+    }
+    lrp[i + 1] = (int)lci.size();
+    urp[i + 1] = (int)uci.size();
+  }
+  lci.push_back(0); uci.push_back(0); lval.push_back(0.0); uval.push_back(0.0);
+  PC_TRY(f.perm.upload(perm));
+  PC_TRY(f.lrp.upload(lrp)); PC_TRY(f.lci.upload(lci)); PC_TRY(f.lval.upload(lval));
+  PC_TRY(f.urp.upload(urp)); PC_TRY(f.uci.upload(uci)); PC_TRY(f.uval.upload(uval));
+  PC_TRY(f.udiag.upload(udiag));
+  PC_TRY(f.t.alloc((size_t)n)); PC_TRY(f.zp.alloc((size_t)n));
+  return CASK_HIP_OK;
+}
+
+int apply_mc(const McFactor &f, const double *d_r, double *d_z, hipStream_t s) {
+  for (int c = 0; c < f.n_colors; c++) {
+    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
+    if (hi > lo)
+      hipLaunchKernelGGL(k_mc_forward, dim3((hi - lo + 255) / 256), dim3(256), 0, s, lo, hi, f.perm.p, f.lrp.p, f.lci.p, f.lval.p,
+                         d_r, f.t.p);
+  }
+  for (int c = f.n_colors - 1; c >= 0; c--) {
+    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
+    if (hi > lo)
+      hipLaunchKernelGGL(k_mc_backward, dim3((hi - lo + 255) / 256), dim3(256), 0, s, lo, hi, f.perm.p, f.urp.p, f.uci.p,
+                         f.uval.p, f.udiag.p, f.t.p, f.zp.p, d_z);
+  }
+  PC_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
 struct cask_hip_precond {
   int kind = 0, n = 0;
   int device = 0;
   std::vector<double> factored;        // ILU0: the factored values in the input pattern (pc of the reference)
   TriFactor L, U;
+  McFactor mc;                         // ILU0_MC: colour-ordered factors
   DevBuf<double> dinv, tmp, d_r, d_z;  // Jacobi: 1/diag ; ILU0: the intermediate vector ; staging for host vectors
 };
 
@@ -720,7 +883,8 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
                             const double *values, cask_hip_precond **out) {
   if (!out) return report_failure(CASK_HIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
-  if (kind != CASK_HIP_PRECOND_JACOBI && kind != CASK_HIP_PRECOND_ILU0 && kind != CASK_HIP_PRECOND_ILU0_UNIT)
+  if (kind != CASK_HIP_PRECOND_JACOBI && kind != CASK_HIP_PRECOND_ILU0 && kind != CASK_HIP_PRECOND_ILU0_UNIT &&
+      kind != CASK_HIP_PRECOND_ILU0_MC)
     return report_failure(CASK_HIP_ERR_INVALID, "unknown preconditioner kind");
   int rc = check_sorted_csr(n, nnz, row_ptr, col_ind);
   if (rc) return rc;
@@ -738,6 +902,12 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
       for (int k = row_ptr[r]; k < row_ptr[r + 1]; k++)
         if (col_ind[k] == r && values[k] != 0.0) dinv[r] = 1.0 / values[k];
     PC_TRY(p->dinv.upload(dinv));
+    *out = p.release();
+    return CASK_HIP_OK;
+  }
+  if (kind == CASK_HIP_PRECOND_ILU0_MC) {
+    rc = build_mc(n, row_ptr, col_ind, values, p->mc);
+    if (rc) return rc;
     *out = p.release();
     return CASK_HIP_OK;
   }
@@ -791,7 +961,8 @@ int cask_hip_precond_destroy(cask_hip_precond *p) {
 
 int cask_hip_precond_factor_values(const cask_hip_precond *p, double *values_out) {
   if (!p || !values_out) return report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
-  if (p->kind == CASK_HIP_PRECOND_JACOBI) return report_failure(CASK_HIP_ERR_INVALID, "only ILU0 keeps factor values");
+  if (p->kind == CASK_HIP_PRECOND_JACOBI || p->kind == CASK_HIP_PRECOND_ILU0_MC)
+    return report_failure(CASK_HIP_ERR_INVALID, "only the natural-order ILU0 kinds keep factor values in the input pattern");
   if (!p->factored.empty()) std::memcpy(values_out, p->factored.data(), p->factored.size() * sizeof(double));
   return CASK_HIP_OK;
 }
@@ -799,6 +970,12 @@ int cask_hip_precond_factor_values(const cask_hip_precond *p, double *values_out
 int cask_hip_precond_info(const cask_hip_precond *p, int32_t *levels_lower, int32_t *levels_upper,
                           int32_t *launches_per_apply) {
   if (!p) return report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
+  if (p->kind == CASK_HIP_PRECOND_ILU0_MC) {                  // "levels" = colours: one wide launch each
+    if (levels_lower) *levels_lower = p->mc.n_colors;
+    if (levels_upper) *levels_upper = p->mc.n_colors;
+    if (launches_per_apply) *launches_per_apply = 2 * p->mc.n_colors;
+    return CASK_HIP_OK;
+  }
   const bool ilu = p->kind != CASK_HIP_PRECOND_JACOBI;
   if (levels_lower) *levels_lower = ilu ? p->L.n_levels : 0;
   if (levels_upper) *levels_upper = ilu ? p->U.n_levels : 0;
@@ -816,6 +993,7 @@ int cask_hip_precond_apply_device(cask_hip_precond *p, const double *d_r, double
     PC_TRY(hipGetLastError());
     return CASK_HIP_OK;
   }
+  if (p->kind == CASK_HIP_PRECOND_ILU0_MC) return apply_mc(p->mc, d_r, d_z, s);
   // z = U^-1 (L^-1 r)   (ILUPreconditioner::apply, SparseLinearSolvers.hpp:143-151)
   int rc = p->L.solve(d_r, p->tmp.p, s);
   if (rc) return rc;
@@ -872,7 +1050,7 @@ const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p) {
 
 // After a host synchronisation: did a sync-free triangular solve of this preconditioner give up on a dependency?
 int cask_hip_precond_check(cask_hip_precond *p) {
-  if (!p || p->kind == CASK_HIP_PRECOND_JACOBI) return CASK_HIP_OK;
+  if (!p || p->kind == CASK_HIP_PRECOND_JACOBI || p->kind == CASK_HIP_PRECOND_ILU0_MC) return CASK_HIP_OK;
   int e[2] = {0, 0};
   if (p->L.sync.p) PC_TRY(hipMemcpy(&e[0], p->L.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
   if (p->U.sync.p) PC_TRY(hipMemcpy(&e[1], p->U.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));

@@ -297,6 +297,11 @@ typedef struct cask_hip_precond cask_hip_precond;
 #define CASK_HIP_PRECOND_JACOBI    1
 #define CASK_HIP_PRECOND_ILU0      2   /* the reference's: both triangular solves divide by the stored diagonal */
 #define CASK_HIP_PRECOND_ILU0_UNIT 3   /* textbook ILU(0): same factors, L applied with a unit diagonal          */
+#define CASK_HIP_PRECOND_ILU0_MC   4   /* OPT-IN, not the reference's factors: ILU(0) (unit lower diagonal) of the matrix
+                                        * permuted colour by colour (greedy multicolouring of its graph) -- an application
+                                        * is 2 x colours wide launches instead of tens of thousands of dependency levels.
+                                        * Needs a structurally symmetric matrix with a full diagonal; a different, usually
+                                        * weaker preconditioner than natural-order ILU(0)                               */
 int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t *row_ptr,
                             const int32_t *col_ind, const double *values, cask_hip_precond **out);
 int cask_hip_precond_destroy(cask_hip_precond *p);
