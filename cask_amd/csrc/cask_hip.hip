@@ -1733,6 +1733,8 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                                   variant == CASK_HIP_VARIANT_SCAN || variant == CASK_HIP_VARIANT_MERGE_PAIR;
             // the paired-block kernel exists for 8 items per thread and a tile
             if (variant == CASK_HIP_VARIANT_MERGE_PAIR && (items[iv] != 8 || tiles[it] <= 0)) continue;
+            // a block with halo sources runs the MERGE variant only: a winner from another family could not be applied
+            if (saved_halo && variant != CASK_HIP_VARIANT_MERGE) continue;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
             if (is_merge && il != 0) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel

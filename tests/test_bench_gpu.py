@@ -68,7 +68,7 @@ def test_single_rank_line():
 def test_two_rank_dry_run_reads_halos_in_kernel():
     # with the DSE, as the driver launches it: the blocks are tuned with their halo sources attached
     rec = run_bench(["--steps", "20", "--warmup", "4", "--copies", "2", "--no-cpu-baseline"], SHARE, world=2)
-    assert rec["config"]["tune"]["points"] >= 30
+    assert rec["config"]["tune"]["points"] >= 10            # blocks with halo sources: the MERGE family only
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["exchange"].startswith("inside the product kernel"), rec["config"]["exchange"]
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
