@@ -1080,7 +1080,7 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
     launch_merge_pair(l, x, y, s);
   else
     launch_merge_blocks<IPT>(l, x, y, s);
-  if (pl.n_split_rows > 0) {
+  if (pl.n_split_rows > 0 && !(pass && pass->final_only)) {   // (a final_only launch runs no product: nothing to fix up)
     // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
     // launch stored (b_new), or the plain vector the pass names (wa without wb)
     const double *fw = pass ? (dot.dot_part ? (pass->wa && !pass->wb ? pass->wa : pass->b_new) : nullptr) : dot.w;
