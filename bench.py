@@ -683,8 +683,16 @@ def run_spmv(cx, weak):
                     m.set_halo_sources(n_local, None)
                 peer.pull()
     elif exchange == "push":
-        x_local = push.x_slot[:n_local]
-        x_in = push.allgather()
+        # the operand of the benchmark does not change: it sits in place in BOTH gathered vectors (slot [rank]), so an
+        # exchange only stores to the peers -- what a solver whose update kernel writes the slice there would see
+        own = []
+        for _ in range(2):
+            slot = push.own_slot()
+            slot.zero_()
+            slot[:n_local].copy_(torch.from_numpy(x_slice).to(dev))
+            own.append(slot)
+            x_in = push.allgather(slot)
+        x_local = own[0][:n_local]
     elif exchange == "all_gather":
         x_local = gather.x_slot[:n_local]                        # the slice lives where the collective reads it
         x_local.copy_(torch.from_numpy(x_slice).to(dev))
@@ -713,7 +721,7 @@ def run_spmv(cx, weak):
 
     def step(i):
         if exchange == "push":
-            mats[i % copies].spmv_device(push.allgather(), y)    # one exchange launch + the product (vectors alternate)
+            mats[i % copies].spmv_device(push.allgather(push.own_slot()), y)   # one exchange launch + the product
             return
         if exchange == "p2p":
             peer.pull()                                          # remote loads over xGMI, on the launch stream

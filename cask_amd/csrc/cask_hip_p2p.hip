@@ -89,8 +89,9 @@ __global__ void k_push_allgather(const double *__restrict__ src, int64_t stride,
 #pragma unroll
       for (int u = 0; u < 4; u++)
         if (i0 + u * step < n2) {
-          // the own copy is read by this GPU's next launch only: plain stores
-          if (g == rank) dst[i0 + u * step] = v[u];
+          // the own copy is read by this GPU's next launch only: plain stores -- and none at all when the caller
+          // keeps its slice in place (d_local IS slot [rank] of the vector being filled: cask_hip_push_own_slot)
+          if (g == rank) { if (dst != s2) dst[i0 + u * step] = v[u]; }
           else store16_sys(dst + i0 + u * step, v[u]);
         }
     }
@@ -108,7 +109,7 @@ __global__ void k_push_allgather(const double *__restrict__ src, int64_t stride,
   }
   __syncthreads();
   const int seq = s_seq;
-  if ((int)threadIdx.x < world) {
+  if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {   // (the own slice needs no flag: same launch, same memory)
     __hip_atomic_store(t.flags[threadIdx.x] + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int *mine = t.flags[rank] + threadIdx.x;
     long long spins = 0;
@@ -120,7 +121,9 @@ __global__ void k_push_allgather(const double *__restrict__ src, int64_t stride,
       __builtin_amdgcn_s_sleep(4);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");               // system scope: nothing cached of what the peers just wrote
+  // No fence here: the gathered vector is read by the NEXT launch on this stream, which starts behind a kernel
+  // boundary -- its acquire is what keeps lines of the previous exchange out of the way (a system-scope acquire at this
+  // point cost 1.7 us per exchange and protected nothing this launch reads).
 }
 
 // ---- push all-reduce of a few scalars (the dot products of a row-sharded solver pass) --------------------------
@@ -234,10 +237,12 @@ int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_
   if (!p || !d_local || !d_full_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
   if (reinterpret_cast<uintptr_t>(d_local) & 15) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "d_local must be 16-byte aligned");
   // stride*8 bytes to each of world destinations (1 MB each at webbase-1M / 8), four 16-byte pairs per lane in flight
-  const int64_t pairs = p->stride >> 1;
-  const int grid = (int)std::min<int64_t>(128, std::max<int64_t>(1, (pairs + 1023) / 1024));
   const int parity = p->parity;
-  hipLaunchKernelGGL(k_push_allgather, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_local, p->stride, p->rank,
+  // one rank whose slice already sits in place: nothing to move (the launch still advances the sequence number)
+  const bool nothing = p->world == 1 && d_local == p->tables.full[parity][0];
+  const int64_t pairs = nothing ? 0 : p->stride >> 1;
+  const int grid = (int)std::min<int64_t>(128, std::max<int64_t>(1, (pairs + 1023) / 1024));
+  hipLaunchKernelGGL(k_push_allgather, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_local, 2 * pairs, p->rank,
                      p->world, p->tables, p->d_state, parity);
   P2P_TRY(hipGetLastError());
   *d_full_out = p->tables.full[parity][p->rank];
@@ -252,6 +257,12 @@ int cask_hip_push_allreduce(double *d_values, int32_t count, void *stream, void 
   hipLaunchKernelGGL(k_push_allreduce, dim3(1), dim3(4 * CASK_HIP_PUSH_MAX_WORLD), 0, static_cast<hipStream_t>(stream), d_values, (int)count, p->rank,
                      p->world, p->tables, p->d_state);
   P2P_TRY(hipGetLastError());
+  return CASK_HIP_OK;
+}
+
+int cask_hip_push_own_slot(cask_hip_push *p, double **d_slot_out) {
+  if (!p || !d_slot_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
+  *d_slot_out = p->tables.full[p->parity][p->rank] + (int64_t)p->rank * p->stride;
   return CASK_HIP_OK;
 }
 

@@ -41,7 +41,7 @@ HANDLE_BYTES = 64
 P2P_SYMBOLS = ("cask_hip_shared_alloc", "cask_hip_shared_free", "cask_hip_shared_open", "cask_hip_shared_close",
                "cask_hip_copy_to_device", "cask_hip_copy_to_host", "cask_hip_halo_pull_device",
                "cask_hip_csr_set_halo_sources", "cask_hip_push_create", "cask_hip_push_destroy",
-               "cask_hip_push_allgather", "cask_hip_push_check", "cask_hip_push_allreduce")
+               "cask_hip_push_allgather", "cask_hip_push_check", "cask_hip_push_allreduce", "cask_hip_push_own_slot")
 
 
 def _lib():
@@ -61,6 +61,7 @@ def _lib():
         L.cask_hip_push_allgather.argtypes = [vp, vp, ctypes.POINTER(vp), vp]
         L.cask_hip_push_check.argtypes = [vp]
         L.cask_hip_push_allreduce.argtypes = [vp, ctypes.c_int32, vp, vp]
+        L.cask_hip_push_own_slot.argtypes = [vp, ctypes.POINTER(vp)]
         for s in P2P_SYMBOLS:
             getattr(L, s).restype = ctypes.c_int
         L._p2p_bound = True
@@ -335,6 +336,14 @@ class PushExchange:
         capi._check(_lib().cask_hip_push_allgather(self._h, c_void_p(src.data_ptr()), ctypes.byref(out),
                                                    c_void_p(capi._stream_ptr(stream))))
         return self._full[self._ptr[int(out.value)]]
+
+    def own_slot(self):
+        """This rank's slice inside the gathered vector the NEXT exchange fills (``stride`` doubles; alternates): write
+        the slice there and pass it to ``allgather`` to skip the own copy."""
+        out = c_void_p()
+        capi._check(_lib().cask_hip_push_own_slot(self._h, ctypes.byref(out)))
+        full = self._full[self._ptr[int(out.value) - 8 * self.rank * self.stride]]
+        return full[self.rank * self.stride: (self.rank + 1) * self.stride]
 
     def allreduce(self, t, stream=None):
         """In-place sum of a 1..4-element float64 CUDA tensor over the ranks (one launch, rank-order sum)."""

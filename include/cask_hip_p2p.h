@@ -87,6 +87,10 @@ int cask_hip_push_create(int32_t rank, int32_t world, int64_t stride, const uint
 int cask_hip_push_destroy(cask_hip_push *p);
 int cask_hip_push_allgather(cask_hip_push *p, const double *d_local, double **d_full_out, void *stream);
 int cask_hip_push_check(cask_hip_push *p);
+/* Where this rank's slice sits inside the gathered vector the NEXT exchange fills (slot [rank]; it alternates with the
+ * vectors).  A producer that writes its slice there and passes that pointer as d_local saves the own copy: the exchange
+ * then only stores to the peers. */
+int cask_hip_push_own_slot(cask_hip_push *p, double **d_slot_out);
 /* In-place sum of 1..4 doubles over the ranks of `push` (a cask_hip_push *), same transport: one one-wave launch on
  * `stream` stores the values into every peer's scalar table (16-byte {value, sequence number} granules: one trip),
  * waits for all world contributions and adds them in rank order (every rank ends with the same bits).  Has the type of cask_hip_allreduce_fn: pass it with

@@ -33,7 +33,8 @@ def _worker(rank, world, port, case, out):
     try:
         kind = case["matrix"]
         n, rp, ci, va = synth.GENERATORS[kind[1]]() if kind[0] == "full" else synth.small(kind[1], factor=kind[2])
-        sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, exchange=case["exchange"])
+        inplace = case["exchange"] == "push_inplace"           # the slice written where it lives in the gathered vector
+        sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, exchange="push" if inplace else case["exchange"])
         b0, b1 = sh.bounds[rank], sh.bounds[rank + 1]
         rng = np.random.default_rng(77)
         ys, gathered_ok = [], True
@@ -41,17 +42,23 @@ def _worker(rank, world, port, case, out):
         for k in range(case["products"]):
             # the operand changes with every product: a slice that arrives one exchange late shows
             x = rng.uniform(-1, 1, n) + k
-            sh.x_slot[: b1 - b0].copy_(torch.from_numpy(x[b0:b1]).cuda())
-            if case["exchange"] == "all_gather":                 # host-staged collective: order the streams by hand
-                torch.cuda.synchronize()
-            xf = sh.gather_x(sh.x_slot)
+            if inplace:
+                slot = sh.push.own_slot()                        # alternates with the gathered vectors
+                slot[: b1 - b0].copy_(torch.from_numpy(x[b0:b1]).cuda())
+                xf = sh.push.allgather(slot)                     # no own copy: stores to the peers only
+                assert xf.data_ptr() + 8 * rank * sh.S == slot.data_ptr()
+            else:
+                sh.x_slot[: b1 - b0].copy_(torch.from_numpy(x[b0:b1]).cuda())
+                if case["exchange"] == "all_gather":             # host-staged collective: order the streams by hand
+                    torch.cuda.synchronize()
+                xf = sh.gather_x(sh.x_slot)
             sh.local_product(xf, y)
             if k in (0, case["products"] - 1):
                 torch.cuda.synchronize()
                 gathered_ok = gathered_ok and bool(np.array_equal(sh.unpad(xf).cpu().numpy(), x))
                 ys.append((k, y.cpu().numpy().copy()))
         torch.cuda.synchronize()
-        if case["exchange"] == "push":
+        if case["exchange"].startswith("push"):
             sh.push.check()
         out[rank] = {"bounds": (b0, b1), "ys": ys, "gathered_ok": gathered_ok, "S": sh.S}
         dist.barrier()
@@ -89,6 +96,14 @@ def test_push_allgather_uneven_blocks_changing_operand(world):
         assert len({r["bounds"][1] - r["bounds"][0] for r in res}) > 1          # genuinely uneven
     assert res[0]["S"] % 32 == 0
     check(res, matrix, 12)
+
+
+def test_push_allgather_slice_in_place():
+    """cask_hip_push_own_slot: the producer writes its slice where it lives in the gathered vector (it alternates with
+    the two vectors); the exchange then only stores to the peers."""
+    matrix = ("small", "webbase-1M", 16)
+    res = run_world(3, {"matrix": matrix, "exchange": "push_inplace", "products": 9})
+    check(res, matrix, 9)
 
 
 def test_padded_stride_allgather_is_one_collective():
