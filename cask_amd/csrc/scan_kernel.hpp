@@ -8,19 +8,21 @@
 //   * a block is a run of at most CAP = wg_size * items_per_thread nonzeros snapped to row boundaries (row ends
 //     are not items, so a block of 1-nonzero rows still carries CAP nonzeros);
 //   * phase 1 is the merge kernel's: the value / column streams in nonzero order with 16-byte loads, x gathered
-//     from L2, products parked in LDS (the transpose from the striped load order to thread-owned runs);
+//     from L2 (or the window), products parked in LDS, one pad double per run (the transpose from the striped load
+//     order to thread-owned runs);
 //   * phase 2: thread t owns products [t*IPT, (t+1)*IPT).  One 32-bit word per thread, made by the planner, says
 //     which of them end a row (bits 0-15) and the ordinal of the thread's first row end among the block's
 //     non-empty rows (bits 16-31).  The thread adds its run in order and stores every row that ends AND starts
 //     inside the run directly; the sum in front of its first row end ("head") needs what earlier threads left
 //     ("carry"), the sum behind its last one ("tail") is what it leaves;
-//   * carries: a segmented inclusive scan of (has a row end, tail) over the workgroup -- six shuffle steps per
-//     wave, the wave aggregates through LDS.  A row of 500 nonzeros is 62 threads' tails joined by the scan in
+//   * carries: a segmented inclusive scan of (has a row end, tail) over the workgroup -- six DPP steps per wave
+//     (row_shr 1/2/4/8, row_bcast15, row_bcast31: no LDS), the wave aggregates through LDS; row sums are staged in
+//     LDS by ordinal and leave for y in one coalesced sweep.  A row of 500 nonzeros is 62 threads' tails joined by the scan in
 //     log steps: no second pass, no lanes-per-row choice, no skew flag.
 //
 // row_ptr is not read at all (4 bytes per row less than the CSR stream; the per-thread words are 0.5 byte per
-// nonzero at 8 items per thread), and the block needs (CAP + 2) * 8 bytes of LDS -- 16 KB at 256 x 8 -- so eight
-// workgroups fit a CU and the whole grid of a 3 M-nonzero matrix is resident at once.
+// nonzero at 8 items per thread), and without a window the block needs (CAP + wg_size + 4) * 8 bytes of LDS -- 18 KB
+// at 256 x 8 -- so eight workgroups fit a CU and the whole grid of a 3 M-nonzero matrix is resident at once.
 //
 // Every floating-point addition's operands are a function of the plan alone: results are bitwise reproducible.
 // The order differs from the merge kernel's (and from the sequential oracle's), like every parallel row sum here.
@@ -30,9 +32,13 @@
 // plan).  Rows longer than CAP/2 are long-row pieces summed by the whole workgroup (+ the fix-up kernel when a row
 // has several).
 //
-// Far columns (FARX instantiation): the plan keeps its own column stream in which a far nonzero -- one whose column
-// lies outside the part of x its XCD keeps in L2 -- carries ~index into `farx` instead of a column; k_far_panels
-// fills farx column panel by column panel just before this launch (see below).
+// x window (XP > 0) and far columns (FARX > 0): the plan then keeps its own column stream.  A nonzero inside its
+// block's x window (per block the densest column range of <= 2 * XP * wg_size entries, loaded in 16-byte pairs in front
+// of the streams and parked in LDS) carries an LDS slot; a far nonzero -- outside the window and outside the rows its
+// XCD walks, i.e. outside what that XCD's L2 keeps anyway -- carries ~index into `farx`, which is filled column panel
+// by column panel either by k_far_panels just before this launch (FARX == 1) or by producer workgroups of this very
+// launch, handed off through per-producer flags (FARX == 2, below).  Both far forms cut the fabric traffic of the
+// webbase-like matrix from 2.3x to 1.28x the algorithmic bytes and both cost more time than they save.
 //
 // Reference: the always-streaming multiply / reduce pipeline of src/spmv/src/SpmvKernel.java:18-309 and the
 // row-length driven read control of ParallelCsrReadControl.java:148-208 -- whose per-cycle "this entry ends a row"

@@ -16,10 +16,11 @@ struct ScanLaunch {
   int xp;                          // 16-byte x window loads per thread: 0 (no window), 2, 4 or 8; window = 2 * xp * wg_size
   bool nontemporal;
   const BlockDesc *blocks;
-  const int *rp, *ci;              // ci: the caller's columns, or (farx != NULL) the plan's own stream with far references
+  const int *rp, *ci;              // ci: the caller's columns, or the plan's own stream (window slots / far references);
+                                   //   rp is read by KIND_HOLES blocks only (which of their rows are empty)
   const double *val;
   const unsigned *meta;            // [block][thread] row-end words
-  const int *rowmap;               // KIND_HOLES blocks: local row of every row-end ordinal, at blocks[b].aux
+  const int *rowmap;               // KIND_HOLES blocks: at blocks[b].aux the number of non-empty rows, then their local rows
   double *farx;                    // far plans: x values of the far nonzeros, else NULL
   int *sync;                       // fused far pre-gather: producer flags [far.grid] then block epochs [grid]; else NULL
   const int *needs;                //   and per block the producers it waits for, [grid][SCAN_NEEDS]
