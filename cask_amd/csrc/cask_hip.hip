@@ -16,6 +16,7 @@
 
 #include "blas1_kernels.hpp"
 #include "cask_hip.h"
+#include "cask_hip_p2p.h"
 #include "merge_launch.hpp"
 #include "scan_launch.hpp"
 #include "spmv_kernels.hpp"
@@ -2060,6 +2061,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r (and p) is final before the first pass
   if (rc) return rc;
 
+  // the caller reduces by peer stores (cask_hip_push_allreduce): the local sum and the exchange become one launch
+  const bool peer_reduce = st.allreduce == &cask_hip_push_allreduce;
   DevEvent e0, e1;
   HIP_TRY(e0.create()); HIP_TRY(e1.create());
   HIP_TRY(hipEventRecord(e0, s));
@@ -2143,9 +2146,13 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       }
     }
     if (st.sharded) {                                         // p.Ap (pt.q): this rank's share -> scalar -> all ranks
-      hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, dot_part, n_dot, scal.p + SC_DOT, (const double *)nullptr, 0,
-                         (double *)nullptr, (const int *)done);
-      rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
+      if (peer_reduce) {                                      // sum + peer-store all-reduce: one launch
+        rc = cask_hip_push_sum_allreduce(dot_part, n_dot, nullptr, 0, scal.p + SC_DOT, done, s, st.allreduce_user);
+      } else {
+        hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, dot_part, n_dot, scal.p + SC_DOT, (const double *)nullptr, 0,
+                           (double *)nullptr, (const int *)done);
+        rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
+      }
       if (rc) return rc;
       dot_part = scal.p + SC_DOT;
       n_dot = 0;
@@ -2162,9 +2169,14 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     const double *chk_part = part_a.p, *rho_part = part_b.p;
     int n_chk = g;
     if (st.sharded) {                                         // r.r (and rt.r): one collective
-      hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, part_a.p, g, scal.p + SC_RR,
-                         bicg ? (const double *)part_b.p : (const double *)nullptr, g, scal.p + SC_RHO, (const int *)done);
-      rc = run_allreduce(st, scal.p + SC_RR, bicg ? 2 : 1, s);
+      if (peer_reduce) {
+        rc = cask_hip_push_sum_allreduce(part_a.p, g, bicg ? (const double *)part_b.p : (const double *)nullptr, g,
+                                         scal.p + SC_RR, done, s, st.allreduce_user);
+      } else {
+        hipLaunchKernelGGL(k_sum_to_scalars, dim3(1), bw, 0, s, part_a.p, g, scal.p + SC_RR,
+                           bicg ? (const double *)part_b.p : (const double *)nullptr, g, scal.p + SC_RHO, (const int *)done);
+        rc = run_allreduce(st, scal.p + SC_RR, bicg ? 2 : 1, s);
+      }
       if (rc) return rc;
       chk_part = scal.p + SC_RR;
       rho_part = scal.p + SC_RHO;

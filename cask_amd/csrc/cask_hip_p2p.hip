@@ -141,14 +141,16 @@ struct alignas(16) PushGranule {
   double value;
   long long tag;
 };
-__global__ void k_push_allreduce(double *__restrict__ vals, int count, int rank, int world, PushTables t, int *state) {
-  __shared__ double got[CASK_HIP_PUSH_MAX_WORLD][PUSH_SCALARS];
+// The exchange proper, for a workgroup of 4 * CASK_HIP_PUSH_MAX_WORLD threads: vals[c] (c < count) of this rank in,
+// the rank-order sum over all ranks out (through `got`, LDS).
+__device__ __forceinline__ void push_reduce(const double *mine_vals, double *out, int count, int rank, int world,
+                                            const PushTables &t, int *state, double (*got)[PUSH_SCALARS]) {
   const int g = threadIdx.x >> 2, c = threadIdx.x & 3;
   const long long seq = (long long)state[3] + 1;
   const int parity = (int)(seq & 1);
   // a rank's flag region: int vec_flags[64]; int reserved[64]; PushGranule table[2][64][PUSH_SCALARS]
   if (g < world && c < count) {
-    const double mine = vals[c];
+    const double mine = mine_vals[c];
     if (g == rank) {
       got[g][c] = mine;
     } else {
@@ -181,9 +183,36 @@ __global__ void k_push_allreduce(double *__restrict__ vals, int count, int rank,
   if ((int)threadIdx.x < count) {
     double sum = 0.0;
     for (int r = 0; r < world; r++) sum += got[r][threadIdx.x];
-    vals[threadIdx.x] = sum;
+    out[threadIdx.x] = sum;
   }
   if (threadIdx.x == 0) state[3] = (int)seq;
+}
+
+__global__ void k_push_allreduce(double *__restrict__ vals, int count, int rank, int world, PushTables t, int *state) {
+  __shared__ double got[CASK_HIP_PUSH_MAX_WORLD][PUSH_SCALARS];
+  __shared__ double mine[PUSH_SCALARS];
+  if ((int)threadIdx.x < count) mine[threadIdx.x] = vals[threadIdx.x];
+  __syncthreads();
+  push_reduce(mine, vals, count, rank, world, t, state, got);
+}
+
+// The solver's "sum this rank's partial sums, then all-reduce" as ONE launch (it was k_sum_to_scalars + the reduction):
+// out[0] = all-rank sum of sum(pa[0..na)), out[1] likewise for pb when given.  Nothing happens once *done is set (every
+// rank sees the same flag, so every rank skips the same exchanges).
+__global__ void k_push_sum_allreduce(const double *__restrict__ pa, int na, const double *__restrict__ pb, int nb,
+                                     double *__restrict__ out, const int *done, int rank, int world, PushTables t, int *state) {
+  __shared__ double got[CASK_HIP_PUSH_MAX_WORLD][PUSH_SCALARS];
+  __shared__ double mine[PUSH_SCALARS];
+  __shared__ double red[16];
+  if (done && *done) return;
+  const double a = caskhip::sum_partials(pa, na, red);
+  if (threadIdx.x == 0) mine[0] = a;
+  if (pb) {
+    const double b = caskhip::sum_partials(pb, nb, red);
+    if (threadIdx.x == 0) mine[1] = b;
+  }
+  __syncthreads();
+  push_reduce(mine, out, pb ? 2 : 1, rank, world, t, state, got);
 }
 
 }  // namespace
@@ -263,6 +292,17 @@ int cask_hip_push_allreduce(double *d_values, int32_t count, void *stream, void 
 int cask_hip_push_own_slot(cask_hip_push *p, double **d_slot_out) {
   if (!p || !d_slot_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
   *d_slot_out = p->tables.full[p->parity][p->rank] + (int64_t)p->rank * p->stride;
+  return CASK_HIP_OK;
+}
+
+// between cask_hip.hip (the solver) and this file: the fused form of k_sum_to_scalars + cask_hip_push_allreduce
+int cask_hip_push_sum_allreduce(const double *d_pa, int na, const double *d_pb, int nb, double *d_out, const int *d_done,
+                                void *stream, void *push) {
+  cask_hip_push *p = static_cast<cask_hip_push *>(push);
+  if (!p || !d_pa || !d_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
+  hipLaunchKernelGGL(k_push_sum_allreduce, dim3(1), dim3(4 * CASK_HIP_PUSH_MAX_WORLD), 0, static_cast<hipStream_t>(stream), d_pa,
+                     na, d_pb, nb, d_out, d_done, p->rank, p->world, p->tables, p->d_state);
+  P2P_TRY(hipGetLastError());
   return CASK_HIP_OK;
 }
 

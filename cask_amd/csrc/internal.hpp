@@ -65,3 +65,8 @@ int cask_hip_precond_rows(const cask_hip_precond *p);      // order of the matri
 int cask_hip_precond_check(cask_hip_precond *p);           // after a host sync: error flag of the sync-free triangular solves
 // Jacobi: the device vector of 1/diag (the PCG driver folds the scaling into its update kernels); NULL otherwise
 const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p);
+
+// Between cask_hip.hip (the solver passes) and cask_hip_p2p.hip: "sum this rank's partial sums, then all-reduce" in one
+// launch, when the all-reduce callback IS cask_hip_push_allreduce.
+extern "C" int cask_hip_push_sum_allreduce(const double *d_pa, int na, const double *d_pb, int nb, double *d_out,
+                                           const int *d_done, void *stream, void *push);

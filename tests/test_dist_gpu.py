@@ -41,6 +41,8 @@ def _worker(rank, world, port, case, out):
     from cask_amd import capi
     from cask_amd import dist as cdist
     torch.cuda.set_device(0)
+    if case.get("peer_allreduce"):                 # dot products reduced by peer stores (cask_hip_push_allreduce), opt-in
+        os.environ["CASK_PEER_ALLREDUCE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n, rp, ci, va = _matrix(case["matrix"])
@@ -82,6 +84,7 @@ def _worker(rank, world, port, case, out):
                 torch.cuda.synchronize()
                 res[f"x{mode}"], res[f"it{mode}"], res[f"conv{mode}"] = xs.cpu().numpy(), it, conv
                 res[f"us{mode}"] = sh.last_usec_per_iteration
+                res["collectives"] = sh.last_collectives
                 fence()
         if case.get("chain"):
             # a product whose operand changes every time: x_{k+1} = y_k / 4 + x_k, every rank rewriting its shared
@@ -330,3 +333,28 @@ def test_sharded_solvers_with_a_nonzero_initial_guess(exchange):
     got = np.concatenate([r["x0"] for r in res])
     assert want_conv and all(r["conv0"] for r in res) and all(abs(r["it0"] - want_it) <= 1 for r in res)
     np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("solver", ["cg", "bicg"])
+def test_sharded_solvers_with_peer_store_allreduce(solver):
+    """CASK_PEER_ALLREDUCE=1: the dot products of a row-sharded pass are summed locally and reduced across the ranks by
+    ONE launch (k_push_sum_allreduce: 16-byte {value, sequence} granules stored into every peer's table, rank-order sum)
+    -- no collective library in the pass.  Three ranks, composed passes over in-kernel halos; iteration counts and the
+    solution against the oracle, every rank stopping in the same pass."""
+    spec = ("small", "G3_circuit", 64) if solver == "cg" else ("small", "atmosmodd", 64)
+    n, rp, ci, va = _matrix(spec)
+    x0 = np.random.default_rng(5).uniform(-1, 1, n)
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    tol = 1e-5 if solver == "cg" else 1e-9
+    want, want_it, want_conv = (oracle.cg_full(rp, ci, va, b) if solver == "cg" else oracle.bicg(rp, ci, va, b, tol=tol))
+    case = {"matrix": spec, "exchange": "p2p", "b": "A*x0", "peer_allreduce": True}
+    if solver == "bicg":
+        case.update(solver="bicg", tol=tol)
+    else:
+        case["modes"] = (0,)
+    res = run_world(3, case)
+    got = np.concatenate([r["x0"] for r in res])
+    assert want_conv and all(r["conv0"] for r in res)
+    assert all(abs(r["it0"] - want_it) <= 2 for r in res) and len({r["it0"] for r in res}) == 1
+    assert all(r.get("collectives", "").startswith("peer-store") for r in res), [r.get("collectives") for r in res]
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(want).max()))
