@@ -466,7 +466,7 @@ def summarise_other(spec, sub, seconds):
            "unit": sub["unit"], "usec": roof["launch_usec"], "steps": sub["steps"], "scaling": sub["scaling"],
            "frac": roof["frac"], "hbm_gbs_algorithmic_per_gpu": roof["achieved"],
            "algorithmic_bytes_per_step_per_gpu": roof["algorithmic_bytes_per_launch"],
-           "traffic": roof.get("traffic"), "exchange": c.get("exchange"), "design_point": c.get("design_point"),
+           "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "exchange": c.get("exchange"), "design_point": c.get("design_point"),
            "seconds_in_bench": round(seconds, 1)}
     if "solve_check" in c:
         out["solve_check"] = c["solve_check"]
@@ -506,14 +506,24 @@ def timed_region(cx, run_steps, lead_in=None):
     return dev_ms, wall
 
 
-def traffic_record(workload):
-    """Counter-measured HBM bytes per launch of an earlier profiled run of the same workload (not measured here)."""
-    tfile = REPO / "profiles" / f"traffic_{workload}.json"
-    if tfile.exists():
+def traffic_record(workload, design=None):
+    """Counter-measured HBM bytes per launch of an earlier profiled run of the same workload (not measured here): the file
+    keyed by THIS design point if one was profiled (tools/pmc_point.sh, tools/dse_evidence.py), else the AUTO plan's."""
+    names = []
+    if design:
+        label = f'{design["variant"]}_w{design["wg_size"]}_i{design["items_per_thread"]}_t{design["tile_width"]}' \
+                f'_l{design["lanes_per_row"]}'.replace("-", "m")
+        names.append((f"traffic_{workload}_{label}.json", True))
+    names.append((f"traffic_{workload}.json", False))
+    for name, exact in names:
+        tfile = REPO / "profiles" / name
+        if not tfile.exists():
+            continue
         try:
             t = json.loads(tfile.read_text())
-            return t.get("hbm_bytes_per_launch"), f"profiles/{tfile.name} (rocprofv3 PMC passes of round {t.get('tag', '?')}, " \
-                                                  "FETCH_SIZE x calibration + WRITE_SIZE; not measured in this run)"
+            note = "this design point" if exact else "the AUTO design point of that round"
+            return t.get("hbm_bytes_per_launch"), f"profiles/{tfile.name} (rocprofv3 PMC passes of round {t.get('tag', '?')} at " \
+                                                  f"{note}, FETCH_SIZE x calibration + WRITE_SIZE; not measured in this run)"
         except Exception:
             pass
     return None, None
@@ -852,7 +862,7 @@ def run_spmv(cx, weak):
         step_us = dev_ms * 1e3 / args.steps                # ONE clock: HIP events on the launch stream, max over ranks
         gflops = 2.0 * nnz_total / step_us * 1e-3
         achieved = alg_bytes / (step_us * 1e-6) / 1e9      # this rank's launch: its algorithmic bytes / the step time
-        traffic, traffic_source = traffic_record(args.workload) if world == 1 else (None, None)
+        traffic, traffic_source = traffic_record(args.workload, design) if world == 1 else (None, None)
         like = {"cant": "cant-like", "cant3": "cant-like (3x3 node blocks, non-uniform band)"}.get(args.workload, args.workload + "-like")
         rec = {
             "metric": f"SpMV GFLOP/s (fp64 CSR, 2*nnz/t), SuiteSparse {like}", "value": round(gflops, 2),
