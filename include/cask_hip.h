@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 3
+#define CASK_HIP_ABI_VERSION 4   /* 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
 
 /* status codes */
 #define CASK_HIP_OK               0
