@@ -152,9 +152,11 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   out = in;
   const double mean = m.n_rows ? (double)m.nnz / m.n_rows : 0.0;
   if (out.variant == CASK_HIP_VARIANT_AUTO) {
-    // Measured on all four BASELINE families (profiles/r01_dse_out.json): the workgroup-level merge
-    // kernel wins everywhere; the DSE (cask_hip_tune / cask_amd.dse) refines the shape per matrix.
+    // Measured on all four BASELINE families (profiles/r01_dse_out.json, r03_dse_out.json): the workgroup-level merge
+    // kernel wins on three; short, heavily skewed rows (webbase-1M-like: mean 3, longest 4 700) are the segmented-scan
+    // kernel's (21.6 against 24.1 us).  The DSE (cask_hip_tune / cask_amd.dse) refines the choice per matrix.
     out.variant = CASK_HIP_VARIANT_MERGE;
+    if (!m.halo_addr && mean < 4.0 && m.max_row > 256 && m.nnz >= (1 << 20)) out.variant = CASK_HIP_VARIANT_SCAN;
   }
   if (out.variant == CASK_HIP_VARIANT_MERGE_PAIR) {           // a spelling of MERGE with paired blocks
     out.variant = CASK_HIP_VARIANT_MERGE;
