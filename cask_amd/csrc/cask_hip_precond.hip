@@ -345,6 +345,223 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
   }
 }
 
+// ---- packed walk, one walker wave (round 3) ------------------------------------------------------------------------
+// k_trsv_packed pays ~500 cycles per level: the four waves take the levels in turn, every level ends in a workgroup
+// barrier, and the three preparation steps of a level (bounds -> right-hand side and entry range -> entries: dependent
+// LDS reads that do NOT depend on x) are done level by level by the waves whose turn it is not.  Here the preparation
+// moves to staging time and the barriers out of the walk:
+//   * after a chunk is staged, all 256 threads REPACK it: position idx gets a 48-byte record {b, diagonal | first two
+//     entry values | their x sources, entry count, first entry} -- three dependent LDS reads per position, once per
+//     chunk, in parallel, instead of once per level on the critical path;
+//   * wave 0 alone walks the chunk's levels: per level one read of the records (three 16-byte reads per lane, independent
+//     of x), the x reads, the row's FMAs in stored order, the ring write.  No barrier: the LDS operations of one wave
+//     execute in order, so a level's x reads see the previous level's ring writes.  The other waves wait at the barrier
+//     that ends the chunk, with the next chunk's prefetch in their registers.
+// Same arithmetic in the same order as k_trsv_packed (and as solve_row): bit-identical results (tested).
+// MEASURED (profiles/r03_trsv.txt, one ILU(0) application): G3_circuit-like 36.5 ms against 32.2 for the four-wave walk,
+// atmosmodd-like 3.52 vs 3.33, cant-like 27.6-32.7 vs 31.3-31.6 -- it LOSES where the levels are narrow and the rows
+// short: one wave issues every instruction of a level itself (~60 of them: records, addresses, the FMAs, an fp64
+// division in the upper solve, the register rotation of the software pipeline) at 4-8 cycles apiece, ~600-700 cycles
+// per level, where the four-wave walk spreads the preparation over three other SIMDs and pays ~500-670 with its
+// barrier.  Opt-in (CASK_HIP_TRSV=walk1); the four-wave walk stays the default.
+constexpr size_t PK1_LDS_BYTES = sizeof(double) * (PK_RING + 2 * PK_ECAP) + 48 * (size_t)PK_CH +
+                                 sizeof(int) * (PK_ECAP + (PK_CH + 1) + (PK_CH + 1));
+typedef double pk_dbl2 __attribute__((ext_vector_type(2)));
+typedef int pk_int4 __attribute__((ext_vector_type(4)));
+
+template <bool LONG>
+__global__ void __launch_bounds__(PK_T)
+k_trsv_walk1(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b, double *x) {
+  extern __shared__ double pk_lds[];
+  double *ring = pk_lds;
+  double *s_val = ring + PK_RING, *s_x = s_val + PK_ECAP;     // (s_src holds byte offsets that assume this order)
+  pk_dbl2 *R0 = reinterpret_cast<pk_dbl2 *>(s_x + PK_ECAP);   // {b[row], diagonal}
+  pk_dbl2 *R1 = R0 + PK_CH;                                   // {value of entry 0, of entry 1}
+  pk_int4 *R2 = reinterpret_cast<pk_int4 *>(R1 + PK_CH);      // {x source of entry 0, of entry 1, entries, first entry}
+  int *s_src = reinterpret_cast<int *>(R2 + PK_CH);
+  int *s_e = s_src + PK_ECAP;
+  int *s_seg = s_e + PK_CH + 1;
+  const char *lds_bytes = reinterpret_cast<const char *>(pk_lds);
+  const int tid = threadIdx.x;
+
+  int r_row[PK_PJ], r_e[PK_PJ + 1], r_seg[PK_PJ + 1];
+  double r_diag[PK_PJ], r_b[PK_PJ], r_val[PK_EJ], r_x[PK_EJ];
+  unsigned r_code[PK_EJ];
+  int4 h0, h1;
+  int w_row[PK_PJ];
+
+  auto load_chunk = [&](int cs, int cnt, int ebase, int ecnt, int sbase, int scnt) {
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_row[j] = t.row[cs + min(tid + PK_T * j, cnt - 1)];
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) r_code[j] = t.code[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_diag[j] = t.diag[cs + min(tid + PK_T * j, cnt - 1)];
+#pragma unroll
+    for (int j = 0; j < PK_PJ + 1; j++) {
+      r_e[j] = t.eptr[cs + min(tid + PK_T * j, cnt)] - ebase;
+      r_seg[j] = t.seg[sbase + min(tid + PK_T * j, scnt - 1)] - cs;
+    }
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) r_val[j] = t.val[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) r_b[j] = b[r_row[j]];
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) {
+      const bool early = tid + PK_T * j < ecnt && !(r_code[j] & PK_NEAR);
+      r_x[j] = __hip_atomic_load(x + (early ? r_code[j] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto store_chunk = [&](int cnt, int ecnt, int scnt) {
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < cnt) {
+        pk_dbl2 r0;
+        r0.x = r_b[j];
+        r0.y = r_diag[j];
+        R0[idx] = r0;
+      }
+      w_row[j] = r_row[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PK_PJ + 1; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx <= cnt) s_e[idx] = r_e[j];
+      if (idx < scnt) s_seg[idx] = r_seg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PK_EJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < ecnt) {
+        s_src[idx] = (r_code[j] & PK_NEAR) ? (int)((r_code[j] & (PK_RING - 1)) * 8u)
+                                           : (int)((PK_RING + PK_ECAP + idx) * 8);
+        s_val[idx] = r_val[j];
+        s_x[idx] = r_x[j];
+      }
+    }
+  };
+  // the per-position records: what the four-wave walk's `rows` and `entries` steps read level by level
+  auto repack = [&](int cnt) {
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) {
+      const int idx = tid + PK_T * j;
+      if (idx < cnt) {
+        const int e0 = s_e[idx], ne = s_e[idx + 1] - e0;
+        const int ea = e0, eb = e0 + min(1, max(ne - 1, 0));   // (an absent entry repeats the last one: never used)
+        pk_dbl2 r1;
+        pk_int4 r2;
+        r1.x = s_val[ea];
+        r1.y = s_val[eb];
+        r2.x = s_src[ea];
+        r2.y = s_src[eb];
+        r2.z = ne;
+        r2.w = e0;
+        R1[idx] = r1;
+        R2[idx] = r2;
+      }
+    }
+  };
+
+  h0 = t.hdr[2 * c0];
+  h1 = t.hdr[2 * c0 + 1];
+  int cs = uniform(h0.x), cnt = uniform(h0.y), ebase = uniform(h0.z), ecnt = uniform(h0.w), sbase = uniform(h1.x),
+      scnt = uniform(h1.y);
+  load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
+  if (c0 + 1 < c1) {
+    h0 = t.hdr[2 * c0 + 2];
+    h1 = t.hdr[2 * c0 + 3];
+  }
+  for (int k = c0; k < c1; k++) {
+    // (the ordering of x stores against the next chunks' early loads: exactly as in k_trsv_packed)
+    static_assert(PK_PJ == 4, "the vmcnt immediate below counts the PK_PJ = 4 x stores per thread of the previous chunk");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    lds_barrier();
+    store_chunk(cnt, ecnt, scnt);
+    const int cur_cs = cs, n_pos = cnt, n_seg = scnt;
+    lds_barrier();
+    repack(n_pos);
+    if (k + 1 < c1) {
+      cs = uniform(h0.x); cnt = uniform(h0.y); ebase = uniform(h0.z); ecnt = uniform(h0.w);
+      sbase = uniform(h1.x); scnt = uniform(h1.y);
+      load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
+      if (k + 2 < c1) {
+        h0 = t.hdr[2 * k + 4];
+        h1 = t.hdr[2 * k + 5];
+      }
+    }
+    lds_barrier();                                            // the records are complete
+    if (tid < 64) {                                           // the walker wave; no barrier until the chunk is done
+      constexpr int PK_U = 16;
+      const int lane = tid;
+      // Software pipeline: while level lv is solved (x reads -> FMAs -> ring write: the only work that depends on the
+      // previous level), the records of level lv + 1 and the bound of level lv + 2 are already requested -- neither
+      // depends on x.  LDS operations of one wave retire in order, so waiting for the older requests never waits for
+      // a younger one.
+      auto solve_one = [&](int idx, const pk_dbl2 &r0, const pk_dbl2 &r1, const pk_int4 &r2) {
+        const int ne = r2.z, e0 = r2.w;
+        const double x0 = *reinterpret_cast<const double *>(lds_bytes + r2.x);
+        const double x1 = *reinterpret_cast<const double *>(lds_bytes + r2.y);
+        double sacc = r0.x;
+        if (0 < ne) sacc -= r1.x * x0;
+        if (1 < ne) sacc -= r1.y * x1;
+        if constexpr (!LONG) {
+          for (int e = e0 + 2; e < e0 + ne; e++)
+            sacc -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
+        } else {
+          for (int e = e0 + 2; e < e0 + ne; e += PK_U) {
+            double v4[PK_U], x4[PK_U];
+            int a4[PK_U];
+#pragma unroll
+            for (int u = 0; u < PK_U; u++) {
+              const int eu = min(e + u, e0 + ne - 1);
+              a4[u] = s_src[eu];
+              v4[u] = s_val[eu];
+            }
+#pragma unroll
+            for (int u = 0; u < PK_U; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+#pragma unroll
+            for (int u = 0; u < PK_U; u++)
+              if (e + u < e0 + ne) sacc -= v4[u] * x4[u];
+          }
+        }
+        ring[(cur_cs + idx) & (PK_RING - 1)] = unit ? sacc : sacc / r0.y;
+      };
+      int l_lo = 0, l_hi = uniform(s_seg[0]);
+      int hi_next = s_seg[min(1, n_seg - 1)];                 // requested now, read (as a uniform) one level later
+      pk_dbl2 c0r = {0.0, 1.0}, c1r = {0.0, 0.0};
+      pk_int4 c2r = {0, 0, 0, 0};
+      {
+        const int idx = min(lane, max(l_hi - 1, 0));
+        c0r = R0[idx]; c1r = R1[idx]; c2r = R2[idx];
+      }
+      for (int lv = 0; lv < n_seg; lv++) {
+        // the next level's first 64 records (clamped into the chunk: lanes past the level's end are masked below)
+        const int n_lo = l_hi, n_hi = uniform(hi_next);
+        hi_next = s_seg[min(lv + 2, n_seg - 1)];
+        const int nidx = min(n_lo + lane, n_pos - 1);
+        const pk_dbl2 n0 = R0[nidx], n1 = R1[nidx];
+        const pk_int4 n2 = R2[nidx];
+        // this level
+        if (l_lo + lane < l_hi) solve_one(l_lo + lane, c0r, c1r, c2r);
+        for (int base = l_lo + 64; base < l_hi; base += 64) { // a level wider than a wave: the other rows one trip at a time
+          const int idx = base + lane;
+          if (idx < l_hi) solve_one(idx, R0[idx], R1[idx], R2[idx]);
+        }
+        c0r = n0; c1r = n1; c2r = n2;
+        l_lo = n_lo;
+        l_hi = n_hi;
+      }
+    }
+    lds_barrier();                                            // the chunk's x values are in the ring
+#pragma unroll
+    for (int j = 0; j < PK_PJ; j++) {
+      const int idx = min(tid + PK_T * j, n_pos - 1);
+      __hip_atomic_store(x + w_row[j], ring[(cur_cs + idx) & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- synchronisation-free triangular solve ---------------------------------------------------------------------
 // Level scheduling pays a barrier (or a launch) per dependency level: 57 436 levels on the G3_circuit-like factor in
 // natural order = 245 ms per application (round 1).  Here ONE launch solves the whole triangle: waves take chunks of
@@ -619,6 +836,11 @@ struct TriFactor {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
+    ok = ok && lds_max >= (int)PK1_LDS_BYTES;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk1<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK1_LDS_BYTES) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk1<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK1_LDS_BYTES) == hipSuccess;
     if (!ok) {
       (void)hipGetLastError();
       for (Step &st : steps) st.c0 = -1;
@@ -634,11 +856,12 @@ struct TriFactor {
   // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
   // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
   // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
-  static int forced_mode() {                                    // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk)
+  static int forced_mode() {     // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk), 3 = walk1 (one walker wave, r3)
     static const int mode = [] {
       const char *force = std::getenv("CASK_HIP_TRSV");
       if (!force) return 0;
-      return std::string(force) == "syncfree" ? 1 : std::string(force) == "levels" ? 2 : 0;
+      const std::string f(force);
+      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : 0;
     }();
     return mode;
   }
@@ -661,6 +884,10 @@ struct TriFactor {
       if (st.wide)
         hipLaunchKernelGGL(k_trsv_level, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, flags,
                            order.p, rp.p, ci.p, val.p, d_b, d_x);
+      else if (packed_ok && st.c0 >= 0 && forced_mode() == 3 && st.long_rows)     // CASK_HIP_TRSV=walk1: one walker wave (r3)
+        hipLaunchKernelGGL(k_trsv_walk1<true>, dim3(1), dim3(PK_T), PK1_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
+      else if (packed_ok && st.c0 >= 0 && forced_mode() == 3)
+        hipLaunchKernelGGL(k_trsv_walk1<false>, dim3(1), dim3(PK_T), PK1_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else if (packed_ok && st.c0 >= 0 && st.long_rows)
         hipLaunchKernelGGL(k_trsv_packed<true>, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else if (packed_ok && st.c0 >= 0)

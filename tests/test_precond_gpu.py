@@ -235,7 +235,7 @@ def test_packed_walk_random_dependency_graphs(seed):
 
 
 def test_triangular_solve_schedules_agree_bit_for_bit():
-    """Three schedules of the same triangular solve (cask_hip_precond.hip): the packed walk of narrow-level runs (the
+    """Four schedules of the same triangular solve (cask_hip_precond.hip): the packed walk of narrow-level runs (the
     default), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
     (CASK_HIP_TRSV=syncfree).  All walk every row in stored order: identical bits -- on a grid factor with thousands
     of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
@@ -271,7 +271,7 @@ np.save(sys.argv[1], np.concatenate(out))
 print(max(levels))
 '''
     outs = {}
-    for mode in ("levels", "syncfree", "packed"):
+    for mode in ("levels", "syncfree", "packed", "walk1"):       # packed = the four-wave walk (default), walk1 = one walker wave (r3)
         path = f"/tmp/cask_trsv_{mode}.npy"
         res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600,
                              env=dict(os.environ, CASK_HIP_TRSV=mode), cwd=str(REPO))
@@ -281,6 +281,7 @@ print(max(levels))
     assert np.all(np.isfinite(outs["levels"]))
     assert np.array_equal(outs["levels"], outs["syncfree"])
     assert np.array_equal(outs["levels"], outs["packed"])
+    assert np.array_equal(outs["levels"], outs["walk1"])
 
 
 def _multicolour_reference(n, rp, ci, va):
