@@ -562,6 +562,390 @@ k_trsv_walk1(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b
   }
 }
 
+// ---- packed walk, walker wave + three staging waves (round 3, second form) -----------------------------------------
+// k_trsv_walk1 showed what one walker wave costs when it issues a level's bookkeeping itself and the other waves idle
+// while it walks.  Here the roles are split for good:
+//   * the factor's level-ordered copy carries, per POSITION, everything that does not depend on x: the first two
+//     entries' values and sources, the entry count -- built once on the host (TriFactor::build_walk2), so no
+//     preparation step is left on the device;
+//   * waves 1-3 (192 threads) are stagers: during the walk of chunk k they write chunk k+1's records into the OTHER
+//     half of a double-buffered LDS area (their global loads were issued a phase earlier), write chunk k-1's results
+//     back from the ring to x, and issue the loads of chunk k+2.  No stager thread reads what another one wrote, so the
+//     only synchronisation is the workgroup barrier that ends a phase;
+//   * wave 0 walks: at the start of a phase it pulls ALL the records of its chunk (up to W2_SUB sub-levels of <= 64
+//     rows) into registers -- a 256-thread workgroup alone on its CU may use 512 VGPRs -- and then runs the levels
+//     back to back, fully unrolled: per level two x reads, the FMAs in stored order, the division, the ring write.
+//     Nothing else is on the dependent chain; level widths come out of the chunk header with scalar shifts.
+// Early sources (x values loaded from memory) must have been written back W2_DIST chunks before their consumer: a
+// chunk's results leave for memory one phase after its walk and every stager drains its stores (the explicit wait
+// below) before that phase's barrier; loads issued from the following phase on see them.
+// Arithmetic and order are solve_row's: bit-identical to the other schedules (tested).
+constexpr int W2_ST = 192, W2_T = 64 + W2_ST;            // wave 0 walks, waves 1-3 stage
+constexpr int W2_GRID = 9;             // workgroup 0 solves, workgroup 8 (same XCD: same L2) reads ahead, the others leave
+constexpr int W2_CH = 640;             // positions per chunk
+constexpr int W2_ECAP = 1280;          // off-diagonal entries per chunk
+constexpr int W2_SUB = 16;             // sub-levels (<= 64 rows each) per chunk: 12-14 VGPRs of records apiece in the walker
+constexpr int W2_Q = 3;                // entries of a row held in its record; a longer row reads the rest from the entry arrays
+constexpr int W2_DIST = 6;             // early sources: producer chunk <= consumer chunk - W2_DIST
+constexpr int W2_PJ = (W2_CH + W2_ST - 1) / W2_ST, W2_EJ = (W2_ECAP + W2_ST - 1) / W2_ST;
+static_assert(PK_RING >= W2_DIST * W2_CH + WIDE_LEVEL, "everything that is not an early source is still in the ring");
+static_assert(W2_ECAP < 2048 && W2_SUB % 4 == 0 && W2_SUB <= 24, "meta word: 11 + 11 bits; header: 6 words of counts");
+// a buffer: recA {b, v0} | recB {v1, v2} | recC {byte addresses of x0, x1, x2, meta} | recD {diagonal}, each with 64 spare
+// records (the walker reads 64 records from a sub-level's first, whatever its width) | s_val | s_x | s_src
+constexpr int W2_RECS = W2_CH + 64;
+constexpr size_t W2_BUF_BYTES = 56 * (size_t)W2_RECS + 20 * (size_t)W2_ECAP;
+constexpr int W2_ZERO = (int)(sizeof(double) * PK_RING + 2 * W2_BUF_BYTES);   // LDS byte address of a constant 0.0 ...
+constexpr int W2_DUMP = W2_ZERO + 8;                                           // ... and of a slot nobody reads
+constexpr size_t W2_LDS_BYTES = W2_DUMP + 8;
+static_assert(W2_LDS_BYTES <= 160 * 1024, "one workgroup's LDS on gfx950");
+
+struct W2Pos {                         // 48 bytes per position (level order): three 16-byte loads
+  double v0, v1, v2, diag;             //   values of the first three entries (0.0 when absent), the diagonal
+  unsigned c0, c1, c2, meta;           //   their sources; entries | first entry (chunk-relative) << 11
+};
+struct W2Ent {                         // 16 bytes per entry, level order
+  double val;
+  unsigned code, pad;                  //   PK_NEAR | producer position (the ring), or the producer position (memory)
+};
+struct Walk2Tri {
+  const W2Pos *pos;
+  const W2Ent *ent;
+  const int4 *hdr;                     // per chunk: {first position, positions, first entry, entries},
+};                                     //   {sub-levels, widths 0-3, 4-7, 8-11 (a byte each)}, {12-15, 16-19, 20-23, sub-levels with longer rows}
+
+// walk2 works in POSITION space: bp[i] = b[order[i]] is gathered by the whole chip before the solve and xp scattered
+// back after it (two launches of ~10 us), so that the one workgroup that walks the levels streams contiguous right-hand
+// sides and results instead of one 128-byte line per row -- a single CU moves ~30 GB/s, and the scattered b[row] and
+// x[row] of a chunk were two thirds of its lines.
+__global__ void k_w2_gather(int n, const int *__restrict__ order, const double *__restrict__ b, double *__restrict__ bp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bp[i] = b[order[i]];
+}
+__global__ void k_w2_scatter(int n, const int *__restrict__ order, const double *__restrict__ xp, double *__restrict__ x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[order[i]] = xp[i];
+}
+// position i: xp[i] = (bp[i] - sum val * xp[producer position]) / diagonal, entries in stored order (solve_row's arithmetic)
+__device__ __forceinline__ void solve_position(int i, int unit, const int *__restrict__ eptr, const int *__restrict__ epos,
+                                               const double *__restrict__ eval, const double *__restrict__ pdiag,
+                                               const double *__restrict__ bp, double *xp) {
+  double s = bp[i];
+  for (int e = eptr[i]; e < eptr[i + 1]; e++) s -= eval[e] * xp[epos[e]];
+  xp[i] = unit ? s : s / pdiag[i];
+}
+__global__ void k_trsv_level_p(int lo, int hi, int unit, const int *__restrict__ eptr, const int *__restrict__ epos,
+                               const double *__restrict__ eval, const double *__restrict__ pdiag,
+                               const double *__restrict__ bp, double *xp) {
+  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < hi) solve_position(i, unit, eptr, epos, eval, pdiag, bp, xp);
+}
+__global__ void k_trsv_levels_p(int l0, int l1, int unit, const int *__restrict__ level_ptr, const int *__restrict__ eptr,
+                                const int *__restrict__ epos, const double *__restrict__ eval,
+                                const double *__restrict__ pdiag, const double *__restrict__ bp, double *xp) {
+  for (int l = l0; l < l1; l++) {
+    const int lo = level_ptr[l], hi = level_ptr[l + 1];
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) solve_position(i, unit, eptr, epos, eval, pdiag, bp, xp);
+    __syncthreads();
+  }
+}
+
+// lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (an asm statement is opaque to it: it
+// would keep every LDS read of the last phase "pending" and serialise the next phase's reads behind waits)
+__device__ __forceinline__ void w2_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);                         // vmcnt 63, expcnt 7, lgkmcnt 0
+  __builtin_amdgcn_s_barrier();
+}
+
+// One chunk by the walker wave.  Records of sub-level s: {b, v0} {v1, v2} {addresses of x0, x1, x2, meta} (and the
+// diagonal).  An absent entry has v = +0.0 and the address of a constant 0.0 -- fma(-0, 0, s) = s for every s -- so the
+// walk needs no masks; lanes past a level's width hold some other row's record and write to a dump slot.  The records
+// of sub-level s + W2_AHEAD are requested behind the x reads of sub-level s: they fill the LDS pipeline in the shadow
+// of the dependent chain (x reads -> FMAs -> ring write), which is all a level costs.  OVF = false is the chunk without
+// any longer row: straight-line code, so the compiler counts what is in flight and a level's x reads go out right
+// behind the previous level's ring write (the LDS executes a wave's operations in order).
+template <bool LONG, bool UNIT, bool OVF>
+__device__ __forceinline__ void w2_walk_chunk(char *lds_bytes, int base, int cs, const int (&cw)[6], int ovf, int lane) {
+  constexpr int OFF_B = 16 * W2_RECS, OFF_C = 32 * W2_RECS, OFF_D = 48 * W2_RECS, OFF_VAL = 56 * W2_RECS,
+                OFF_SRC = OFF_VAL + 16 * W2_ECAP;
+  constexpr int W2_AHEAD = 4;
+  pk_dbl2 ra[W2_SUB], rb[W2_SUB];
+  pk_int4 rc[W2_SUB];
+  double rd[W2_SUB];
+  int lo = 0, lo_solve = 0;
+  auto preload = [&](int s) {                                 // unconditional: the compiler can count what is in flight
+    const char *rec = lds_bytes + base + 16 * (lo + lane);
+    ra[s] = *reinterpret_cast<const pk_dbl2 *>(rec);
+    rb[s] = *reinterpret_cast<const pk_dbl2 *>(rec + OFF_B);
+    rc[s] = *reinterpret_cast<const pk_int4 *>(rec + OFF_C);
+    if constexpr (!UNIT) rd[s] = *reinterpret_cast<const double *>(lds_bytes + base + OFF_D + 8 * (lo + lane));
+    lo += (cw[s >> 2] >> (8 * (s & 3))) & 0xff;
+  };
+#pragma unroll
+  for (int s = 0; s < W2_AHEAD; s++) preload(s);
+  const double *s_val = reinterpret_cast<const double *>(lds_bytes + base + OFF_VAL);
+  const int *s_src = reinterpret_cast<const int *>(lds_bytes + base + OFF_SRC);
+#pragma unroll
+  for (int s = 0; s < W2_SUB; s++) {
+    // the x reads first, the records of sub-level s + W2_AHEAD behind them in the LDS queue
+    const double x0 = *reinterpret_cast<const double *>(lds_bytes + rc[s].x);
+    const double x1 = *reinterpret_cast<const double *>(lds_bytes + rc[s].y);
+    const double x2 = *reinterpret_cast<const double *>(lds_bytes + rc[s].z);
+    if (s + W2_AHEAD < W2_SUB) preload(s + W2_AHEAD);
+    const int width = (cw[s >> 2] >> (8 * (s & 3))) & 0xff;
+    const bool mine = lane < width;                           // lanes past the level's width hold some other row's record
+    const int dst = mine ? ((cs + lo_solve + lane) & (PK_RING - 1)) * 8 : W2_DUMP;
+    lo_solve += width;
+    double sacc = ra[s].x - ra[s].y * x0;                     // (contracted to one fma, like `s -= v * x` everywhere else)
+    sacc -= rb[s].x * x1;
+    sacc -= rb[s].y * x2;
+    if constexpr (OVF) {
+      if ((ovf >> s) & 1) {                                   // (scalar) some row of this sub-level has more entries
+        const int ne = mine ? (int)(rc[s].w & 0x7ff) : 0;
+        if (W2_Q < ne) {
+          const int e0 = (rc[s].w >> 11) & 0x7ff;
+          if constexpr (!LONG) {
+            for (int e = e0 + W2_Q; e < e0 + ne; e++)
+              sacc -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
+          } else {
+            constexpr int PK_U = 16;
+            for (int e = e0 + W2_Q; e < e0 + ne; e += PK_U) {
+              double v4[PK_U], x4[PK_U];
+              int a4[PK_U];
+#pragma unroll
+              for (int u = 0; u < PK_U; u++) {
+                const int eu = min(e + u, e0 + ne - 1);
+                a4[u] = s_src[eu];
+                v4[u] = s_val[eu];
+              }
+#pragma unroll
+              for (int u = 0; u < PK_U; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+#pragma unroll
+              for (int u = 0; u < PK_U; u++)
+                if (e + u < e0 + ne) sacc -= v4[u] * x4[u];
+            }
+          }
+        }
+      }
+    }
+    *reinterpret_cast<double *>(lds_bytes + dst) = UNIT ? sacc : sacc / rd[s];
+  }
+}
+
+template <bool LONG, bool UNIT>
+__global__ void __launch_bounds__(W2_T)
+k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *xp, int *progress,
+             unsigned long long *dbg) {
+  // Workgroup 0 is the team that solves; workgroup 8 -- dispatched to the same XCD, hence the same L2 -- only reads
+  // ahead: one word per 128-byte line of the chunks the team will stage next, paced by the team's progress word.  A CU
+  // sustains few misses at a time (this workgroup alone streams ~15 GB/s from memory); with the lines already in the
+  // L2 a stager's load costs an L2 hit.  Nothing depends on the read-ahead: if it falls behind or lands elsewhere, the
+  // solve is only slower.
+  if (blockIdx.x != 0) {
+    if (blockIdx.x != 8) return;
+    constexpr int FETCH_AHEAD = 10;
+    unsigned acc = 0;
+    const int ft = threadIdx.x;
+    for (int f = c0 + 3; f < c1; f++) {
+      for (int polls = 0; polls < (1 << 14); polls++) {       // bounded: a stuck progress word only costs the pacing
+        if (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + FETCH_AHEAD >= f) break;
+        __builtin_amdgcn_s_sleep(20);
+      }
+      const int4 h = t.hdr[3 * f];
+      const long p0 = 48L * h.x, p1 = 48L * (h.x + h.y), e0 = 16L * h.z, e1 = 16L * (h.z + h.w), b0 = 8L * h.x, b1 = 8L * (h.x + h.y);
+      for (long a = (p0 & ~127L) + 128L * ft; a < p1; a += 128L * W2_T)
+        acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.pos) + a);
+      for (long a = (e0 & ~127L) + 128L * ft; a < e1; a += 128L * W2_T)
+        acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.ent) + a);
+      for (long a = (b0 & ~127L) + 128L * ft; a < b1; a += 128L * W2_T)
+        acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(bp) + a);
+      if (ft == 0) acc += (unsigned)t.hdr[3 * min(f + 1, c1 - 1)].x;
+    }
+    if (acc == 0x9e3779b9u) *progress = -1;                   // (keeps the loads alive)
+    return;
+  }
+  extern __shared__ double pk_lds[];
+  double *ring = pk_lds;
+  char *lds_bytes = reinterpret_cast<char *>(pk_lds);
+  const int tid = threadIdx.x, lane = tid & 63, st = tid - 64;
+  auto buf_base = [&](int which) { return (int)(sizeof(double) * PK_RING + (size_t)which * W2_BUF_BYTES); };
+  constexpr int OFF_B = 16 * W2_RECS, OFF_C = 32 * W2_RECS, OFF_D = 48 * W2_RECS, OFF_VAL = 56 * W2_RECS,
+                OFF_X = OFF_VAL + 8 * W2_ECAP, OFF_SRC = OFF_X + 8 * W2_ECAP;
+
+  if (tid < 64) {
+    // ------------------------------------------------------------------------------------------------ the walker
+    // The level widths of a chunk come by a VECTOR load (lane i: word i of the header's last 32 bytes), a phase ahead:
+    // a scalar load in flight would share lgkmcnt with the LDS reads and, returning out of order, force every wait
+    // for an LDS read to wait for all of them.
+    const int *hw = reinterpret_cast<const int *>(t.hdr);
+    int gw = hw[12 * c0 + 4 + (lane & 7)], gcs = hw[12 * c0];
+    unsigned long long d_wait = 0, d_walk = 0;
+    for (int k = c0; k < c1; k++) {
+      const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+      w2_barrier();                                           // chunk k is staged
+      const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+      const int w = gw, cs = uniform(gcs);
+      gw = hw[12 * min(k + 1, c1 - 1) + 4 + (lane & 7)];
+      gcs = hw[12 * min(k + 1, c1 - 1)];
+      const int cw[6] = {__builtin_amdgcn_readlane(w, 1), __builtin_amdgcn_readlane(w, 2), __builtin_amdgcn_readlane(w, 3),
+                         __builtin_amdgcn_readlane(w, 4), __builtin_amdgcn_readlane(w, 5), __builtin_amdgcn_readlane(w, 6)};
+      const int ovf = __builtin_amdgcn_readlane(w, 7);        // sub-levels with a row of more than W2_Q entries
+      const int base = buf_base((k - c0) & 1);
+      if (ovf) w2_walk_chunk<LONG, UNIT, true>(lds_bytes, base, cs, cw, ovf, lane);
+      else w2_walk_chunk<LONG, UNIT, false>(lds_bytes, base, cs, cw, 0, lane);
+      if (dbg) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        d_wait += q1 - q0;
+        d_walk += __builtin_amdgcn_s_memtime() - q1;
+      }
+    }
+    if (dbg && lane == 0) { atomicAdd(dbg + 0, d_wait); atomicAdd(dbg + 1, d_walk); atomicAdd(dbg + 3, (unsigned long long)(c1 - c0)); }
+    w2_barrier();                                             // the last chunk's x values are in the ring
+    w2_barrier();                                             // (the stagers' extra phase: the last write-back)
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- the stagers
+  // Three chunks are in flight per thread: `cur` (all loaded: staged this phase), `nxt` (its x-independent loads
+  // landed during the last phase: b[row] and the early x values are requested this phase), and the chunk after it,
+  // whose x-independent loads go out at the end of the phase.  No load is waited for in the phase that issued it.
+  struct Indep {                                              // what does not depend on x
+    int4 q0[W2_PJ], q1[W2_PJ], q2[W2_PJ];                     // {v0, v1} {v2, diagonal} {c0, c1, c2, meta} of a position
+    double b[W2_PJ];                                          // its right-hand side
+    int4 ent[W2_EJ];                                          // {value, code, -} of an entry
+  };
+  Indep P, Q;
+  double l_x[W2_EJ];                                          // early x values of the chunk staged next
+  int cs1 = 0, cnt1 = 0, cs2 = 0, cnt2 = 0, cs3 = 0, cnt3 = 0;   // the last three chunks staged (3: written back next)
+  auto rotate_chunks = [&]() {
+    cs3 = cs2; cnt3 = cnt2;
+    cs2 = cs1; cnt2 = cnt1;
+  };
+  auto as_double = [](int lo, int hi) { return __hiloint2double(hi, lo); };
+
+  auto load_indep = [&](Indep &d, const int4 &h) {
+    const int cs = uniform(h.x), cnt = uniform(h.y), ebase = uniform(h.z), ecnt = uniform(h.w);
+#pragma unroll
+    for (int j = 0; j < W2_PJ; j++) {
+      const int p = cs + min(st + W2_ST * j, cnt - 1);
+      const int4 *rec = reinterpret_cast<const int4 *>(t.pos + p);
+      d.q0[j] = rec[0];
+      if constexpr (UNIT) { d.q1[j].x = reinterpret_cast<const int *>(rec)[4]; d.q1[j].y = reinterpret_cast<const int *>(rec)[5]; }
+      else d.q1[j] = rec[1];
+      d.q2[j] = rec[2];
+      d.b[j] = bp[p];
+    }
+#pragma unroll
+    for (int j = 0; j < W2_EJ; j++)
+      d.ent[j] = *reinterpret_cast<const int4 *>(t.ent + ebase + min(st + W2_ST * j, max(ecnt - 1, 0)));
+  };
+  auto load_dep = [&](const Indep &d, const int4 &h) {        // xp[producer position] of the early sources
+    const int ecnt = uniform(h.w);
+#pragma unroll
+    for (int j = 0; j < W2_EJ; j++) {
+      const unsigned code = (unsigned)d.ent[j].z;
+      const bool early = st + W2_ST * j < ecnt && !(code & PK_NEAR);
+      l_x[j] = __hip_atomic_load(xp + (early ? code : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto stage = [&](const Indep &d, const int4 &h, int which) {  // registers -> buffer `which`
+    const int cs = uniform(h.x), cnt = uniform(h.y), ecnt = uniform(h.w);
+    const int base = buf_base(which);
+    // a near value is read from the ring, an early one from the buffer's s_x, an absent one from the constant 0.0
+    auto source = [&](unsigned code, int e, bool present) {
+      return !present ? W2_ZERO : (code & PK_NEAR) ? (int)((code & (PK_RING - 1)) * 8u) : base + OFF_X + 8 * e;
+    };
+#pragma unroll
+    for (int j = 0; j < W2_PJ; j++) {
+      const int p = st + W2_ST * j;
+      if (p < cnt) {
+        const unsigned meta = (unsigned)d.q2[j].w;
+        const int ne = (int)(meta & 0x7ffu), e0 = (int)((meta >> 11) & 0x7ffu);
+        pk_dbl2 a, bb;
+        pk_int4 c;
+        a.x = d.b[j]; a.y = as_double(d.q0[j].x, d.q0[j].y);
+        bb.x = as_double(d.q0[j].z, d.q0[j].w); bb.y = as_double(d.q1[j].x, d.q1[j].y);
+        c.x = source((unsigned)d.q2[j].x, e0, ne > 0);
+        c.y = source((unsigned)d.q2[j].y, e0 + 1, ne > 1);
+        c.z = source((unsigned)d.q2[j].z, e0 + 2, ne > 2);
+        c.w = (int)meta;
+        *reinterpret_cast<pk_dbl2 *>(lds_bytes + base + 16 * p) = a;
+        *reinterpret_cast<pk_dbl2 *>(lds_bytes + base + OFF_B + 16 * p) = bb;
+        *reinterpret_cast<pk_int4 *>(lds_bytes + base + OFF_C + 16 * p) = c;
+        if constexpr (!UNIT) *reinterpret_cast<double *>(lds_bytes + base + OFF_D + 8 * p) = as_double(d.q1[j].z, d.q1[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W2_EJ; j++) {
+      const int e = st + W2_ST * j;
+      if (e < ecnt) {
+        const unsigned code = (unsigned)d.ent[j].z;
+        *reinterpret_cast<double *>(lds_bytes + base + OFF_VAL + 8 * e) = as_double(d.ent[j].x, d.ent[j].y);
+        *reinterpret_cast<double *>(lds_bytes + base + OFF_X + 8 * e) = l_x[j];
+        *reinterpret_cast<int *>(lds_bytes + base + OFF_SRC + 4 * e) =
+            (code & PK_NEAR) ? (int)((code & (PK_RING - 1)) * 8u) : base + OFF_X + 8 * e;
+      }
+    }
+    rotate_chunks();
+    cs1 = cs; cnt1 = cnt;
+  };
+  auto write_back3 = [&]() {                                  // ring -> xp for the chunk behind the one being walked:
+    if (cnt3 > 0) {                                           //   always W2_PJ stores per thread (lanes past the end repeat the
+#pragma unroll                                                //   chunk's last position)
+      for (int j = 0; j < W2_PJ; j++) {
+        const int p = cs3 + min(st + W2_ST * j, cnt3 - 1);
+        __hip_atomic_store(xp + p, ring[p & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+
+  if (tid == 64) {
+    *reinterpret_cast<double *>(lds_bytes + W2_ZERO) = 0.0;
+    *reinterpret_cast<double *>(lds_bytes + W2_DUMP) = 0.0;
+  }
+  // Three chunks are in flight per thread, in two register sets that swap roles every phase (no copies): in phase k set
+  // X holds chunk k + 1 complete (staged now, then reloaded with the x-independent part of chunk k + 3), set Y the
+  // x-independent part of chunk k + 2 (its b[row] and early x values are requested now).  No load is waited for in the
+  // phase that issued it.  Chunk headers travel ahead of their loads.
+  auto hdr_at = [&](int k) { return t.hdr[3 * min(k, c1 - 1)]; };
+  int4 hA = hdr_at(c0), hB = hdr_at(c0 + 1), hC = hdr_at(c0 + 2), hD = hdr_at(c0 + 3);
+  load_indep(P, hA);
+  load_indep(Q, hB);
+  load_dep(P, hA);                                            // (waits for P's codes)
+  stage(P, hA, 0);                                            // chunk c0 (waits for everything)
+  load_dep(Q, hB);                                            // chunk c0 + 1
+  load_indep(P, hC);                                          // chunk c0 + 2
+  hA = hB; hB = hC; hC = hD; hD = hdr_at(c0 + 4);
+  unsigned long long e_wait = 0, e_work = 0;
+  auto phase = [&](Indep &X, Indep &Y, int k) {               // X = chunk k + 1, Y = chunk k + 2 (x-independent part)
+    const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    w2_barrier();                                             // phase k: the walker is on chunk k
+    const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    // Memory operations retire in order.  The youngest W2_PJ of this thread are the write-back stores of the last
+    // phase: everything older -- every load (each had that phase to land) and the stores of the phase before it -- is
+    // complete after this wait, and the write-through stores themselves (1.2 us) are never waited for.  By the
+    // barrier that ends THIS phase every thread has passed this point, so the results written back during phase k - 2
+    // (chunk k - 3) are in memory for every load issued from phase k + 1 on: those are for chunk k + 3 = the
+    // producer's chunk + W2_DIST.
+    static_assert(W2_PJ == 4, "the vmcnt immediate below counts the W2_PJ = 4 write-back stores per thread");
+    __builtin_amdgcn_s_waitcnt(0x0F74);                       // vmcnt 4, expcnt 7, lgkmcnt 15
+    if (tid == 64) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (paces the read-ahead workgroup)
+    if (k + 1 < c1) stage(X, hA, (k + 1 - c0) & 1);           // chunk k + 1
+    else rotate_chunks();
+    if (k + 2 < c1) load_dep(Y, hB);                          // chunk k + 2
+    if (k + 3 < c1) load_indep(X, hC);                        // chunk k + 3
+    hA = hB; hB = hC; hC = hD; hD = hdr_at(k + 5);
+    write_back3();                                            // chunk k - 1 (nothing in the first phase): the youngest operations
+    if (dbg) { e_wait += q1 - q0; e_work += __builtin_amdgcn_s_memtime() - q1; }
+  };
+  for (int k = c0; k < c1; k += 2) {
+    phase(Q, P, k);
+    if (k + 1 < c1) phase(P, Q, k + 1);
+  }
+  if (dbg && tid == 64) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
+  w2_barrier();                                               // the last chunk is walked
+  rotate_chunks();
+  write_back3();
+  w2_barrier();
+}
+
 // ---- synchronisation-free triangular solve ---------------------------------------------------------------------
 // Level scheduling pays a barrier (or a launch) per dependency level: 57 436 levels on the G3_circuit-like factor in
 // natural order = 245 ms per application (round 1).  Here ONE launch solves the whole triangle: waves take chunks of
@@ -674,13 +1058,23 @@ struct TriFactor {
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
-  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; bool long_rows; };   // levels [l0,l1) = positions [lo,hi) of `order`;
+  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; bool long_rows; int d0 = -1, d1 = -1; };   // levels [l0,l1) = positions [lo,hi) of `order`;
   std::vector<Step> steps;                                      // chunks [c0,c1) of the packed form (c0 < 0: none)
   // the factor once more in level order for k_trsv_packed (see there)
   DevBuf<int> pk_row, pk_eptr, pk_seg;
   DevBuf<int4> pk_hdr;
   DevBuf<unsigned> pk_code;
   DevBuf<double> pk_diag, pk_val;
+  // ... and once more for k_trsv_walk2 (CASK_HIP_TRSV=walk2): per-position records, its own chunks [d0,d1) per step
+  DevBuf<W2Pos> w2_pos;
+  DevBuf<W2Ent> w2_ent;
+  DevBuf<int> w2_eptr, w2_epos;
+  DevBuf<double> w2_eval, w2_pdiag;
+  mutable DevBuf<double> w2_bp, w2_xp;             // the right-hand side and the result in position space
+  mutable DevBuf<int> w2_progress;                 // the chunk the team is on (paces the read-ahead workgroup)
+  bool w2_ok = false;
+  DevBuf<int4> w2_hdr;
+  mutable DevBuf<unsigned long long> w2_dbg;
   DevBuf<int> sync;                                   // [0] chunk counter, [1] error flag of the sync-free solve
   int sf_grid = 0;
 
@@ -722,6 +1116,10 @@ struct TriFactor {
     }
     int rc = build_packed(h_rp, h_ci, h_val, level, lp, ord);
     if (rc) return rc;
+    if (forced_mode() == 4) {
+      rc = build_walk2(h_rp, h_ci, h_val, level, lp, ord);
+      if (rc) return rc;
+    }
     PC_TRY(rp.upload(h_rp));
     PC_TRY(ci.upload(h_ci));
     PC_TRY(val.upload(h_val));
@@ -848,6 +1246,135 @@ struct TriFactor {
     return CASK_HIP_OK;
   }
 
+  // The level-ordered copy for k_trsv_walk2 (see there): chunks of <= W2_SUB sub-levels (<= 64 consecutive rows of one
+  // level) / W2_CH positions / W2_ECAP entries; per position the first two entries and the entry range; a source is
+  // NEAR (the ring) when its producer is within PK_RING positions of the consumer's level end, else EARLY (memory),
+  // which needs the producer W2_DIST chunks back.  A step that does not fit keeps d0 = -1.
+  int build_walk2(const std::vector<int> &h_rp, const std::vector<int> &h_ci, const std::vector<double> &h_val,
+                  const std::vector<int> &level, const std::vector<int> &lp, const std::vector<int> &ord) {
+    std::vector<int> pos_of((size_t)n), peptr((size_t)n + 1, 0), ppos;
+    for (int i = 0; i < n; i++) pos_of[ord[i]] = i;
+    std::vector<unsigned> pcode, pmeta((size_t)n + 1, 0u), pc0((size_t)n + 1, PK_NEAR), pc1((size_t)n + 1, PK_NEAR),
+        pc2((size_t)n + 1, PK_NEAR);
+    std::vector<double> pval, pdiag((size_t)n + 1, 1.0), pv0((size_t)n + 1, 0.0), pv1((size_t)n + 1, 0.0), pv2((size_t)n + 1, 0.0);
+    ppos.reserve(h_ci.size());
+    pval.reserve(h_ci.size());
+    for (int i = 0; i < n; i++) {
+      const int r = ord[i];
+      for (int k = h_rp[r]; k < h_rp[r + 1]; k++) {
+        const int c = h_ci[k];
+        if (c == r) pdiag[i] = h_val[k];
+        else if (lower ? c < r : c > r) {
+          ppos.push_back(pos_of[c]);                          // the producer's POSITION: walk2 works in position space
+          pval.push_back(h_val[k]);
+        }
+      }
+      peptr[i + 1] = (int)ppos.size();
+    }
+    pcode.assign(ppos.begin(), ppos.end());                   // a position in memory (early) unless marked near below
+    std::vector<int4> hdr;
+    std::vector<int> chunk_of((size_t)n, 0);
+    for (Step &st : steps) {
+      if (st.wide) continue;
+      struct Chunk { int cs, ce, n_sub; unsigned char width[W2_SUB]; };
+      std::vector<Chunk> chunks;
+      bool ok = true;
+      Chunk cur{st.lo, st.lo, 0, {}};
+      for (int i = st.lo; i < st.hi && ok;) {
+        // the next sub-level: rows of i's level, at most 64, at most W2_ECAP entries
+        const int level_end = lp[level[ord[i]] + 1];
+        int e = i;
+        while (e < level_end && e - i < 64 && peptr[e + 1] - peptr[i] <= W2_ECAP) e++;
+        if (e == i) { ok = false; break; }                    // one row with more than W2_ECAP entries
+        const bool fits = cur.n_sub < W2_SUB && e - cur.cs <= W2_CH && peptr[e] - peptr[cur.cs] <= W2_ECAP;
+        if (!fits) {
+          chunks.push_back(cur);
+          cur = Chunk{i, i, 0, {}};
+        }
+        cur.width[cur.n_sub++] = (unsigned char)(e - i);
+        cur.ce = e;
+        i = e;
+      }
+      if (ok && cur.n_sub > 0) chunks.push_back(cur);
+      if (!ok || chunks.empty()) continue;
+      for (size_t k = 0; k < chunks.size(); k++)
+        for (int i = chunks[k].cs; i < chunks[k].ce; i++) chunk_of[i] = (int)k;
+      for (size_t k = 0; k < chunks.size() && ok; k++) {
+        const Chunk &ch = chunks[k];
+        for (int i = ch.cs; i < ch.ce && ok; i++) {
+          const int level_end = lp[level[ord[i]] + 1];
+          const int ne = peptr[i + 1] - peptr[i], e0 = peptr[i] - peptr[ch.cs];
+          for (int e = peptr[i]; e < peptr[i + 1]; e++) {
+            const int pp = ppos[e];
+            if (pp >= st.lo && pp >= level_end - PK_RING) pcode[e] = PK_NEAR | (unsigned)pp;
+            else if (pp >= st.lo && chunk_of[pp] > (int)k - W2_DIST) { ok = false; break; }   // (the static_assert rules it out)
+          }
+          pmeta[i] = (unsigned)ne | ((unsigned)e0 << 11);
+          if (ne > 0) { pv0[i] = pval[peptr[i]]; pc0[i] = pcode[peptr[i]]; }
+          if (ne > 1) { pv1[i] = pval[peptr[i] + 1]; pc1[i] = pcode[peptr[i] + 1]; }
+          if (ne > 2) { pv2[i] = pval[peptr[i] + 2]; pc2[i] = pcode[peptr[i] + 2]; }
+        }
+      }
+      if (!ok) continue;                                      // (cannot happen; the step runs k_trsv_levels_p)
+      st.d0 = (int)(hdr.size() / 3);
+      for (const Chunk &ch : chunks) {
+        int w[6] = {0, 0, 0, 0, 0, 0}, ovf = 0, at = ch.cs;
+        for (int q = 0; q < ch.n_sub; q++) {
+          w[q >> 2] |= (int)ch.width[q] << (8 * (q & 3));
+          for (int i = at; i < at + ch.width[q]; i++)
+            if (peptr[i + 1] - peptr[i] > W2_Q) ovf |= 1 << q;   // a row with more entries than its record holds
+          at += ch.width[q];
+        }
+        hdr.push_back(make_int4(ch.cs, ch.ce - ch.cs, peptr[ch.cs], peptr[ch.ce] - peptr[ch.cs]));
+        hdr.push_back(make_int4(ch.n_sub, w[0], w[1], w[2]));
+        hdr.push_back(make_int4(w[3], w[4], w[5], ovf));
+      }
+      st.d1 = (int)(hdr.size() / 3);
+    }
+    pcode.push_back(0u);                                      // spare elements: the kernel's clamped loads
+    pval.push_back(0.0);
+    ppos.push_back(0);
+    if (hdr.empty()) hdr.push_back(make_int4(0, 0, 0, 0));
+    {
+      std::vector<W2Pos> apos((size_t)n + 1);
+      for (int i = 0; i <= n; i++) {
+        W2Pos &q = apos[i];
+        q.v0 = pv0[i]; q.v1 = pv1[i]; q.v2 = pv2[i]; q.diag = pdiag[i];
+        q.c0 = pc0[i]; q.c1 = pc1[i]; q.c2 = pc2[i]; q.meta = pmeta[i];
+      }
+      std::vector<W2Ent> aent(pcode.size());
+      for (size_t e = 0; e < pcode.size(); e++) aent[e] = W2Ent{pval[e], pcode[e], 0u};
+      PC_TRY(w2_pos.upload(apos));
+      PC_TRY(w2_ent.upload(aent));
+    }
+    PC_TRY(w2_eptr.upload(peptr));                            // the position-space CSR of the wide levels' kernel
+    PC_TRY(w2_epos.upload(ppos));
+    PC_TRY(w2_eval.upload(pval));
+    PC_TRY(w2_pdiag.upload(pdiag));
+    PC_TRY(w2_bp.alloc((size_t)n + 1));
+    PC_TRY(w2_xp.alloc((size_t)n + 1));
+    PC_TRY(w2_progress.alloc(1));
+    PC_TRY(w2_hdr.upload(hdr));
+    if (std::getenv("W2_DBG")) { PC_TRY(w2_dbg.alloc(8)); PC_TRY(hipMemset(w2_dbg.p, 0, 64)); }
+    int dev = 0, lds_max = 0;
+    w2_ok = hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+            lds_max >= (int)W2_LDS_BYTES;
+    w2_ok = w2_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk2<false, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES) == hipSuccess;
+    w2_ok = w2_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk2<false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES) == hipSuccess;
+    w2_ok = w2_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk2<true, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES) == hipSuccess;
+    w2_ok = w2_ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk2<true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES) == hipSuccess;
+    if (!w2_ok) {
+      (void)hipGetLastError();
+      for (Step &st : steps) st.d0 = -1;
+    }
+    return CASK_HIP_OK;
+  }
+
   // Level-scheduled by default (runs of narrow levels: the packed walk, k_trsv_packed; CASK_HIP_TRSV=levels keeps the
   // row-indexed walk of round 1); CASK_HIP_TRSV=syncfree selects the one-launch synchronisation-free solve.  Measured
   // on the G3_circuit-like ILU(0) factors (57 436 levels, profiles/r02_trsv.txt): levels 225 ms, sync-free 210-270 ms
@@ -856,12 +1383,12 @@ struct TriFactor {
   // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
   // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
   // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
-  static int forced_mode() {     // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk), 3 = walk1 (one walker wave, r3)
+  static int forced_mode() {     // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk), 3 = walk1 (one walker wave, r3), 4 = walk2 (walker + stagers)
     static const int mode = [] {
       const char *force = std::getenv("CASK_HIP_TRSV");
       if (!force) return 0;
       const std::string f(force);
-      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : 0;
+      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : f == "walk2" ? 4 : 0;
     }();
     return mode;
   }
@@ -875,6 +1402,40 @@ struct TriFactor {
       hipLaunchKernelGGL(k_trsv_syncfree, dim3(sf_grid), dim3(256), 0, s, n, flags, rp.p, ci.p, val.p, d_b, d_x, sync.p,
                          sync.p + 1);
       PC_TRY(hipGetLastError());
+      return CASK_HIP_OK;
+    }
+    if (forced_mode() == 4 && n > 0 && w2_bp.p) {              // CASK_HIP_TRSV=walk2: the whole solve in position space
+      const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_hdr.p};
+      const int pg = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256), u = unit ? 1 : 0;
+      PC_TRY(hipMemsetAsync(w2_progress.p, 0, sizeof(int), s));
+      hipLaunchKernelGGL(k_w2_gather, dim3(pg), dim3(256), 0, s, n, order.p, d_b, w2_bp.p);
+      for (const Step &st : steps) {
+        if (st.wide)
+          hipLaunchKernelGGL(k_trsv_level_p, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, u, w2_eptr.p,
+                             w2_epos.p, w2_eval.p, w2_pdiag.p, w2_bp.p, w2_xp.p);
+        else if (st.d0 < 0)
+          hipLaunchKernelGGL(k_trsv_levels_p, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, u, level_ptr.p, w2_eptr.p, w2_epos.p,
+                             w2_eval.p, w2_pdiag.p, w2_bp.p, w2_xp.p);
+        else if (st.long_rows && unit)
+          hipLaunchKernelGGL((k_trsv_walk2<true, true>), dim3(W2_GRID), dim3(W2_T), W2_LDS_BYTES, s, w2, st.d0, st.d1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
+        else if (st.long_rows)
+          hipLaunchKernelGGL((k_trsv_walk2<true, false>), dim3(W2_GRID), dim3(W2_T), W2_LDS_BYTES, s, w2, st.d0, st.d1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
+        else if (unit)
+          hipLaunchKernelGGL((k_trsv_walk2<false, true>), dim3(W2_GRID), dim3(W2_T), W2_LDS_BYTES, s, w2, st.d0, st.d1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
+        else
+          hipLaunchKernelGGL((k_trsv_walk2<false, false>), dim3(W2_GRID), dim3(W2_T), W2_LDS_BYTES, s, w2, st.d0, st.d1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
+      }
+      hipLaunchKernelGGL(k_w2_scatter, dim3(pg), dim3(256), 0, s, n, order.p, w2_xp.p, d_x);
+      PC_TRY(hipGetLastError());
+      if (w2_dbg.p) {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, w2_dbg.p, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemset(w2_dbg.p, 0, sizeof(h));
+        if (h[3])
+          std::fprintf(stderr, "walk2 %s: chunks %llu | cycles/chunk: walker at the barrier %.0f, walking %.0f | stagers at the barrier %.0f, working %.0f\n",
+                       lower ? "L" : "U", h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[4] / h[3], (double)h[6] / h[3]);
+      }
       return CASK_HIP_OK;
     }
     // the packed walk reads b a chunk ahead of the x it writes: not for an in-place solve

@@ -271,7 +271,7 @@ np.save(sys.argv[1], np.concatenate(out))
 print(max(levels))
 '''
     outs = {}
-    for mode in ("levels", "syncfree", "packed", "walk1"):       # packed = the four-wave walk (default), walk1 = one walker wave (r3)
+    for mode in ("levels", "syncfree", "packed", "walk1", "walk2"):   # packed = the four-wave walk (default); walk1 / walk2 = r3
         path = f"/tmp/cask_trsv_{mode}.npy"
         res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600,
                              env=dict(os.environ, CASK_HIP_TRSV=mode), cwd=str(REPO))
@@ -282,6 +282,7 @@ print(max(levels))
     assert np.array_equal(outs["levels"], outs["syncfree"])
     assert np.array_equal(outs["levels"], outs["packed"])
     assert np.array_equal(outs["levels"], outs["walk1"])
+    assert np.array_equal(outs["levels"], outs["walk2"])
 
 
 def _multicolour_reference(n, rp, ci, va):
