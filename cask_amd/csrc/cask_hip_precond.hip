@@ -562,29 +562,44 @@ k_trsv_walk1(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b
   }
 }
 
-// ---- packed walk, walker wave + three staging waves (round 3, second form) -----------------------------------------
+// ---- the walk of narrow levels, round 3 (k_trsv_walk2, the default) -------------------------------------------------
 // k_trsv_walk1 showed what one walker wave costs when it issues a level's bookkeeping itself and the other waves idle
-// while it walks.  Here the roles are split for good:
-//   * the factor's level-ordered copy carries, per POSITION, everything that does not depend on x: the first two
-//     entries' values and sources, the entry count -- built once on the host (TriFactor::build_walk2), so no
-//     preparation step is left on the device;
-//   * waves 1-3 (192 threads) are stagers: during the walk of chunk k they write chunk k+1's records into the OTHER
-//     half of a double-buffered LDS area (their global loads were issued a phase earlier), write chunk k-1's results
-//     back from the ring to x, and issue the loads of chunk k+2.  No stager thread reads what another one wrote, so the
-//     only synchronisation is the workgroup barrier that ends a phase;
-//   * wave 0 walks: at the start of a phase it pulls ALL the records of its chunk (up to W2_SUB sub-levels of <= 64
-//     rows) into registers -- a 256-thread workgroup alone on its CU may use 512 VGPRs -- and then runs the levels
-//     back to back, fully unrolled: per level two x reads, the FMAs in stored order, the division, the ring write.
-//     Nothing else is on the dependent chain; level widths come out of the chunk header with scalar shifts.
-// Early sources (x values loaded from memory) must have been written back W2_DIST chunks before their consumer: a
-// chunk's results leave for memory one phase after its walk and every stager drains its stores (the explicit wait
-// below) before that phase's barrier; loads issued from the following phase on see them.
+// while it walks.  Here the work is split by kind, and everything that does not depend on x leaves the dependent chain:
+//   * POSITION SPACE.  The solve runs on bp[i] = b[order[i]] and xp[i] (gathered / scattered by the whole chip around it:
+//     two ~10 us launches), so the one workgroup that walks streams contiguous right-hand sides and results.  A single
+//     CU sustains few misses at a time (~15-30 GB/s from memory): the row-indexed b[row] / x[row] of a chunk were two
+//     thirds of its cache lines.
+//   * HOST-BUILT RECORDS (TriFactor::build_walk2).  Per position 48 bytes: the first W2_Q = 3 entries' values, a "source
+//     word" each -- the LDS byte address its x value will have: a ring slot, a slot of the chunk's s_x area, or a
+//     constant 0.0 for an absent entry (fma(-0, 0, s) = s for every s: the walk needs no masks) -- and the entry range.
+//     x values the ring no longer holds ("early": 4 % of the G3_circuit-like factor's entries) are a list per chunk
+//     {producer position, s_x slot}.  Chunks hold <= W2_SUB sub-levels of <= 64 rows; the header carries their widths.
+//   * STAGERS (waves 1-3).  During the walk of chunk k they write chunk k+1's records into the other half of a
+//     double-buffered LDS area, request the early x values of chunk k+2 and the records of chunk k+3, and write chunk
+//     k-1's results from the ring to xp.  Two register sets swap roles every phase; no load is waited for in the phase
+//     that issued it; no stager reads what another wrote: the only synchronisation is the barrier that ends a phase.
+//   * WALKER (wave 0).  Holds the chunk's records in registers (the workgroup is alone on its CU: 512 VGPRs) and runs
+//     the levels back to back, fully unrolled: per level the x reads, the FMAs in stored order, (the division,) the ring
+//     write -- and, in the shadow of that chain, the LDS reads of the records four levels ahead.  A chunk without longer
+//     rows is straight-line code: the compiler counts the LDS operations in flight and a level's x reads go out right
+//     behind the previous level's ring write (LDS executes a wave's operations in order).
+//   * READ-AHEAD (workgroup 8 of a 9-workgroup launch: same XCD, hence the same L2).  Touches one word per 128-byte
+//     line of the chunks ten ahead of the team, paced by a progress word: the stagers' loads become L2 hits.
+// Early sources must be W2_DIST chunks back: a chunk's results leave for memory one phase after its walk, the stores
+// drain during the next phase (never waited for directly), and loads issued two phases later see them.
+// Measured (one ILU(0) application, profiles/r03_trsv.txt): G3_circuit-like 14.8 ms against 32.2 for the four-wave walk
+// of round 2 -- walker 2 870 / 4 360 cycles per chunk of ~15 levels (lower / upper: the upper solve divides), stagers
+// 3 700-3 800 -- ; the stencil system 2.1 against 3.3 (its wide levels gain from position space); cant-like (32 entries
+// a row: the rows' tails are read entry by entry) 32.2, no better than the four-wave walk's 31.8.
 // Arithmetic and order are solve_row's: bit-identical to the other schedules (tested).
 constexpr int W2_ST = 192, W2_T = 64 + W2_ST;            // wave 0 walks, waves 1-3 stage
 constexpr int W2_GRID = 9;             // workgroup 0 solves, workgroup 8 (same XCD: same L2) reads ahead, the others leave
 constexpr int W2_CH = 640;             // positions per chunk
 constexpr int W2_ECAP = 1280;          // off-diagonal entries per chunk
 constexpr int W2_SUB = 16;             // sub-levels (<= 64 rows each) per chunk: 12-14 VGPRs of records apiece in the walker
+constexpr int W2_HAS_OVF = 1 << 24;    // in a chunk header's second word (positions | early sources << 10): some row has more than W2_Q entries
+constexpr int W2_EARLY_PT = 2;         // early sources (x values read from memory) per stager thread and chunk
+constexpr unsigned W2_IN_BUF = 0x80000000u;   // a source word: LDS byte address, relative to the chunk's buffer when this bit is set
 constexpr int W2_Q = 3;                // entries of a row held in its record; a longer row reads the rest from the entry arrays
 constexpr int W2_DIST = 6;             // early sources: producer chunk <= consumer chunk - W2_DIST
 constexpr int W2_PJ = (W2_CH + W2_ST - 1) / W2_ST, W2_EJ = (W2_ECAP + W2_ST - 1) / W2_ST;
@@ -601,16 +616,20 @@ static_assert(W2_LDS_BYTES <= 160 * 1024, "one workgroup's LDS on gfx950");
 
 struct W2Pos {                         // 48 bytes per position (level order): three 16-byte loads
   double v0, v1, v2, diag;             //   values of the first three entries (0.0 when absent), the diagonal
-  unsigned c0, c1, c2, meta;           //   their sources; entries | first entry (chunk-relative) << 11
+  unsigned s0, s1, s2, meta;           //   where their x values are (source words); entries | first entry (chunk-relative) << 11
 };
-struct W2Ent {                         // 16 bytes per entry, level order
+struct W2Ent {                         // 16 bytes per entry, level order (read for chunks with longer rows only)
   double val;
-  unsigned code, pad;                  //   PK_NEAR | producer position (the ring), or the producer position (memory)
+  unsigned src, pad;                   //   source word
+};
+struct W2Early {                       // an x value a chunk reads from memory: producer position -> s_x slot (chunk-relative entry)
+  int pos, slot;
 };
 struct Walk2Tri {
   const W2Pos *pos;
   const W2Ent *ent;
-  const int4 *hdr;                     // per chunk: {first position, positions, first entry, entries},
+  const W2Early *early;
+  const int4 *hdr;                     // per chunk: {first position, positions | early sources << 10 | flag, first entry, entries}, {first early source, ...
 };                                     //   {sub-levels, widths 0-3, 4-7, 8-11 (a byte each)}, {12-15, 16-19, 20-23, sub-levels with longer rows}
 
 // walk2 works in POSITION space: bp[i] = b[order[i]] is gathered by the whole chip before the solve and xp scattered
@@ -749,7 +768,9 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
         __builtin_amdgcn_s_sleep(20);
       }
       const int4 h = t.hdr[3 * f];
-      const long p0 = 48L * h.x, p1 = 48L * (h.x + h.y), e0 = 16L * h.z, e1 = 16L * (h.z + h.w), b0 = 8L * h.x, b1 = 8L * (h.x + h.y);
+      const int fcnt = h.y & 0x3ff;
+      const long p0 = 48L * h.x, p1 = 48L * (h.x + fcnt), e0 = 16L * h.z, e1 = (h.y & W2_HAS_OVF) ? 16L * (h.z + h.w) : e0,
+                 b0 = 8L * h.x, b1 = 8L * (h.x + fcnt);
       for (long a = (p0 & ~127L) + 128L * ft; a < p1; a += 128L * W2_T)
         acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.pos) + a);
       for (long a = (e0 & ~127L) + 128L * ft; a < e1; a += 128L * W2_T)
@@ -807,12 +828,13 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
   // landed during the last phase: b[row] and the early x values are requested this phase), and the chunk after it,
   // whose x-independent loads go out at the end of the phase.  No load is waited for in the phase that issued it.
   struct Indep {                                              // what does not depend on x
-    int4 q0[W2_PJ], q1[W2_PJ], q2[W2_PJ];                     // {v0, v1} {v2, diagonal} {c0, c1, c2, meta} of a position
+    int4 q0[W2_PJ], q1[W2_PJ], q2[W2_PJ];                     // {v0, v1} {v2, diagonal} {source words, meta} of a position
     double b[W2_PJ];                                          // its right-hand side
-    int4 ent[W2_EJ];                                          // {value, code, -} of an entry
+    int4 ent[W2_EJ];                                          // {value, source word, -} of an entry (chunks with longer rows only)
+    int2 early[W2_EARLY_PT];                                  // {producer position, s_x slot} of an x value read from memory
   };
   Indep P, Q;
-  double l_x[W2_EJ];                                          // early x values of the chunk staged next
+  double l_x[W2_EARLY_PT];                                    // the early x values of the chunk staged next
   int cs1 = 0, cnt1 = 0, cs2 = 0, cnt2 = 0, cs3 = 0, cnt3 = 0;   // the last three chunks staged (3: written back next)
   auto rotate_chunks = [&]() {
     cs3 = cs2; cnt3 = cnt2;
@@ -820,10 +842,13 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
   };
   auto as_double = [](int lo, int hi) { return __hiloint2double(hi, lo); };
 
-  auto load_indep = [&](Indep &d, const int4 &h) {
-    const int cs = uniform(h.x), cnt = uniform(h.y), ebase = uniform(h.z), ecnt = uniform(h.w);
+  auto load_indep = [&](Indep &d, const int4 &h, int ebase_early) {
+    const int cs = uniform(h.x), cnt = uniform(h.y) & 0x3ff, n_early = (uniform(h.y) >> 10) & 0x3ff, ebase = uniform(h.z),
+              ecnt = uniform(h.w);
+    const bool longer = uniform(h.y) & W2_HAS_OVF;
 #pragma unroll
     for (int j = 0; j < W2_PJ; j++) {
+      if (W2_ST * j >= cnt) continue;                         // (scalar: a typical chunk fills two and a half of the four)
       const int p = cs + min(st + W2_ST * j, cnt - 1);
       const int4 *rec = reinterpret_cast<const int4 *>(t.pos + p);
       d.q0[j] = rec[0];
@@ -832,57 +857,61 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
       d.q2[j] = rec[2];
       d.b[j] = bp[p];
     }
+    if (longer) {                                             // (the entry arrays repeat what the records hold)
 #pragma unroll
-    for (int j = 0; j < W2_EJ; j++)
-      d.ent[j] = *reinterpret_cast<const int4 *>(t.ent + ebase + min(st + W2_ST * j, max(ecnt - 1, 0)));
+      for (int j = 0; j < W2_EJ; j++)
+        d.ent[j] = *reinterpret_cast<const int4 *>(t.ent + ebase + min(st + W2_ST * j, max(ecnt - 1, 0)));
+    }
+#pragma unroll
+    for (int j = 0; j < W2_EARLY_PT; j++)
+      if (W2_ST * j < n_early)
+        d.early[j] = *reinterpret_cast<const int2 *>(t.early + ebase_early + min(st + W2_ST * j, n_early - 1));
   };
   auto load_dep = [&](const Indep &d, const int4 &h) {        // xp[producer position] of the early sources
-    const int ecnt = uniform(h.w);
+    const int n_early = (uniform(h.y) >> 10) & 0x3ff;
 #pragma unroll
-    for (int j = 0; j < W2_EJ; j++) {
-      const unsigned code = (unsigned)d.ent[j].z;
-      const bool early = st + W2_ST * j < ecnt && !(code & PK_NEAR);
-      l_x[j] = __hip_atomic_load(xp + (early ? code : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int j = 0; j < W2_EARLY_PT; j++)
+      if (W2_ST * j < n_early) l_x[j] = __hip_atomic_load(xp + d.early[j].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto stage = [&](const Indep &d, const int4 &h, int which) {  // registers -> buffer `which`
-    const int cs = uniform(h.x), cnt = uniform(h.y), ecnt = uniform(h.w);
+    const int cs = uniform(h.x), cnt = uniform(h.y) & 0x3ff, n_early = (uniform(h.y) >> 10) & 0x3ff, ecnt = uniform(h.w);
+    const bool longer = uniform(h.y) & W2_HAS_OVF;
     const int base = buf_base(which);
-    // a near value is read from the ring, an early one from the buffer's s_x, an absent one from the constant 0.0
-    auto source = [&](unsigned code, int e, bool present) {
-      return !present ? W2_ZERO : (code & PK_NEAR) ? (int)((code & (PK_RING - 1)) * 8u) : base + OFF_X + 8 * e;
-    };
+    // a source word is an LDS byte address: of a ring slot or the constant 0.0 as it stands, of an s_x slot of this
+    // chunk's buffer when W2_IN_BUF is set (the host cannot know which of the two buffers the chunk gets)
+    auto address = [&](unsigned word) { return (int)(word & ~W2_IN_BUF) + ((word & W2_IN_BUF) ? base : 0); };
 #pragma unroll
     for (int j = 0; j < W2_PJ; j++) {
       const int p = st + W2_ST * j;
+      if (W2_ST * j >= cnt) continue;
       if (p < cnt) {
-        const unsigned meta = (unsigned)d.q2[j].w;
-        const int ne = (int)(meta & 0x7ffu), e0 = (int)((meta >> 11) & 0x7ffu);
         pk_dbl2 a, bb;
         pk_int4 c;
         a.x = d.b[j]; a.y = as_double(d.q0[j].x, d.q0[j].y);
         bb.x = as_double(d.q0[j].z, d.q0[j].w); bb.y = as_double(d.q1[j].x, d.q1[j].y);
-        c.x = source((unsigned)d.q2[j].x, e0, ne > 0);
-        c.y = source((unsigned)d.q2[j].y, e0 + 1, ne > 1);
-        c.z = source((unsigned)d.q2[j].z, e0 + 2, ne > 2);
-        c.w = (int)meta;
+        c.x = address((unsigned)d.q2[j].x);
+        c.y = address((unsigned)d.q2[j].y);
+        c.z = address((unsigned)d.q2[j].z);
+        c.w = d.q2[j].w;
         *reinterpret_cast<pk_dbl2 *>(lds_bytes + base + 16 * p) = a;
         *reinterpret_cast<pk_dbl2 *>(lds_bytes + base + OFF_B + 16 * p) = bb;
         *reinterpret_cast<pk_int4 *>(lds_bytes + base + OFF_C + 16 * p) = c;
         if constexpr (!UNIT) *reinterpret_cast<double *>(lds_bytes + base + OFF_D + 8 * p) = as_double(d.q1[j].z, d.q1[j].w);
       }
     }
+    if (longer) {
 #pragma unroll
-    for (int j = 0; j < W2_EJ; j++) {
-      const int e = st + W2_ST * j;
-      if (e < ecnt) {
-        const unsigned code = (unsigned)d.ent[j].z;
-        *reinterpret_cast<double *>(lds_bytes + base + OFF_VAL + 8 * e) = as_double(d.ent[j].x, d.ent[j].y);
-        *reinterpret_cast<double *>(lds_bytes + base + OFF_X + 8 * e) = l_x[j];
-        *reinterpret_cast<int *>(lds_bytes + base + OFF_SRC + 4 * e) =
-            (code & PK_NEAR) ? (int)((code & (PK_RING - 1)) * 8u) : base + OFF_X + 8 * e;
+      for (int j = 0; j < W2_EJ; j++) {
+        const int e = st + W2_ST * j;
+        if (e < ecnt) {
+          *reinterpret_cast<double *>(lds_bytes + base + OFF_VAL + 8 * e) = as_double(d.ent[j].x, d.ent[j].y);
+          *reinterpret_cast<int *>(lds_bytes + base + OFF_SRC + 4 * e) = address((unsigned)d.ent[j].z);
+        }
       }
     }
+#pragma unroll
+    for (int j = 0; j < W2_EARLY_PT; j++)                     // the x values read from memory, where the source words point
+      if (st + W2_ST * j < n_early) *reinterpret_cast<double *>(lds_bytes + base + OFF_X + 8 * d.early[j].y) = l_x[j];
     rotate_chunks();
     cs1 = cs; cnt1 = cnt;
   };
@@ -905,15 +934,18 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
   // x-independent part of chunk k + 2 (its b[row] and early x values are requested now).  No load is waited for in the
   // phase that issued it.  Chunk headers travel ahead of their loads.
   auto hdr_at = [&](int k) { return t.hdr[3 * min(k, c1 - 1)]; };
+  auto early_at = [&](int k) { return uniform(t.hdr[3 * min(k, c1 - 1) + 1].x); };   // first early source of a chunk
   int4 hA = hdr_at(c0), hB = hdr_at(c0 + 1), hC = hdr_at(c0 + 2), hD = hdr_at(c0 + 3);
-  load_indep(P, hA);
-  load_indep(Q, hB);
-  load_dep(P, hA);                                            // (waits for P's codes)
+  int eC = early_at(c0 + 2), eD = early_at(c0 + 3);
+  load_indep(P, hA, early_at(c0));
+  load_indep(Q, hB, early_at(c0 + 1));
+  load_dep(P, hA);                                            // (waits for P's early list)
   stage(P, hA, 0);                                            // chunk c0 (waits for everything)
   load_dep(Q, hB);                                            // chunk c0 + 1
-  load_indep(P, hC);                                          // chunk c0 + 2
+  load_indep(P, hC, eC);                                      // chunk c0 + 2
   hA = hB; hB = hC; hC = hD; hD = hdr_at(c0 + 4);
-  unsigned long long e_wait = 0, e_work = 0;
+  eC = eD; eD = early_at(c0 + 4);
+  unsigned long long e_wait = 0, e_work = 0, e_a = 0, e_b = 0, e_c = 0, e_d = 0;
   auto phase = [&](Indep &X, Indep &Y, int k) {               // X = chunk k + 1, Y = chunk k + 2 (x-independent part)
     const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     w2_barrier();                                             // phase k: the walker is on chunk k
@@ -926,20 +958,25 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
     // producer's chunk + W2_DIST.
     static_assert(W2_PJ == 4, "the vmcnt immediate below counts the W2_PJ = 4 write-back stores per thread");
     __builtin_amdgcn_s_waitcnt(0x0F74);                       // vmcnt 4, expcnt 7, lgkmcnt 15
+    const unsigned long long q2 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     if (tid == 64) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (paces the read-ahead workgroup)
     if (k + 1 < c1) stage(X, hA, (k + 1 - c0) & 1);           // chunk k + 1
     else rotate_chunks();
+    if (dbg) __builtin_amdgcn_s_waitcnt(0xC07F);
+    const unsigned long long q3 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     if (k + 2 < c1) load_dep(Y, hB);                          // chunk k + 2
-    if (k + 3 < c1) load_indep(X, hC);                        // chunk k + 3
+    if (k + 3 < c1) load_indep(X, hC, eC);                    // chunk k + 3
     hA = hB; hB = hC; hC = hD; hD = hdr_at(k + 5);
+    eC = eD; eD = early_at(k + 5);
+    const unsigned long long q4 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     write_back3();                                            // chunk k - 1 (nothing in the first phase): the youngest operations
-    if (dbg) { e_wait += q1 - q0; e_work += __builtin_amdgcn_s_memtime() - q1; }
+    if (dbg) { const unsigned long long q5 = __builtin_amdgcn_s_memtime(); e_wait += q1 - q0; e_work += q5 - q1; e_a += q2 - q1; e_b += q3 - q2; e_c += q4 - q3; e_d += q5 - q4; }
   };
   for (int k = c0; k < c1; k += 2) {
     phase(Q, P, k);
     if (k + 1 < c1) phase(P, Q, k + 1);
   }
-  if (dbg && tid == 64) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
+  if (dbg && tid == 64) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); atomicAdd(dbg + 8, e_a); atomicAdd(dbg + 9, e_b); atomicAdd(dbg + 10, e_c); atomicAdd(dbg + 11, e_d); }
   w2_barrier();                                               // the last chunk is walked
   rotate_chunks();
   write_back3();
@@ -1068,11 +1105,12 @@ struct TriFactor {
   // ... and once more for k_trsv_walk2 (CASK_HIP_TRSV=walk2): per-position records, its own chunks [d0,d1) per step
   DevBuf<W2Pos> w2_pos;
   DevBuf<W2Ent> w2_ent;
+  DevBuf<W2Early> w2_early;
   DevBuf<int> w2_eptr, w2_epos;
   DevBuf<double> w2_eval, w2_pdiag;
   mutable DevBuf<double> w2_bp, w2_xp;             // the right-hand side and the result in position space
   mutable DevBuf<int> w2_progress;                 // the chunk the team is on (paces the read-ahead workgroup)
-  bool w2_ok = false;
+  bool w2_ok = false, walk2 = false;                // walk2: this factor is solved by k_trsv_walk2 (position space)
   DevBuf<int4> w2_hdr;
   mutable DevBuf<unsigned long long> w2_dbg;
   DevBuf<int> sync;                                   // [0] chunk counter, [1] error flag of the sync-free solve
@@ -1114,12 +1152,17 @@ struct TriFactor {
       steps.push_back(Step{l, e, lp[l], lp[e], false, -1, -1, false});
       l = e;
     }
-    int rc = build_packed(h_rp, h_ci, h_val, level, lp, ord);
-    if (rc) return rc;
-    if (forced_mode() == 4) {
-      rc = build_walk2(h_rp, h_ci, h_val, level, lp, ord);
-      if (rc) return rc;
+    bool any_long = false;
+    for (Step &st : steps) {
+      if (st.wide) continue;
+      int64_t ents = 0;
+      for (int i = st.lo; i < st.hi; i++) ents += h_rp[ord[i] + 1] - h_rp[ord[i]] - 1;
+      st.long_rows = ents > 6 * (int64_t)(st.hi - st.lo);      // more than 6 entries a row on average
+      any_long = any_long || st.long_rows;
     }
+    walk2 = forced_mode() == 4 || (forced_mode() == 0 && !any_long);
+    int rc = walk2 ? build_walk2(h_rp, h_ci, h_val, level, lp, ord) : build_packed(h_rp, h_ci, h_val, level, lp, ord);
+    if (rc) return rc;
     PC_TRY(rp.upload(h_rp));
     PC_TRY(ci.upload(h_ci));
     PC_TRY(val.upload(h_val));
@@ -1254,9 +1297,7 @@ struct TriFactor {
                   const std::vector<int> &level, const std::vector<int> &lp, const std::vector<int> &ord) {
     std::vector<int> pos_of((size_t)n), peptr((size_t)n + 1, 0), ppos;
     for (int i = 0; i < n; i++) pos_of[ord[i]] = i;
-    std::vector<unsigned> pcode, pmeta((size_t)n + 1, 0u), pc0((size_t)n + 1, PK_NEAR), pc1((size_t)n + 1, PK_NEAR),
-        pc2((size_t)n + 1, PK_NEAR);
-    std::vector<double> pval, pdiag((size_t)n + 1, 1.0), pv0((size_t)n + 1, 0.0), pv1((size_t)n + 1, 0.0), pv2((size_t)n + 1, 0.0);
+    std::vector<double> pval, pdiag((size_t)n + 1, 1.0);
     ppos.reserve(h_ci.size());
     pval.reserve(h_ci.size());
     for (int i = 0; i < n; i++) {
@@ -1271,27 +1312,55 @@ struct TriFactor {
       }
       peptr[i + 1] = (int)ppos.size();
     }
-    pcode.assign(ppos.begin(), ppos.end());                   // a position in memory (early) unless marked near below
+    // where an entry's x value is: the ring (near: the producer is within PK_RING positions of the consumer's level end,
+    // in this step) or memory (early: it must then be W2_DIST chunks back, checked below)
+    std::vector<unsigned char> is_early(ppos.size() + 1, 0);
+    std::vector<int> early_in_row((size_t)n + 1, 0);
+    std::vector<int> step_lo((size_t)n, 0);
+    for (const Step &st : steps)
+      for (int i = st.lo; i < st.hi; i++) step_lo[i] = st.lo;
+    for (int i = 0; i < n; i++) {
+      const int level_end = lp[level[ord[i]] + 1];
+      for (int e = peptr[i]; e < peptr[i + 1]; e++) {
+        const int pp = ppos[e];
+        is_early[e] = !(pp >= step_lo[i] && pp >= level_end - PK_RING);
+        early_in_row[i] += is_early[e];
+      }
+    }
+    constexpr int OFF_X_IN_BUF = 56 * W2_RECS + 8 * W2_ECAP;   // (k_trsv_walk2's OFF_X)
     std::vector<int4> hdr;
+    std::vector<W2Early> early_list;
+    std::vector<W2Pos> apos((size_t)n + 1);
+    std::vector<W2Ent> aent(ppos.size() + 1);
+    for (int i = 0; i <= n; i++) {
+      apos[i] = W2Pos{0.0, 0.0, 0.0, pdiag[i], (unsigned)W2_ZERO, (unsigned)W2_ZERO, (unsigned)W2_ZERO, 0u};
+    }
+    for (size_t e = 0; e < aent.size(); e++) aent[e] = W2Ent{0.0, (unsigned)W2_ZERO, 0u};
     std::vector<int> chunk_of((size_t)n, 0);
     for (Step &st : steps) {
       if (st.wide) continue;
-      struct Chunk { int cs, ce, n_sub; unsigned char width[W2_SUB]; };
+      struct Chunk { int cs, ce, n_sub, n_early; unsigned char width[W2_SUB]; };
       std::vector<Chunk> chunks;
       bool ok = true;
-      Chunk cur{st.lo, st.lo, 0, {}};
+      Chunk cur{st.lo, st.lo, 0, 0, {}};
       for (int i = st.lo; i < st.hi && ok;) {
         // the next sub-level: rows of i's level, at most 64, at most W2_ECAP entries
         const int level_end = lp[level[ord[i]] + 1];
-        int e = i;
-        while (e < level_end && e - i < 64 && peptr[e + 1] - peptr[i] <= W2_ECAP) e++;
-        if (e == i) { ok = false; break; }                    // one row with more than W2_ECAP entries
-        const bool fits = cur.n_sub < W2_SUB && e - cur.cs <= W2_CH && peptr[e] - peptr[cur.cs] <= W2_ECAP;
+        int e = i, early = 0;
+        while (e < level_end && e - i < 64 && peptr[e + 1] - peptr[i] <= W2_ECAP &&
+               early + early_in_row[e] <= W2_EARLY_PT * W2_ST) {
+          early += early_in_row[e];
+          e++;
+        }
+        if (e == i) { ok = false; break; }                    // one row with more than W2_ECAP entries (or early sources)
+        const bool fits = cur.n_sub < W2_SUB && e - cur.cs <= W2_CH && peptr[e] - peptr[cur.cs] <= W2_ECAP &&
+                          cur.n_early + early <= W2_EARLY_PT * W2_ST;
         if (!fits) {
           chunks.push_back(cur);
-          cur = Chunk{i, i, 0, {}};
+          cur = Chunk{i, i, 0, 0, {}};
         }
         cur.width[cur.n_sub++] = (unsigned char)(e - i);
+        cur.n_early += early;
         cur.ce = e;
         i = e;
       }
@@ -1299,24 +1368,38 @@ struct TriFactor {
       if (!ok || chunks.empty()) continue;
       for (size_t k = 0; k < chunks.size(); k++)
         for (int i = chunks[k].cs; i < chunks[k].ce; i++) chunk_of[i] = (int)k;
+      const size_t early0 = early_list.size();
       for (size_t k = 0; k < chunks.size() && ok; k++) {
         const Chunk &ch = chunks[k];
         for (int i = ch.cs; i < ch.ce && ok; i++) {
-          const int level_end = lp[level[ord[i]] + 1];
           const int ne = peptr[i + 1] - peptr[i], e0 = peptr[i] - peptr[ch.cs];
+          unsigned word[W2_Q] = {(unsigned)W2_ZERO, (unsigned)W2_ZERO, (unsigned)W2_ZERO};
           for (int e = peptr[i]; e < peptr[i + 1]; e++) {
-            const int pp = ppos[e];
-            if (pp >= st.lo && pp >= level_end - PK_RING) pcode[e] = PK_NEAR | (unsigned)pp;
-            else if (pp >= st.lo && chunk_of[pp] > (int)k - W2_DIST) { ok = false; break; }   // (the static_assert rules it out)
+            const int pp = ppos[e], slot = e - peptr[ch.cs];
+            unsigned src;
+            if (!is_early[e]) src = (unsigned)(pp & (PK_RING - 1)) * 8u;
+            else {
+              if (pp >= st.lo && chunk_of[pp] > (int)k - W2_DIST) { ok = false; break; }   // (the static_assert rules it out)
+              src = W2_IN_BUF | (unsigned)(OFF_X_IN_BUF + 8 * slot);
+              early_list.push_back(W2Early{pp, slot});
+            }
+            aent[e] = W2Ent{pval[e], src, 0u};
+            if (e - peptr[i] < W2_Q) word[e - peptr[i]] = src;
           }
-          pmeta[i] = (unsigned)ne | ((unsigned)e0 << 11);
-          if (ne > 0) { pv0[i] = pval[peptr[i]]; pc0[i] = pcode[peptr[i]]; }
-          if (ne > 1) { pv1[i] = pval[peptr[i] + 1]; pc1[i] = pcode[peptr[i] + 1]; }
-          if (ne > 2) { pv2[i] = pval[peptr[i] + 2]; pc2[i] = pcode[peptr[i] + 2]; }
+          W2Pos &q = apos[i];
+          q.s0 = word[0]; q.s1 = word[1]; q.s2 = word[2];
+          q.meta = (unsigned)ne | ((unsigned)e0 << 11);
+          if (ne > 0) q.v0 = pval[peptr[i]];
+          if (ne > 1) q.v1 = pval[peptr[i] + 1];
+          if (ne > 2) q.v2 = pval[peptr[i] + 2];
         }
       }
-      if (!ok) continue;                                      // (cannot happen; the step runs k_trsv_levels_p)
+      if (!ok) {                                              // (cannot happen; the step runs k_trsv_levels_p)
+        early_list.resize(early0);
+        continue;
+      }
       st.d0 = (int)(hdr.size() / 3);
+      size_t early_at = early0;
       for (const Chunk &ch : chunks) {
         int w[6] = {0, 0, 0, 0, 0, 0}, ovf = 0, at = ch.cs;
         for (int q = 0; q < ch.n_sub; q++) {
@@ -1325,28 +1408,21 @@ struct TriFactor {
             if (peptr[i + 1] - peptr[i] > W2_Q) ovf |= 1 << q;   // a row with more entries than its record holds
           at += ch.width[q];
         }
-        hdr.push_back(make_int4(ch.cs, ch.ce - ch.cs, peptr[ch.cs], peptr[ch.ce] - peptr[ch.cs]));
-        hdr.push_back(make_int4(ch.n_sub, w[0], w[1], w[2]));
+        hdr.push_back(make_int4(ch.cs, (ch.ce - ch.cs) | (ch.n_early << 10) | (ovf ? W2_HAS_OVF : 0), peptr[ch.cs],
+                                peptr[ch.ce] - peptr[ch.cs]));
+        hdr.push_back(make_int4((int)early_at, w[0], w[1], w[2]));
         hdr.push_back(make_int4(w[3], w[4], w[5], ovf));
+        early_at += ch.n_early;
       }
       st.d1 = (int)(hdr.size() / 3);
     }
-    pcode.push_back(0u);                                      // spare elements: the kernel's clamped loads
-    pval.push_back(0.0);
+    pval.push_back(0.0);                                      // spare elements: the kernels' clamped loads
     ppos.push_back(0);
+    early_list.push_back(W2Early{0, 0});
     if (hdr.empty()) hdr.push_back(make_int4(0, 0, 0, 0));
-    {
-      std::vector<W2Pos> apos((size_t)n + 1);
-      for (int i = 0; i <= n; i++) {
-        W2Pos &q = apos[i];
-        q.v0 = pv0[i]; q.v1 = pv1[i]; q.v2 = pv2[i]; q.diag = pdiag[i];
-        q.c0 = pc0[i]; q.c1 = pc1[i]; q.c2 = pc2[i]; q.meta = pmeta[i];
-      }
-      std::vector<W2Ent> aent(pcode.size());
-      for (size_t e = 0; e < pcode.size(); e++) aent[e] = W2Ent{pval[e], pcode[e], 0u};
-      PC_TRY(w2_pos.upload(apos));
-      PC_TRY(w2_ent.upload(aent));
-    }
+    PC_TRY(w2_pos.upload(apos));
+    PC_TRY(w2_ent.upload(aent));
+    PC_TRY(w2_early.upload(early_list));
     PC_TRY(w2_eptr.upload(peptr));                            // the position-space CSR of the wide levels' kernel
     PC_TRY(w2_epos.upload(ppos));
     PC_TRY(w2_eval.upload(pval));
@@ -1355,7 +1431,11 @@ struct TriFactor {
     PC_TRY(w2_xp.alloc((size_t)n + 1));
     PC_TRY(w2_progress.alloc(1));
     PC_TRY(w2_hdr.upload(hdr));
-    if (std::getenv("W2_DBG")) { PC_TRY(w2_dbg.alloc(8)); PC_TRY(hipMemset(w2_dbg.p, 0, 64)); }
+    if (std::getenv("CASK_HIP_TRSV_STATS")) {               // cycles per chunk by role, printed after every solve
+      PC_TRY(w2_dbg.alloc(12));
+      PC_TRY(hipMemset(w2_dbg.p, 0, 96));
+      std::fprintf(stderr, "walk2 %s: %zu chunks, %zu x values read from memory\n", lower ? "L" : "U", hdr.size() / 3, early_list.size() - 1);
+    }
     int dev = 0, lds_max = 0;
     w2_ok = hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
@@ -1383,12 +1463,16 @@ struct TriFactor {
   // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
   // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
   // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
-  static int forced_mode() {     // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk), 3 = walk1 (one walker wave, r3), 4 = walk2 (walker + stagers)
+  // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk, r1), 3 = walk1 (one walker wave, r3), 4 = walk2 (walker +
+  // stagers + read-ahead, position space), 5 = packed (the four-wave walk, r2).  Unset (0): walk2, except for a factor
+  // whose narrow levels have long rows (an FEM factor: the four-wave walk reads a row's tail 16 entries at a time and is
+  // the faster one there -- cant-like 31.7 against 32-40 ms).
+  static int forced_mode() {
     static const int mode = [] {
       const char *force = std::getenv("CASK_HIP_TRSV");
       if (!force) return 0;
       const std::string f(force);
-      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : f == "walk2" ? 4 : 0;
+      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : 0;
     }();
     return mode;
   }
@@ -1404,8 +1488,8 @@ struct TriFactor {
       PC_TRY(hipGetLastError());
       return CASK_HIP_OK;
     }
-    if (forced_mode() == 4 && n > 0 && w2_bp.p) {              // CASK_HIP_TRSV=walk2: the whole solve in position space
-      const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_hdr.p};
+    if (walk2 && n > 0 && w2_bp.p) {                            // the whole solve in position space
+      const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_early.p, w2_hdr.p};
       const int pg = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256), u = unit ? 1 : 0;
       PC_TRY(hipMemsetAsync(w2_progress.p, 0, sizeof(int), s));
       hipLaunchKernelGGL(k_w2_gather, dim3(pg), dim3(256), 0, s, n, order.p, d_b, w2_bp.p);
@@ -1428,13 +1512,14 @@ struct TriFactor {
       hipLaunchKernelGGL(k_w2_scatter, dim3(pg), dim3(256), 0, s, n, order.p, w2_xp.p, d_x);
       PC_TRY(hipGetLastError());
       if (w2_dbg.p) {
-        unsigned long long h[8];
+        unsigned long long h[12];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, w2_dbg.p, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipMemset(w2_dbg.p, 0, sizeof(h));
         if (h[3])
-          std::fprintf(stderr, "walk2 %s: chunks %llu | cycles/chunk: walker at the barrier %.0f, walking %.0f | stagers at the barrier %.0f, working %.0f\n",
-                       lower ? "L" : "U", h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[4] / h[3], (double)h[6] / h[3]);
+          std::fprintf(stderr, "walk2 %s: chunks %llu | cycles/chunk: walker at the barrier %.0f, walking %.0f | stagers at the barrier %.0f, working %.0f (load wait %.0f, stage %.0f, issue loads %.0f, write back %.0f)\n",
+                       lower ? "L" : "U", h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[4] / h[3], (double)h[6] / h[3],
+                       (double)h[8] / h[3], (double)h[9] / h[3], (double)h[10] / h[3], (double)h[11] / h[3]);
       }
       return CASK_HIP_OK;
     }
