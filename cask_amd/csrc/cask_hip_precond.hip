@@ -115,7 +115,11 @@ struct PackedTri {
   const double *diag, *val;
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (the wait as a builtin, not asm: the compiler's wait-count bookkeeping sees it -- see w2_barrier)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);                         // vmcnt 63, expcnt 7, lgkmcnt 0
+  __builtin_amdgcn_s_barrier();
+}
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LONG: the rows of the step have many entries (an FEM factor): the entries beyond the prepared ones are read PK_U at a
