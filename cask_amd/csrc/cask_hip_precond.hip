@@ -852,12 +852,16 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
     const bool longer = uniform(h.y) & W2_HAS_OVF;
 #pragma unroll
     for (int j = 0; j < W2_PJ; j++) {
-      if (W2_ST * j >= cnt) continue;                         // (scalar: a typical chunk fills two and a half of the four)
+      // (unconditional, clamped: a conditional load would be merged with the register's old value through a copy, and
+      // the copy waits for the load -- 700 cycles each, one after the other)
       const int p = cs + min(st + W2_ST * j, cnt - 1);
       const int4 *rec = reinterpret_cast<const int4 *>(t.pos + p);
       d.q0[j] = rec[0];
-      if constexpr (UNIT) { d.q1[j].x = reinterpret_cast<const int *>(rec)[4]; d.q1[j].y = reinterpret_cast<const int *>(rec)[5]; }
-      else d.q1[j] = rec[1];
+      if constexpr (UNIT) {                                   // (v2 only: one 8-byte load, not half of a 16-byte one)
+        const int2 v2 = *reinterpret_cast<const int2 *>(rec + 1);
+        d.q1[j].x = v2.x;
+        d.q1[j].y = v2.y;
+      } else d.q1[j] = rec[1];
       d.q2[j] = rec[2];
       d.b[j] = bp[p];
     }
@@ -868,14 +872,13 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
     }
 #pragma unroll
     for (int j = 0; j < W2_EARLY_PT; j++)
-      if (W2_ST * j < n_early)
-        d.early[j] = *reinterpret_cast<const int2 *>(t.early + ebase_early + min(st + W2_ST * j, n_early - 1));
+      d.early[j] = *reinterpret_cast<const int2 *>(t.early + ebase_early + min(st + W2_ST * j, max(n_early - 1, 0)));
   };
   auto load_dep = [&](const Indep &d, const int4 &h) {        // xp[producer position] of the early sources
     const int n_early = (uniform(h.y) >> 10) & 0x3ff;
 #pragma unroll
     for (int j = 0; j < W2_EARLY_PT; j++)
-      if (W2_ST * j < n_early) l_x[j] = __hip_atomic_load(xp + d.early[j].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l_x[j] = __hip_atomic_load(xp + (st + W2_ST * j < n_early ? d.early[j].x : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto stage = [&](const Indep &d, const int4 &h, int which) {  // registers -> buffer `which`
     const int cs = uniform(h.x), cnt = uniform(h.y) & 0x3ff, n_early = (uniform(h.y) >> 10) & 0x3ff, ecnt = uniform(h.w);
