@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -317,7 +318,13 @@ int cask_hip_push_check(cask_hip_push *p) {
 int cask_hip_shared_alloc(int64_t bytes, void **d_ptr_out, unsigned char *handle_out) {
   if (bytes <= 0 || !d_ptr_out || !handle_out) return caskhip::report_failure(CASK_HIP_ERR_INVALID, "bad argument");
   void *p = nullptr;
-  P2P_TRY(hipMalloc(&p, (size_t)bytes));
+  // FINE-GRAINED device memory: peers store into this region and its owner polls flags in it INSIDE a kernel.  Ordinary
+  // (coarse-grained) memory is coherent across devices at kernel boundaries only -- a polled flag line may sit stale in
+  // the owner's L2 -- whereas fine-grained memory is coherent at system scope.  (CASK_HIP_SHARED_COARSE=1: plain hipMalloc,
+  // for comparison on one GPU.)
+  static const bool coarse = std::getenv("CASK_HIP_SHARED_COARSE") != nullptr;
+  if (coarse) P2P_TRY(hipMalloc(&p, (size_t)bytes));
+  else P2P_TRY(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
   hipError_t e = hipMemset(p, 0, (size_t)bytes);
   hipIpcMemHandle_t h;
   if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);

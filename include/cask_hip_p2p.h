@@ -27,7 +27,8 @@ extern "C" {
 
 #define CASK_HIP_SHARED_HANDLE_BYTES 64
 
-/* Allocate `bytes` of zeroed device memory on the current device and export it.
+/* Allocate `bytes` of zeroed FINE-GRAINED device memory on the current device (coherent at system scope while
+ * kernels run: peers store into it and its owner polls flags in it) and export it.
  * handle_out receives CASK_HIP_SHARED_HANDLE_BYTES bytes to pass to the peer processes
  * (any byte transport: torch.distributed object collectives, a file, a socket). */
 int cask_hip_shared_alloc(int64_t bytes, void **d_ptr_out, unsigned char *handle_out);
