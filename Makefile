@@ -81,11 +81,19 @@ build/membench: tools/membench.hip
 build/membench2: tools/membench2.hip
 	mkdir -p build
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+# round-3 microbenchmarks: one-launch streaming floor, the SCAN block shape, grid-wide hand-off, gather flavours
+build/streamfloor build/scanfloor build/gatherbench build/lds_granule: build/%: tools/%.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+build/gridsync: tools/gridsync_bench.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+microbench: build/membench build/membench2 build/streamfloor build/scanfloor build/gatherbench build/gridsync
 
 clean:
 	rm -rf $(LIBDIR) build oracle/_build
 
-.PHONY: all oracle clean clients
+.PHONY: all oracle clean clients microbench
 
 # diagnostic build with in-kernel phase stamps (tools/stamps.py); never used by tests or bench
 build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
