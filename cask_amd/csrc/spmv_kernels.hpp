@@ -101,6 +101,7 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
   const int rows_per_wg = (blockDim.x / L) * VEC_RG;
   const int j = lane & (L - 1), q = lane / L;
   const int row0 = wg * rows_per_wg + wave * (RPW * VEC_RG) + q;
+  CASK_STAMP(0);
   if (nnz == 0) {                                             // nothing to stream (and no valid pair to clamp to)
 #pragma unroll
     for (int g = 0; g < VEC_RG; g++)
@@ -146,11 +147,17 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
       c[g][u] = stream_load<NT>(ci2 + p);
     }
   }
+  CASK_STAMP(1);                                              // the row bounds have arrived: the stream is requested
   if (LDSX && in_lds) {
 #pragma unroll
     for (int u = 0; u < VEC_XW; u++) xs[u * blockDim.x + tid] = xw[u];
     __syncthreads();
   }
+  CASK_STAMP(2);
+#ifdef CASK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CASK_STAMP(3);                                              // the stream has landed
+#endif
   double acc[VEC_RG];
 #pragma unroll
   for (int g = 0; g < VEC_RG; g++) {
@@ -186,11 +193,13 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
       if (2 * p + 1 < e[g]) acc[g] = fma(vv.y, x1, acc[g]);
     }
   }
+  CASK_STAMP(4);
 #pragma unroll
   for (int g = 0; g < VEC_RG; g++) {
     const double r = group_sum<L>(acc[g]);
     if (j == 0 && row0 + g * RPW < n_rows) y[row0 + g * RPW] = r;
   }
+  CASK_STAMP(5);
 }
 
 // --------------------------------------------- merge variant, pipelined waves

@@ -240,8 +240,9 @@ def test_triangular_solve_schedules_agree_bit_for_bit():
     default for long-row factors), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
     (CASK_HIP_TRSV=syncfree).  All walk every row in stored order: identical bits -- on a grid factor with thousands
     of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
-    per level run, entry-capped chunks) and an arrow matrix whose last row is longer than a chunk can hold (that
-    step falls back to the row-indexed walk)."""
+    per level run, entry-capped chunks), an arrow matrix whose last row is longer than a chunk can hold (that
+    step falls back to the row-indexed walk) and a ragged random triangle (rows of 0-9 entries, sources near, beyond
+    the LDS ring and anywhere)."""
     import os
     import subprocess
     import sys
@@ -258,10 +259,31 @@ def arrow(n):
     va = rng.uniform(0.5, 1.5, ci.size)
     va[rp[1:] - 1] += 4.0
     return n, rp, ci, va
+def ragged(n):
+    """rows of 0..9 lower entries (Poisson 2.6): records with absent entries, rows longer than a record holds, sources
+    a few rows back (deep levels), a few thousand back (beyond the LDS ring: read from memory) and anywhere"""
+    rows = []
+    for i in range(n):
+        k = min(int(rng.poisson(2.6)), i)
+        near = i - 1 - rng.geometric(0.3, size=k)
+        far = rng.integers(0, max(i, 1), size=k)
+        mid = i - rng.integers(4000, 9000, size=k)
+        pick = rng.random(k)
+        cols = np.where(pick < 0.6, near, np.where(pick < 0.8, mid, far))
+        cols = np.unique(cols[(cols >= 0) & (cols < i)])
+        rows.append(np.concatenate([cols, [i]]))
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+    ci = np.concatenate(rows).astype(np.int32)
+    va = rng.uniform(-1.0, 1.0, ci.size)
+    va[rp[1:] - 1] = rng.uniform(2.0, 3.0, n) * rng.choice([-1.0, 1.0], n)
+    return n, rp, ci, va
 cases = [synth.small("G3_circuit", factor=16), synth.small("atmosmodd", factor=32),
-         synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000)]
-for n, rp, ci, va in cases:
+         synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000), ragged(30000)]
+for case_no, (n, rp, ci, va) in enumerate(cases):
     r = rng.standard_normal(n)
+    if case_no == 4:                                       # a triangular matrix as it stands: no factorisation
+        out.append(capi.trsolve(n, rp, ci, va, r, lower=True))
+        continue
     for kind in ("ilu0_unit", "ilu0"):
         pc = capi.Preconditioner(kind, n, rp, ci, va)
         out.append(pc.apply(r))

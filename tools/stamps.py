@@ -23,7 +23,10 @@ def main():
     dev = torch.device("cuda", 0)
     copies = 13 if name == "cant" else 5
     rp_t = torch.from_numpy(rp).to(dev)
-    prm = capi.make_params(variant=variant, wg_size=wg, items_per_thread=ipt, tile_width=tile)
+    lanes = int(sys.argv[6]) if len(sys.argv) > 6 else 32         # "vector": lanes per row; phases 0 entry, 1 row bounds arrived
+    #   (stream requested), 2 window parked, 3 stream landed, 4 gathers + FMAs, 5 rows stored
+    prm = (capi.make_params(variant=variant, wg_size=wg, lanes_per_row=lanes, tile_width=tile) if variant == "vector" else
+           capi.make_params(variant=variant, wg_size=wg, items_per_thread=ipt, tile_width=tile))
     print(name, variant, "wg", wg, "items", ipt, "tile", tile)
     mats = [capi.CsrMatrix.from_device(n, n, rp_t, torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), prm)
             for _ in range(copies)]
