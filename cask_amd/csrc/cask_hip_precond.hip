@@ -594,7 +594,8 @@ k_trsv_walk1(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b
 // Measured (one ILU(0) application, profiles/r03_trsv.txt): G3_circuit-like 14.8 ms against 32.2 for the four-wave walk
 // of round 2 -- walker 2 870 / 4 360 cycles per chunk of ~15 levels (lower / upper: the upper solve divides), stagers
 // 3 700-3 800 -- ; the stencil system 2.1 against 3.3 (its wide levels gain from position space); cant-like (32 entries
-// a row: the rows' tails are read entry by entry) 32.2, no better than the four-wave walk's 31.8.
+// a row) 16.3 against 31.7: in a step of long rows a row's tail is padded to W2_TAIL entries of +0.0 x (constant 0.0) and
+// taken W2_TAIL at a time, no index clamped, no product masked (with clamps and masks: 32-40 ms).
 // Arithmetic and order are solve_row's: bit-identical to the other schedules (tested).
 constexpr int W2_ST = 192, W2_T = 64 + W2_ST;            // wave 0 walks, waves 1-3 stage
 constexpr int W2_GRID = 9;             // workgroup 0 solves, workgroup 8 (same XCD: same L2) reads ahead, the others leave
@@ -604,6 +605,7 @@ constexpr int W2_SUB = 16;             // sub-levels (<= 64 rows each) per chunk
 constexpr int W2_HAS_OVF = 1 << 24;    // in a chunk header's second word (positions | early sources << 10): some row has more than W2_Q entries
 constexpr int W2_EARLY_PT = 2;         // early sources (x values read from memory) per stager thread and chunk
 constexpr unsigned W2_IN_BUF = 0x80000000u;   // a source word: LDS byte address, relative to the chunk's buffer when this bit is set
+constexpr int W2_TAIL = 32;            // long rows: the entries beyond the record come W2_TAIL at a time (tails padded to it)
 constexpr int W2_Q = 3;                // entries of a row held in its record; a longer row reads the rest from the entry arrays
 constexpr int W2_DIST = 6;             // early sources: producer chunk <= consumer chunk - W2_DIST
 constexpr int W2_PJ = (W2_CH + W2_ST - 1) / W2_ST, W2_EJ = (W2_ECAP + W2_ST - 1) / W2_ST;
@@ -728,21 +730,19 @@ __device__ __forceinline__ void w2_walk_chunk(char *lds_bytes, int base, int cs,
             for (int e = e0 + W2_Q; e < e0 + ne; e++)
               sacc -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
           } else {
-            constexpr int PK_U = 16;
-            for (int e = e0 + W2_Q; e < e0 + ne; e += PK_U) {
-              double v4[PK_U], x4[PK_U];
-              int a4[PK_U];
+            for (int e = e0 + W2_Q; e < e0 + ne; e += W2_TAIL) {   // (ne: the padded count -- no clamp, no mask)
+              // straight-line: all W2_TAIL sources and values requested at once (they do not depend on x), then the x
+              // values, then the FMAs in stored order
+              double v4[W2_TAIL], x4[W2_TAIL];
+              int a4[W2_TAIL];
 #pragma unroll
-              for (int u = 0; u < PK_U; u++) {
-                const int eu = min(e + u, e0 + ne - 1);
-                a4[u] = s_src[eu];
-                v4[u] = s_val[eu];
-              }
+              for (int u = 0; u < W2_TAIL; u++) a4[u] = s_src[e + u];
 #pragma unroll
-              for (int u = 0; u < PK_U; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+              for (int u = 0; u < W2_TAIL; u++) v4[u] = s_val[e + u];
 #pragma unroll
-              for (int u = 0; u < PK_U; u++)
-                if (e + u < e0 + ne) sacc -= v4[u] * x4[u];
+              for (int u = 0; u < W2_TAIL; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
+#pragma unroll
+              for (int u = 0; u < W2_TAIL; u++) sacc -= v4[u] * x4[u];
             }
           }
         }
@@ -1167,7 +1167,8 @@ struct TriFactor {
       st.long_rows = ents > 6 * (int64_t)(st.hi - st.lo);      // more than 6 entries a row on average
       any_long = any_long || st.long_rows;
     }
-    walk2 = forced_mode() == 4 || (forced_mode() == 0 && !any_long);
+    (void)any_long;
+    walk2 = forced_mode() == 4 || forced_mode() == 0;
     int rc = walk2 ? build_walk2(h_rp, h_ci, h_val, level, lp, ord) : build_packed(h_rp, h_ci, h_val, level, lp, ord);
     if (rc) return rc;
     PC_TRY(rp.upload(h_rp));
@@ -1334,11 +1335,24 @@ struct TriFactor {
         early_in_row[i] += is_early[e];
       }
     }
+    // Slots of the entry arrays.  In a step of long rows a row's tail (what its record does not hold) is padded to a
+    // multiple of W2_TAIL entries of value +0.0 reading the constant 0.0: the walker then takes a tail W2_TAIL entries at
+    // a time without clamping an index or masking a product (fma(-0, 0, s) = s).
+    std::vector<unsigned char> long_step((size_t)n, 0);
+    for (const Step &st : steps)
+      if (!st.wide && st.long_rows)
+        for (int i = st.lo; i < st.hi; i++) long_step[i] = 1;
+    std::vector<int> qptr((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+      const int ne = peptr[i + 1] - peptr[i];
+      const int slots = (long_step[i] && ne > W2_Q) ? W2_Q + (ne - W2_Q + W2_TAIL - 1) / W2_TAIL * W2_TAIL : ne;
+      qptr[i + 1] = qptr[i] + slots;
+    }
     constexpr int OFF_X_IN_BUF = 56 * W2_RECS + 8 * W2_ECAP;   // (k_trsv_walk2's OFF_X)
     std::vector<int4> hdr;
     std::vector<W2Early> early_list;
     std::vector<W2Pos> apos((size_t)n + 1);
-    std::vector<W2Ent> aent(ppos.size() + 1);
+    std::vector<W2Ent> aent((size_t)qptr[n] + 1);
     for (int i = 0; i <= n; i++) {
       apos[i] = W2Pos{0.0, 0.0, 0.0, pdiag[i], (unsigned)W2_ZERO, (unsigned)W2_ZERO, (unsigned)W2_ZERO, 0u};
     }
@@ -1354,13 +1368,13 @@ struct TriFactor {
         // the next sub-level: rows of i's level, at most 64, at most W2_ECAP entries
         const int level_end = lp[level[ord[i]] + 1];
         int e = i, early = 0;
-        while (e < level_end && e - i < 64 && peptr[e + 1] - peptr[i] <= W2_ECAP &&
+        while (e < level_end && e - i < 64 && qptr[e + 1] - qptr[i] <= W2_ECAP &&
                early + early_in_row[e] <= W2_EARLY_PT * W2_ST) {
           early += early_in_row[e];
           e++;
         }
         if (e == i) { ok = false; break; }                    // one row with more than W2_ECAP entries (or early sources)
-        const bool fits = cur.n_sub < W2_SUB && e - cur.cs <= W2_CH && peptr[e] - peptr[cur.cs] <= W2_ECAP &&
+        const bool fits = cur.n_sub < W2_SUB && e - cur.cs <= W2_CH && qptr[e] - qptr[cur.cs] <= W2_ECAP &&
                           cur.n_early + early <= W2_EARLY_PT * W2_ST;
         if (!fits) {
           chunks.push_back(cur);
@@ -1379,10 +1393,10 @@ struct TriFactor {
       for (size_t k = 0; k < chunks.size() && ok; k++) {
         const Chunk &ch = chunks[k];
         for (int i = ch.cs; i < ch.ce && ok; i++) {
-          const int ne = peptr[i + 1] - peptr[i], e0 = peptr[i] - peptr[ch.cs];
+          const int ne = peptr[i + 1] - peptr[i], e0 = qptr[i] - qptr[ch.cs], ne_slots = qptr[i + 1] - qptr[i];
           unsigned word[W2_Q] = {(unsigned)W2_ZERO, (unsigned)W2_ZERO, (unsigned)W2_ZERO};
           for (int e = peptr[i]; e < peptr[i + 1]; e++) {
-            const int pp = ppos[e], slot = e - peptr[ch.cs];
+            const int pp = ppos[e], slot = e0 + (e - peptr[i]);
             unsigned src;
             if (!is_early[e]) src = (unsigned)(pp & (PK_RING - 1)) * 8u;
             else {
@@ -1390,12 +1404,12 @@ struct TriFactor {
               src = W2_IN_BUF | (unsigned)(OFF_X_IN_BUF + 8 * slot);
               early_list.push_back(W2Early{pp, slot});
             }
-            aent[e] = W2Ent{pval[e], src, 0u};
+            aent[(size_t)qptr[ch.cs] + slot] = W2Ent{pval[e], src, 0u};
             if (e - peptr[i] < W2_Q) word[e - peptr[i]] = src;
           }
           W2Pos &q = apos[i];
           q.s0 = word[0]; q.s1 = word[1]; q.s2 = word[2];
-          q.meta = (unsigned)ne | ((unsigned)e0 << 11);
+          q.meta = (unsigned)ne_slots | ((unsigned)e0 << 11);   // (slots: the padded count in a step of long rows)
           if (ne > 0) q.v0 = pval[peptr[i]];
           if (ne > 1) q.v1 = pval[peptr[i] + 1];
           if (ne > 2) q.v2 = pval[peptr[i] + 2];
@@ -1415,8 +1429,8 @@ struct TriFactor {
             if (peptr[i + 1] - peptr[i] > W2_Q) ovf |= 1 << q;   // a row with more entries than its record holds
           at += ch.width[q];
         }
-        hdr.push_back(make_int4(ch.cs, (ch.ce - ch.cs) | (ch.n_early << 10) | (ovf ? W2_HAS_OVF : 0), peptr[ch.cs],
-                                peptr[ch.ce] - peptr[ch.cs]));
+        hdr.push_back(make_int4(ch.cs, (ch.ce - ch.cs) | (ch.n_early << 10) | (ovf ? W2_HAS_OVF : 0), qptr[ch.cs],
+                                qptr[ch.ce] - qptr[ch.cs]));
         hdr.push_back(make_int4((int)early_at, w[0], w[1], w[2]));
         hdr.push_back(make_int4(w[3], w[4], w[5], ovf));
         early_at += ch.n_early;
@@ -1471,9 +1485,7 @@ struct TriFactor {
   // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
   // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
   // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk, r1), 3 = walk1 (one walker wave, r3), 4 = walk2 (walker +
-  // stagers + read-ahead, position space), 5 = packed (the four-wave walk, r2).  Unset (0): walk2, except for a factor
-  // whose narrow levels have long rows (an FEM factor: the four-wave walk reads a row's tail 16 entries at a time and is
-  // the faster one there -- cant-like 31.7 against 32-40 ms).
+  // stagers + read-ahead, position space), 5 = packed (the four-wave walk, r2).  Unset (0): walk2.
   static int forced_mode() {
     static const int mode = [] {
       const char *force = std::getenv("CASK_HIP_TRSV");

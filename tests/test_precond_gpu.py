@@ -236,8 +236,7 @@ def test_packed_walk_random_dependency_graphs(seed):
 
 def test_triangular_solve_schedules_agree_bit_for_bit():
     """Five schedules of the same triangular solve (cask_hip_precond.hip): walker + stagers in position space (walk2, the
-    default for short-row factors), the one-walker-wave kernel (walk1), the four-wave packed walk of narrow-level runs (packed: the
-    default for long-row factors), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
+    default), the one-walker-wave kernel (walk1), the four-wave packed walk of narrow-level runs (packed, r2), the row-indexed walk of round 1 (CASK_HIP_TRSV=levels) and the one-launch synchronisation-free solve
     (CASK_HIP_TRSV=syncfree).  All walk every row in stored order: identical bits -- on a grid factor with thousands
     of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
     per level run, entry-capped chunks), an arrow matrix whose last row is longer than a chunk can hold (that
