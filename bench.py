@@ -47,6 +47,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
+EXIT_OTHERS_FAILED = 3            # the headline line was printed, an appended workload failed or hung (never a restart in-process)
 HALO_FRACTION_FOR_ALLGATHER = 0.10   # a block that references more than this share of x gets the all-gather:
 #   per-element remote loads pay a fabric packet per 8 useful bytes, the all-gather moves whole slices (webbase-like
 #   blocks reference 16 % of x scattered over every peer; stencil / banded blocks 0.1-2 % from their neighbours)
@@ -59,9 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "atmosmodd"])
     ap.add_argument("--solver", default=None, choices=["cg", "bicg"], help="time solver passes instead of products")
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager", "windowgraph"],
                     help="graph: the K steps as one HIP graph; sequence: K launches from one C call (no graph start-up "
                          "inside a short timed region); eager: per-step calls; auto: sequence below 200 steps, else graph")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of K steps each, back to back behind one pre-roll; ms_per_step is the MEDIAN window "
+                         "/ K (0 = auto: at least 31, more while K*windows < 2000 steps, at most 101)")
     ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -75,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true",
                     help="headline workload only (the default cant run otherwise appends the other BASELINE configs "
                          "under config.other_workloads)")
+    ap.add_argument("--strict-exit", action="store_true",
+                    help="exit with status 3 (after printing the headline line) when an appended workload failed or hung")
     ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each appended workload")
     ap.add_argument("--other-seconds", type=float, default=150.0,
                     help="watchdog for the appended workloads as a whole: past it the headline line is printed without them")
@@ -134,7 +140,7 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
                                                                    p(lci), p(x), p(ys)))
             # the host is shared and a 62 K-row product does not feed 128 threads: time a few team sizes for
             # a slice of the budget each and report the best one (threads pinned: OMP_PROC_BIND/OMP_PLACES below)
-            counts = sorted({t for t in (8, 16, 32, 64) if 0 < t <= max_threads} | {min(max_threads, 16)})
+            counts = sorted({t for t in (8, 16, 32, 64, 128, 256) if 0 < t <= max_threads} | {min(max_threads, 16)})
             by_routine, best = {}, None
             for name, (fn, args) in routines.items():
                 by_threads = by_routine.setdefault(name, {})
@@ -253,7 +259,7 @@ def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
         routines = {"mkl_cspblas_dcsrgemv": None}
         if kind == "cg":
             routines["mkl_dcsrsymv('l')"] = lower_triangle_1based(rp, ci, va)
-        counts = sorted({t for t in (8, 16, 32, 64) if t <= max_threads} | {min(16, max_threads)})
+        counts = sorted({t for t in (8, 16, 32, 64, 128, 256) if t <= max_threads} | {min(16, max_threads)})
         by_routine, best = {}, None
         for name, sym in routines.items():
             by_threads = by_routine.setdefault(name, {})
@@ -412,8 +418,9 @@ def main():
                 return
             if rank == 0:
                 others.append({"error": f"watchdog: appended workloads exceeded {args.other_seconds:.0f} s"})
+                rec["appended_workloads_failed"] = True
                 print(json.dumps(rec), flush=True)
-            os._exit(0)
+            os._exit(others_exit_status(args))               # the headline went out
         dog = threading.Timer(args.other_seconds, give_up)
         dog.daemon = True
         dog.start()
@@ -436,15 +443,31 @@ def main():
                     # Its line (rank 0) goes out now; the peers' watchdogs end them with the headline intact.
                     state["done"] = True
                     if rank == 0:
+                        rec["appended_workloads_failed"] = True
                         print(json.dumps(rec), flush=True)
-                    os._exit(0)
+                    os._exit(others_exit_status(args))
         state["done"] = True
         dog.cancel()
+        failed = any("error" in o for o in others)
+    else:
+        failed = False
     if rank == 0:
+        if failed:
+            rec["appended_workloads_failed"] = True
         print(json.dumps(rec), flush=True)
     if use_dist:
         host_barrier()
         dist.destroy_process_group()
+    if failed and others_exit_status(args):
+        sys.exit(others_exit_status(args))
+
+
+def others_exit_status(args):
+    """Exit status once the headline line is out and an appended workload failed or hung.  The line then carries
+    `appended_workloads_failed: true` and the error entries; with --strict-exit (or CASK_BENCH_STRICT_EXIT=1) the process
+    also ends with status 3 so that a harness which only looks at exit codes sees it.  Not the default: the driver's
+    contract is ONE JSON line from a run it can use, and the headline measurement in that line is complete and valid."""
+    return EXIT_OTHERS_FAILED if (args.strict_exit or os.environ.get("CASK_BENCH_STRICT_EXIT")) else 0
 
 
 def other_workload_specs(world):
@@ -467,7 +490,10 @@ def summarise_other(spec, sub, seconds):
            "frac": roof["frac"], "hbm_gbs_algorithmic_per_gpu": roof["achieved"],
            "algorithmic_bytes_per_step_per_gpu": roof["algorithmic_bytes_per_launch"],
            "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "exchange": c.get("exchange"), "design_point": c.get("design_point"),
-           "seconds_in_bench": round(seconds, 1)}
+           "windows": sub.get("windows"), "usec_p10": round(sub.get("ms_per_step_p10", 0) * 1e3, 3),
+           "usec_p90": round(sub.get("ms_per_step_p90", 0) * 1e3, 3), "seconds_in_bench": round(seconds, 1)}
+    if roof.get("working_set_note"):
+        out["working_set_note"] = roof["working_set_note"]
     if "solve_check" in c:
         out["solve_check"] = c["solve_check"]
         out["collectives"] = c.get("collectives")
@@ -478,32 +504,150 @@ def summarise_other(spec, sub, seconds):
     return out
 
 
-def timed_region(cx, run_steps, lead_in=None):
-    """The K timed steps between the two barrier + synchronize brackets; returns (device ms: max over ranks,
-    host wall seconds: max over ranks).  ``lead_in`` (an untimed replay of the same graph) is queued in front of the
-    first event: the timed replay is then already submitted when the event fires, and the K steps are timed from a
-    busy stream instead of from the runtime's idle-stream start-up."""
+def n_windows(args):
+    """Windows of K timed steps (the same on every rank: a function of the arguments alone)."""
+    if args.windows > 0:
+        return args.windows
+    r = 31
+    while r * max(args.steps, 1) < 2000 and r < 101:
+        r += 10
+    return r
+
+
+def gpu_clocks(dev_index=0):
+    """Current shader / memory clock of the device in MHz from sysfs (pp_dpm_sclk / pp_dpm_mclk: the starred level), so
+    that a slow box explains itself in the line.  None where the files cannot be read."""
+    out = {}
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        bus = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+        roots = [Path("/sys/bus/pci/devices") / bus]
+    except Exception:  # noqa: BLE001 - reporting only
+        roots = []
+    if not roots or not (roots[0] / "pp_dpm_sclk").exists():
+        roots = sorted(Path("/sys/class/drm").glob("card[0-9]*/device"))
+    for root in roots:
+        got = {}
+        for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+            try:
+                for line in (root / name).read_text().splitlines():
+                    if "*" in line:
+                        got[key] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except Exception:  # noqa: BLE001
+                pass
+        if got:
+            out = got
+            break
+    return out or None
+
+
+def timed_windows(cx, run_steps, lead_in=None, windows=31, native=None):
+    """R windows of exactly K timed steps each, back to back on the launch stream between the two barrier + synchronize
+    brackets: R + 1 HIP events, window r = event r -> event r + 1.  ``lead_in`` (an untimed run of the same K steps) is
+    queued in front of the first event so that the timed work is already submitted when that event fires.  Returns a
+    dict: per-window device ms of THIS rank, their median / min / p10 / p90 / max, the MAX over ranks of the median
+    (`dev_ms`: the figure ms_per_step is derived from -- ONE 20-step window is a 0.2 ms sample and moves by 10 % from box
+    to box and run to run; the median of >= 31 of them does not), the whole region's device time and host wall time."""
     import torch
     import torch.distributed as dist
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(windows + 1)]
     cx.host_barrier()
     torch.cuda.synchronize()
-    t_lead = 0.0
     if lead_in is not None:
-        tl = time.perf_counter()
         lead_in()
-        t_lead = time.perf_counter() - tl                   # host time to submit it (the device runs it meanwhile)
     t0 = time.perf_counter()
-    e0.record()
-    run_steps()
-    e1.record()
-    cx.host_barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
+    if native is not None:
+        # the engine's own windows: K launches + one timing event per window from ONE C call, events without the
+        # system-scope fence a torch event carries (cask_hip_spmv_windows_device); returns when the last has completed
+        ms = [u * 1e-3 for u in native(windows)]
+        t_submit = time.perf_counter() - t0
+        clocks_busy = gpu_clocks(cx.dev.index or 0)
+        cx.host_barrier()
+        wall = time.perf_counter() - t0
+        total = float(sum(ms))
+    else:
+        ev[0].record()
+        for r in range(windows):
+            run_steps()
+            ev[r + 1].record()
+        t_submit = time.perf_counter() - t0
+        clocks_busy = gpu_clocks(cx.dev.index or 0)        # read while the windows run (the host is ahead of the stream)
+        cx.host_barrier()
+        wall = time.perf_counter() - t0
+        ms = [ev[r].elapsed_time(ev[r + 1]) for r in range(windows)]
+        total = ev[0].elapsed_time(ev[windows])
+    srt = sorted(ms)
+    q = lambda f: srt[min(windows - 1, max(0, int(round(f * (windows - 1)))))]   # noqa: E731
+    med = float(np.median(ms))
+    out = {"windows": windows, "ms": ms, "median": med, "min": srt[0], "p10": q(0.10), "p90": q(0.90), "max": srt[-1],
+           "mean": total / windows, "first": ms[0], "host_submit_s": t_submit, "clocks_during": clocks_busy}
     if cx.use_dist:
-        dev_ms = cx.all_reduce_scalar(dev_ms, dist.ReduceOp.MAX)
-        wall = cx.all_reduce_scalar(wall, dist.ReduceOp.MAX)
-    return dev_ms, wall
+        out["dev_ms"] = cx.all_reduce_scalar(med, dist.ReduceOp.MAX)
+        out["mean_max"] = cx.all_reduce_scalar(out["mean"], dist.ReduceOp.MAX)
+        out["wall"] = cx.all_reduce_scalar(wall, dist.ReduceOp.MAX)
+    else:
+        out["dev_ms"], out["mean_max"], out["wall"] = med, out["mean"], wall
+    return out
+
+
+def timed_window_graph(cx, step, steps, windows):
+    """All R windows as ONE HIP graph: R x K kernel nodes with an event-record node at every window boundary (external
+    events), replayed once untimed and once timed between the brackets.  Graph nodes are the cheapest launches the
+    runtime has (no per-launch host work, no graph start inside a window)."""
+    import torch
+    import torch.distributed as dist
+    ev = [torch.cuda.Event(enable_timing=True, external=True) for _ in range(windows + 1)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(3):
+            step(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ev[0].record()
+        for r in range(windows):
+            for i in range(steps):
+                step(r * steps + i)
+            ev[r + 1].record()
+    g.replay()
+    torch.cuda.synchronize()
+    for _ in range(2):                                          # ~40 ms of load in front of the timed replay
+        g.replay()
+    cx.host_barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.replay()
+    g.replay()                                                  # the events keep the LAST replay's times
+    clocks_busy = gpu_clocks(cx.dev.index or 0)
+    cx.host_barrier()
+    wall = (time.perf_counter() - t0) / 2
+    ms = [ev[r].elapsed_time(ev[r + 1]) for r in range(windows)]
+    total = ev[0].elapsed_time(ev[windows])
+    srt = sorted(ms)
+    q = lambda f: srt[min(windows - 1, max(0, int(round(f * (windows - 1)))))]   # noqa: E731
+    med = float(np.median(ms))
+    out = {"windows": windows, "ms": ms, "median": med, "min": srt[0], "p10": q(0.10), "p90": q(0.90), "max": srt[-1],
+           "mean": total / windows, "first": ms[0], "host_submit_s": 0.0, "clocks_during": clocks_busy}
+    if cx.use_dist:
+        out["dev_ms"] = cx.all_reduce_scalar(med, dist.ReduceOp.MAX)
+        out["mean_max"] = cx.all_reduce_scalar(out["mean"], dist.ReduceOp.MAX)
+        out["wall"] = cx.all_reduce_scalar(wall, dist.ReduceOp.MAX) * windows
+    else:
+        out["dev_ms"], out["mean_max"], out["wall"] = med, out["mean"], wall * windows
+    return out
+
+
+def window_fields(tw, steps):
+    """The spread of the timed windows for the JSON line (ms per step, like ms_per_step)."""
+    k = max(steps, 1)
+    r6 = lambda v: round(v / k, 6)                          # noqa: E731
+    return {"windows": tw["windows"], "ms_per_step_min": r6(tw["min"]), "ms_per_step_p10": r6(tw["p10"]),
+            "ms_per_step_p90": r6(tw["p90"]), "ms_per_step_max": r6(tw["max"]), "ms_per_step_mean": r6(tw["mean_max"]),
+            "ms_per_step_first_window": r6(tw["first"]),
+            "window_spread_pct": round(100.0 * (tw["p90"] - tw["p10"]) / max(tw["median"], 1e-12), 2)}
 
 
 def traffic_record(workload, design=None):
@@ -748,6 +892,8 @@ def run_spmv(cx, weak):
     torch.cuda.synchronize()
 
     launch_mode = args.launch if exchange not in ("all_gather", "push") else "eager"
+    if args.launch == "windowgraph" and exchange in ("all_gather", "push"):
+        launch_mode = "eager"
     if exchange == "push" and args.launch in ("auto", "graph") and args.steps % 2 == 0:
         # the push exchange is plain kernel launches: capturable.  Its two gathered vectors alternate per exchange and
         # the product's operand pointer is frozen into the graph, so a replay must return to the parity it started
@@ -820,11 +966,23 @@ def run_spmv(cx, weak):
         preroll = int(min(2000, max(2, 40.0 / max(e0.elapsed_time(e1), 1e-3))))
         for _ in range(preroll):
             run_steps()
-    dev_ms, wall = timed_region(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None))
-    clock = "HIP events around the K timed steps on the launch stream" + (
-        "; an untimed replay is queued in front of the first event so that the timed replay starts on a busy stream "
-        "(starting a graph on an idle stream costs ~15 us: 8 % of a 20-step region)" if graph is not None else
-        "; an untimed sequence of K launches is queued in front of the first event" if sequence else "")
+    clocks_before = gpu_clocks(dev.index or 0)                  # the pre-roll is still running: clocks under load
+    if launch_mode == "windowgraph":
+        tw = timed_window_graph(cx, step, args.steps, n_windows(args))
+    else:
+        native_windows = None
+        if sequence and not os.environ.get("CASK_BENCH_TORCH_EVENTS"):
+            native_windows = lambda r: capi.spmv_windows_device(mats, x_in, y, args.steps, r)   # noqa: E731
+        tw = timed_windows(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None),
+                           windows=n_windows(args), native=native_windows)
+    clocks_after = gpu_clocks(dev.index or 0)
+    dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
+    clock = (f"MEDIAN of {tw['windows']} back-to-back windows of K = {args.steps} steps, each between two HIP events on the "
+             "launch stream (max over ranks of the per-rank median)") + (
+        "; an untimed replay is queued in front of the first event so that the first window starts on a busy stream"
+        if graph is not None else
+        "; K launches + one timing event (no system-scope fence) per window from one C call, an untimed sequence of K "
+        "launches queued in front of the first event" if sequence else "")
     y_gpu = y.cpu().numpy()
     # post-run check: every rank's whole block against the CPU oracle (the global x is a formula, nothing to gather)
     import oracle
@@ -870,6 +1028,9 @@ def run_spmv(cx, weak):
             "ms_per_step": round(step_us * 1e-3, 6), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if source == "synthetic" else source,
             "host_wall_ms_per_step": round(wall * 1e3 / args.steps, 6), "clock": clock,
+            **window_fields(tw, args.steps),
+            "gpu_clocks_mhz": {"before_under_preroll": clocks_before, "during_windows": tw["clocks_during"],
+                               "after": clocks_after},
             "config": {"workload": f"{like} CSR SpMV, {n_local} rows x {n_global} cols on rank 0, "
                                    f"{nnz_local} nnz on rank 0, x_i = 0.25 i / n",
                        "rows": n_global, "nnz": int(nnz_total),
@@ -1008,7 +1169,8 @@ def run_solver(cx):
     # ---- warm-up + timed region: exactly K passes (tol = 0 never converges) -----------
     if args.warmup:
         solve(args.warmup, 0.0)
-    dev_ms, wall = timed_region(cx, lambda: solve(args.steps, 0.0))
+    tw = timed_windows(cx, lambda: solve(args.steps, 0.0), windows=n_windows(args))
+    dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
     rec = None
     if rank == 0:
         step_us = dev_ms * 1e3 / args.steps
@@ -1023,6 +1185,8 @@ def run_solver(cx):
             "warmup": args.warmup, "ms_per_step": round(step_us * 1e-3, 6), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if source == "synthetic" else source,
             "host_wall_ms_per_step": round(wall * 1e3 / args.steps, 6),
+            "clock": f"MEDIAN of {tw['windows']} back-to-back solves of exactly K = {args.steps} passes, each between two HIP events",
+            **window_fields(tw, args.steps),
             "config": {"workload": f"{kind} on the {name}-like system, {n} rows, {nnz} nnz, b = A x0, one step = one pass",
                        "rows": n, "nnz": nnz, "parallelism": f"row-blocks x{world} (nnz-balanced)",
                        "exchange": {"none": "none", "p2p_fused": "halos read inside the product kernels over xGMI; dot products: "

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "cask_hip_daxpy_device", "cask_hip_daxpby_device", "cask_hip_cg", "cask_hip_bicg",
     "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
     "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
-    "cask_hip_solve_device", "cask_hip_spmv_sequence_device",
+    "cask_hip_solve_device", "cask_hip_spmv_sequence_device", "cask_hip_spmv_windows_device",
 )
 SOLVER_CG, SOLVER_BICG = 1, 2
 SOLVER_AUTO, SOLVER_COMPOSED, SOLVER_CLASSIC = 0, 1, 2
@@ -133,6 +133,8 @@ def load() -> ctypes.CDLL:
         L.cask_hip_pcg.argtypes = [vp, vp, vp, vp, i32, dbl, POINTER(i32), POINTER(i32), POINTER(dbl)]
     if hasattr(L, "cask_hip_spmv_sequence_device"):
         L.cask_hip_spmv_sequence_device.argtypes = [vp, i32, vp, vp, i32, vp]
+    if hasattr(L, "cask_hip_spmv_windows_device"):
+        L.cask_hip_spmv_windows_device.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
     if hasattr(L, "cask_hip_solve_device"):
         L.cask_hip_solve_device.argtypes = [vp, vp, POINTER(SolverConfig), vp, vp, i32, dbl, POINTER(i32), POINTER(i32),
                                             POINTER(dbl), vp]
@@ -505,6 +507,16 @@ def spmv_sequence_device(mats, x_t, y_t, k, stream=None):
     arr = (c_void_p * len(mats))(*[m._h for m in mats])
     _check(load().cask_hip_spmv_sequence_device(arr, len(mats), c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
                                                 int(k), c_void_p(_stream_ptr(stream))))
+
+
+def spmv_windows_device(mats, x_t, y_t, k, windows, stream=None):
+    """`windows` timed windows of k products each from one call (cask_hip_spmv_windows_device); returns after the last
+    one has completed with the device microseconds of every window."""
+    arr = (c_void_p * len(mats))(*[m._h for m in mats])
+    usec = np.zeros(int(windows), dtype=np.float64)
+    _check(load().cask_hip_spmv_windows_device(arr, len(mats), c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
+                                               int(k), int(windows), _p(usec), c_void_p(_stream_ptr(stream))))
+    return usec
 
 
 def _stream_ptr(stream):

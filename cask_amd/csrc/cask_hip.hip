@@ -1473,6 +1473,45 @@ int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, 
   return CASK_HIP_OK;
 }
 
+int cask_hip_spmv_windows_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
+                                 int32_t k, int32_t windows, double *usec, void *stream) {
+  if (!mats || n_mats <= 0 || k <= 0 || windows <= 0 || !usec) return fail(CASK_HIP_ERR_INVALID, "bad argument");
+  for (int i = 0; i < n_mats; i++) {
+    if (!mats[i]) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
+    if (mats[i]->n_rows != mats[0]->n_rows || mats[i]->n_cols != mats[0]->n_cols)
+      return fail(CASK_HIP_ERR_INVALID, "the handles of a sequence must have one shape");
+  }
+  if ((mats[0]->n_cols > 0 && !d_x) || (mats[0]->n_rows > 0 && !d_y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
+  if (reinterpret_cast<uintptr_t>(d_x) & 15) return fail(CASK_HIP_ERR_INVALID, "x must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  struct Events {
+    std::vector<hipEvent_t> e;
+    ~Events() { for (hipEvent_t ev : e) (void)hipEventDestroy(ev); }
+  } evs;
+  evs.e.reserve((size_t)windows + 1);
+  for (int r = 0; r <= windows; r++) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
+    evs.e.push_back(ev);
+  }
+  HIP_TRY(hipEventRecord(evs.e[0], s));
+  int64_t i = 0;
+  for (int r = 0; r < windows; r++) {
+    for (int j = 0; j < k; j++, i++) {
+      int rc = launch_spmv(*mats[i % n_mats], d_x, d_y, s);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(evs.e[(size_t)r + 1], s));
+  }
+  HIP_TRY(hipEventSynchronize(evs.e[(size_t)windows]));
+  for (int r = 0; r < windows; r++) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, evs.e[(size_t)r], evs.e[(size_t)r + 1]));
+    usec[r] = 1e3 * (double)ms;
+  }
+  return CASK_HIP_OK;
+}
+
 int cask_hip_spmv_dot_device(cask_hip_matrix *m, const double *d_x, double *d_y, const double *d_w, double *d_result,
                              void *stream) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
@@ -1714,17 +1753,20 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
   int count = 0, best = -1;
   double best_us = 0.0;
   cask_hip_params best_params{};
-  // Pruning: a family whose two first measured points are both more than 1.5x behind the incumbent is not measured
-  // further (its remaining points are reported with valid = 0, usec = -1).  Round 2: the row-mapped VECTOR family was
-  // 24 of the 40 points and 77-91 % of the sweep's launch time, and wins on no matrix.  CASK_HIP_TUNE_NO_PRUNE=1
-  // measures everything.
+  // Pruning (r4).  The RESULTS keep the reference's odometer order (first range fastest, Utils.hpp:173-192; unlike
+  // Dse.cpp:40-47 the last point is evaluated too) -- the MEASUREMENTS do not follow it.  Every family's points are
+  // ranked by a prior (VECTOR: the lane count nearest the mean row length; the merge families: AUTO's shape), the
+  // two best guesses of every family are measured first, and only then may a family be dropped: when even those two
+  // are more than 1.5x behind the incumbent AND its times are not still improving (its latest point was not its best
+  // by > 10 %).  Round 3 pruned in odometer order, i.e. after L = 4 and L = 8 for the row-mapped VECTOR family --
+  // its worst points on 64-nonzero rows -- and never saw L = 32.  Pruned points are reported with valid = 0,
+  // usec = -1; CASK_HIP_TUNE_NO_PRUNE=1 measures everything.
   const bool prune = std::getenv("CASK_HIP_TUNE_NO_PRUNE") == nullptr;
-  int fam_points[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  double fam_best[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool fam_pruned[8] = {false, false, false, false, false, false, false, false};
-  // Odometer over the ranges, first range fastest (Utils.hpp:173-192); unlike
-  // Dse.cpp:40-47 the last point is evaluated too.  lanes only matter for
-  // VECTOR and items only for MERGE: irrelevant repeats are skipped.
+  struct Cand { cask_hip_tune_point pt; int family; double prior; int rank; bool done; };
+  std::vector<Cand> cands;
+  const double mean_row = m->n_rows ? std::max(1.0, (double)m->nnz / m->n_rows) : 1.0;
+  auto l2 = [](double v) { return std::log2(std::max(v, 1.0)); };
+  // lanes only matter for VECTOR and items only for the merge families: irrelevant repeats are skipped.
   for (int iv = 0; iv < n_items; iv++)
     for (int iw = 0; iw < n_wg_sizes; iw++)
       for (int it = 0; it < n_tiles; it++)
@@ -1741,49 +1783,85 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
             if (is_merge && il != 0) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel
-            cask_hip_tune_point pt{};
-            pt.params = saved;
-            pt.params.variant = variant;
-            if (variant != CASK_HIP_VARIANT_MERGE_PAIR && pt.params.xcd_remap == 2) pt.params.xcd_remap = 1;
-            pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
-            pt.params.items_per_thread = is_merge ? items[iv] : 0;
-            pt.params.tile_width = tiles[it];
-            pt.params.wg_size = wg_sizes[iw];
-            if (prune && fam_pruned[variant & 7]) {
-              pt.valid = 0;
-              pt.usec = -1.0;                                 // pruned, not measured
-              if (results && count < max_results) results[count] = pt;
-              count++;
-              continue;
-            }
-            int rc = build_plan(*m, pt.params);
-            for (size_t c = 1; c < rot.size() && rc == CASK_HIP_OK; c++) rc = clone_plan(*rot[c], *m);
-            if (rc == CASK_HIP_OK && m->plan.prm.variant == CASK_HIP_VARIANT_VECTOR &&
-                m->plan.prm.wg_size < m->plan.prm.lanes_per_row)
-              rc = CASK_HIP_ERR_INVALID;
-            if (rc == CASK_HIP_OK) {
-              double cold = 0, warm = 0;
-              rc = time_graph(one, x.p, y.p, k_warm, warmup, 3, &warm);
-              if (rc == CASK_HIP_OK) rc = copies > 1 ? time_graph(rot, x.p, y.p, k_cold, warmup, 3, &cold) : CASK_HIP_OK;
-              if (rc == CASK_HIP_OK) {
-                if (copies == 1) cold = warm;
-                pt.params = m->plan.prm;
-                pt.usec = cold;
-                pt.usec_warm = warm;
-                pt.copies = copies;
-                pt.gflops = cold > 0 ? 2.0 * m->nnz / cold * 1e-3 : 0.0;
-                pt.gbytes_per_s = cold > 0 ? info.algorithmic_bytes / cold * 1e-3 : 0.0;
-                pt.valid = 1;
-                if (best < 0 || cold < best_us) { best = count; best_us = cold; best_params = pt.params; }
-                const int f = variant & 7;
-                fam_points[f]++;
-                if (fam_points[f] == 1 || cold < fam_best[f]) fam_best[f] = cold;
-                if (fam_points[f] >= 2 && fam_best[f] > 1.5 * best_us) fam_pruned[f] = true;
-              }
-            }
-            if (results && count < max_results) results[count] = pt;
-            count++;
+            Cand c{};
+            c.pt.params = saved;
+            c.pt.params.variant = variant;
+            if (variant != CASK_HIP_VARIANT_MERGE_PAIR && c.pt.params.xcd_remap == 2) c.pt.params.xcd_remap = 1;
+            c.pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
+            c.pt.params.items_per_thread = is_merge ? items[iv] : 0;
+            c.pt.params.tile_width = tiles[it];
+            c.pt.params.wg_size = wg_sizes[iw];
+            c.pt.valid = 0;
+            c.pt.usec = -1.0;                                 // "pruned, not measured" until it is
+            c.family = variant & 7;
+            // the prior: distance from the family's best guess (ties: odometer order)
+            const double d_wg = std::fabs(l2(wg_sizes[iw]) - l2(256));
+            const double tile_ref = variant == CASK_HIP_VARIANT_SCAN ? 4096 : (mean_row >= 16 ? 1024 : 2048);
+            const double d_tile = tiles[it] <= 0 ? 1.5 : std::fabs(l2(tiles[it]) - l2(tile_ref)) * 0.5;
+            if (variant == CASK_HIP_VARIANT_VECTOR)
+              c.prior = 4.0 * std::fabs(l2(lanes[il]) - l2(std::min(mean_row, 64.0) / 2.0)) + d_wg + d_tile;
+            else
+              c.prior = 2.0 * std::fabs(l2(items[iv]) - l2(8)) + d_wg + d_tile;
+            cands.push_back(c);
           }
+  count = (int)cands.size();
+  // rank within the family
+  for (int f = 0; f < 8; f++) {
+    std::vector<int> idx;
+    for (int i = 0; i < count; i++)
+      if (cands[i].family == f) idx.push_back(i);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cands[a].prior < cands[b].prior; });
+    for (size_t r = 0; r < idx.size(); r++) cands[idx[r]].rank = (int)r;
+  }
+  // schedule: rank 0 of every family, rank 1 of every family, then the rest in odometer order
+  std::vector<int> order;
+  for (int r = 0; r < 2; r++)
+    for (int i = 0; i < count; i++)
+      if (cands[i].rank == r) order.push_back(i);
+  const size_t n_prior = order.size();
+  for (int i = 0; i < count; i++)
+    if (cands[i].rank >= 2) order.push_back(i);
+  int fam_points[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double fam_best[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fam_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double fam_prev_best[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (size_t oi = 0; oi < order.size(); oi++) {
+    Cand &c = cands[order[oi]];
+    const int f = c.family;
+    if (prune && oi >= n_prior && fam_points[f] >= 2 && best >= 0 && fam_best[f] > 1.5 * best_us) {
+      // ... unless the family is still on its way down: its latest point beat everything it had by > 10 %
+      const bool improving = fam_last[f] == fam_best[f] && fam_prev_best[f] > 0 && fam_last[f] < 0.9 * fam_prev_best[f];
+      if (!improving) continue;                               // stays valid = 0, usec = -1
+    }
+    cask_hip_tune_point &pt = c.pt;
+    int rc = build_plan(*m, pt.params);
+    for (size_t k = 1; k < rot.size() && rc == CASK_HIP_OK; k++) rc = clone_plan(*rot[k], *m);
+    if (rc == CASK_HIP_OK && m->plan.prm.variant == CASK_HIP_VARIANT_VECTOR &&
+        m->plan.prm.wg_size < m->plan.prm.lanes_per_row)
+      rc = CASK_HIP_ERR_INVALID;
+    pt.usec = 0.0;                                            // measured (or rejected), not pruned
+    if (rc == CASK_HIP_OK) {
+      double cold = 0, warm = 0;
+      rc = time_graph(one, x.p, y.p, k_warm, warmup, 3, &warm);
+      if (rc == CASK_HIP_OK) rc = copies > 1 ? time_graph(rot, x.p, y.p, k_cold, warmup, 3, &cold) : CASK_HIP_OK;
+      if (rc == CASK_HIP_OK) {
+        if (copies == 1) cold = warm;
+        pt.params = m->plan.prm;
+        pt.usec = cold;
+        pt.usec_warm = warm;
+        pt.copies = copies;
+        pt.gflops = cold > 0 ? 2.0 * m->nnz / cold * 1e-3 : 0.0;
+        pt.gbytes_per_s = cold > 0 ? info.algorithmic_bytes / cold * 1e-3 : 0.0;
+        pt.valid = 1;
+        if (best < 0 || cold < best_us) { best = order[oi]; best_us = cold; best_params = pt.params; }
+        fam_points[f]++;
+        fam_prev_best[f] = fam_best[f];
+        if (fam_points[f] == 1 || cold < fam_best[f]) fam_best[f] = cold;
+        fam_last[f] = cold;
+      }
+    }
+  }
+  if (results)
+    for (int i = 0; i < count && i < max_results; i++) results[i] = cands[i].pt;
   if (n_results) *n_results = std::min(count, max_results);
   if (best_index) *best_index = (best < max_results) ? best : -1;
   if (saved_halo) {                                           // back on, before the winner's plan is built

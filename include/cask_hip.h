@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 4   /* 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
+#define CASK_HIP_ABI_VERSION 5   /* 5: cask_hip_spmv_windows_device, run-encoded slots (index16 = 3); 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
 
 /* status codes */
 #define CASK_HIP_OK               0
@@ -168,6 +168,16 @@ int cask_hip_spmv_device(cask_hip_matrix *m, const double *d_x, double *d_y, voi
  * instead of a language binding's call cost. */
 int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
                                   int32_t k, void *stream);
+
+/* `windows` timed windows of k products each, back to back on `stream`, from ONE host call: windows + 1 timing
+ * events (created with hipEventDisableSystemFence: a timing event needs no system-scope fence, and that fence
+ * costs ~4 us per record between dependent launches), event r -> event r + 1 brackets exactly the k launches of
+ * window r; product i of the whole call is y = A_(i mod n_mats) x.  Returns after the last event has completed
+ * with usec[r] = the device time of window r in microseconds.  Replaces the reference's timed loop
+ * (src/runtime/Spmv.cpp:265-301: impl.Spmv x nIterations between two clock reads, divided by nIterations) with a
+ * distribution instead of one sample. */
+int cask_hip_spmv_windows_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
+                                 int32_t k, int32_t windows, double *usec, void *stream);
 
 /* y = A x and *d_result = w . y in one pass (device vectors, asynchronous on `stream`): with a
  * MERGE design point every workgroup leaves its rows' share of the dot behind and a one-workgroup

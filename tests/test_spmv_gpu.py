@@ -254,16 +254,58 @@ def test_tune_sweeps_in_reference_order_and_keeps_the_best(monkeypatch):
 
 
 def test_tune_prunes_a_family_that_is_far_behind():
-    """a family whose first two measured points are both > 1.5x behind the incumbent is not measured
-    further; its remaining points come back as valid = 0 / usec = -1, the order of the list is unchanged."""
+    """a family is dropped only after the two points its PRIOR ranks best are both > 1.5x
+    behind the incumbent (VECTOR: the lane counts nearest half the mean row length -- here 8 and 4 of [1, 2, 4, 8] on
+    64-nonzero rows -- not the first two in odometer order, which are its worst); its remaining points come back as
+    valid = 0 / usec = -1 and the order of the list is the odometer's."""
     n, rp, ci, va = synth.small("cant", factor=4)
     m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
     pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[1, 2, 4, 8], tiles=[-1], wg_sizes=[256], items=[8])
     assert len(pts) == 4 + 1
     vec = [p for p in pts if p["params"]["variant"] == "vector"]
-    assert [p["valid"] for p in vec[:2]] == [True, True]        # thread / two lanes per 64-nonzero row: far behind merge
-    assert not any(p["valid"] for p in vec[2:]) and all(p["usec"] == -1.0 for p in vec[2:])
+    assert [p["params"]["lanes_per_row"] for p in vec] == [1, 2, 4, 8]            # reported in the odometer's order
+    assert [p["valid"] for p in vec[2:]] == [True, True]        # 4 and 8 lanes per 64-nonzero row: measured first
+    assert not any(p["valid"] for p in vec[:2]) and all(p["usec"] == -1.0 for p in vec[:2])   # a thread / two lanes: never
     assert pts[best]["params"]["variant"] == "merge"
+    m.close()
+
+
+def test_tune_measures_the_lane_count_nearest_the_row_length_first():
+    """BASELINE configs[1] is "DSE over rows-per-wavefront" -- on 64-nonzero rows the sweep must reach
+    L = 32 (2 rows per wavefront), the row-mapped family's best, before it may drop the family."""
+    n, rp, ci, va = synth.small("cant", factor=4)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[4, 8, 16, 32], tiles=[-1, 1024],
+                       wg_sizes=[256], items=[8])
+    vec = {(p["params"]["lanes_per_row"], p["params"]["tile_width"]): p for p in pts if p["params"]["variant"] == "vector"}
+    measured = [k for k, p in vec.items() if p["valid"]]
+    assert any(k[0] == 32 for k in measured), measured
+    l32 = min(p["usec"] for k, p in vec.items() if k[0] == 32 and p["valid"])
+    others = [p["usec"] for k, p in vec.items() if k[0] in (4, 8) and p["valid"]]
+    assert all(l32 < t for t in others)                        # and it is the family's best where both were measured
+    m.close()
+
+
+def test_tune_keeps_a_family_that_is_within_reach():
+    """A test_dense_128-like fixture scaled up (2048 rows of 128 consecutive nonzeros, 3 MB: timed warm): the row-mapped
+    family is within 1.5x of the merge kernels there, so none of its points may be dropped."""
+    n, k = 2048, 128
+    rp = np.arange(n + 1, dtype=np.int32) * k
+    start = np.minimum(np.arange(n), n - k)
+    ci = (start[:, None] + np.arange(k)[None, :]).astype(np.int32).ravel()
+    va = np.random.default_rng(11).standard_normal(n * k)
+    x = mmio.test_vector(n)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[4, 8, 16, 32], tiles=[-1, 1024],
+                       wg_sizes=[256], items=[8])
+    vec = [p for p in pts if p["params"]["variant"] == "vector"]
+    top = min(p["usec"] for p in pts if p["valid"])
+    vbest = min(p["usec"] for p in vec if p["valid"])
+    if vbest <= 1.5 * top:
+        assert all(p["valid"] and p["usec"] > 0 for p in vec), [(p["params"]["lanes_per_row"], p["usec"]) for p in vec]
+    else:                                                        # (not expected; keep the evidence in the failure message)
+        raise AssertionError(f"row-mapped family {vbest:.2f} us against {top:.2f}: not the fixture this test wants")
+    oracle.assert_almost_equal(m.spmv(x), oracle.csr_spmv(rp, ci, va, x), what="after tune, dense-128-like")
     m.close()
 
 
