@@ -395,6 +395,14 @@ def main():
         if use_dist:
             dist.barrier()
     cx.all_reduce_scalar, cx.host_barrier = all_reduce_scalar, host_barrier
+    t_start = time.perf_counter()
+
+    def phase(name, since):
+        """Per-phase wall budget on stderr (rank 0): a multi-GPU run that comes close to the harness's limit says where."""
+        if rank == 0 and (world > 1 or os.environ.get("CASK_BENCH_PHASES")):
+            now = time.perf_counter()
+            print(f"[bench] {name}: {now - since:.1f} s (run so far {now - t_start:.1f} s)", file=sys.stderr, flush=True)
+    cx.phase = phase
 
     def run_one(a):
         c = Ctx()
@@ -497,8 +505,10 @@ def summarise_other(spec, sub, seconds):
     if "solve_check" in c:
         out["solve_check"] = c["solve_check"]
         out["collectives"] = c.get("collectives")
+        out["exchange_selfcheck"] = c.get("exchange_selfcheck")
     else:
         out["rows_wrong"] = c.get("rows_wrong_vs_oracle_all_ranks")
+        out["exchange_selfcheck"] = c.get("exchange_selfcheck")
         out["matrix_copies_rotated"] = c.get("matrix_copies_rotated")
         out["launch"] = c.get("launch")
     return out
@@ -679,6 +689,9 @@ def run_spmv(cx, weak):
     from cask_amd import capi, synth
     from cask_amd import dist as cdist
     args, rank, world, dev, use_dist = cx.args, cx.rank, cx.world, cx.dev, cx.use_dist
+    from cask_amd import selfcheck
+    selfchecks = {}
+    phase = cx.phase
 
     # ---- workload -----------------------------------------------------------
     t_gen = time.perf_counter()
@@ -758,21 +771,28 @@ def run_spmv(cx, weak):
                 out = [None] * world
                 dist.all_gather_object(out, obj)
                 return out
+            t_sc = time.perf_counter()
             try:
                 push = p2p.PushExchange(rank, world, gather.S, dev, gather_objects)
-                push.x_slot[:n_local].copy_(torch.from_numpy(x_slice).to(dev))
-                ok = True
-                for _ in range(3):                                   # both gathered vectors, and a wrap-around
-                    xf = push.allgather()
-                    torch.cuda.synchronize()
-                    ok = ok and bool(torch.equal(gather.unpad(xf), torch.from_numpy(x_host).to(dev)))
-                push.check()
+                # first contact: 50 exchanges, the operand changes every time, every entry of the gathered vector is
+                # checked against its formula on every rank (cask_amd/selfcheck.py)
+                pos = torch.arange(gather.n_full, device=dev)
+                owner, off = pos // gather.S, pos % gather.S
+                sizes_t = torch.tensor(gather.sizes, device=dev)
+                starts_t = torch.tensor(gather.bounds[:-1], device=dev)
+                valid = off < sizes_t[owner]
+                idx_all = torch.where(valid, starts_t[owner] + off, torch.zeros_like(pos))
+                idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
+                ok, push_error = selfcheck.check_push_allgather(torch, push, n_local, idx_own, idx_all, valid, n_global)
             except Exception as e:  # noqa: BLE001 - construction is collective: raised on every rank or on none
                 ok, push_error = False, repr(e)
-            ok = cx.all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            ok, why = selfcheck.agree(ok, push_error, lambda v: cx.all_reduce_scalar(v, dist.ReduceOp.MIN), gather_objects)
+            selfchecks["push_allgather"] = "ok" if ok else f"fell back: {why}"
+            phase("exchange self-check (push all-gather)", t_sc)
             if ok:
                 exchange = "push"
             else:
+                push_error = why
                 if rank == 0:
                     print(f"[bench] push all-gather unavailable ({push_error or 'gathered vector mismatch'}); using RCCL",
                           file=sys.stderr)
@@ -813,26 +833,40 @@ def run_spmv(cx, weak):
             # Fold the exchange into the product kernel: the workgroups at a seam read the halo from the
             # peers' slices themselves (cask_hip_csr_set_halo_sources), a step is ONE launch.  Checked
             # against the pull path first; any rank that disagrees sends every rank back to the pull.
-            y_ref = torch.zeros(n_local, dtype=torch.float64, device=dev)
-            peer.pull()
-            mats[0].spmv_device(x_in, y_ref)
+            # First contact (cask_amd/selfcheck.py): 50 products whose operand changes every time.  The reference
+            # products come from a private operand built from the formula, with the plain kernel, BEFORE the halo
+            # sources are attached; then every rank rewrites its shared slice per exchange and the attached kernel
+            # must reproduce them bit for bit while the local halo copy holds NaN.
+            t_sc = time.perf_counter()
+            idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
+            idx_halo = torch.from_numpy(halo_cols).to(dev)
+            refs = []
+            for e in range(selfcheck.N_EXCHANGES):
+                xe = torch.cat([selfcheck.operand(e, idx_own, n_global), selfcheck.operand(e, idx_halo, n_global)])
+                yr = torch.empty(n_local, dtype=torch.float64, device=dev)
+                mats[0].spmv_device(xe, yr)
+                refs.append(yr)
             torch.cuda.synchronize()
             try:
                 for m in mats:
                     peer.attach(m)
-                y_try = torch.zeros(n_local, dtype=torch.float64, device=dev)
                 peer.x_ext[n_local:].fill_(float("nan"))         # the kernel must not read the local halo copy
-                mats[0].spmv_device(x_in, y_try)
-                torch.cuda.synchronize()
-                fused_ok = bool(torch.equal(y_try, y_ref))
+                fused_ok, p2p_error = selfcheck.check_fused_halo(
+                    torch, lambda yy: mats[0].spmv_device(x_in, yy), lambda e: refs[e], peer.x_local, idx_own,
+                    cx.host_barrier, n_global)
             except Exception as e:  # noqa: BLE001
                 fused_ok, p2p_error = False, repr(e)
-            fused_ok = cx.all_reduce_scalar(1.0 if fused_ok else 0.0, dist.ReduceOp.MIN) > 0.5
+            del refs
+            fused_ok, why = selfcheck.agree(fused_ok, p2p_error, lambda v: cx.all_reduce_scalar(v, dist.ReduceOp.MIN))
+            selfchecks["in_kernel_halo"] = "ok" if fused_ok else f"fell back: {why}"
+            peer.x_local.copy_(torch.from_numpy(x_slice).to(dev))    # the benchmark's operand again
+            cx.host_barrier()
+            phase("exchange self-check (in-kernel halo)", t_sc)
             if fused_ok:
                 exchange = "p2p_fused"
             else:
                 if rank == 0:
-                    print(f"[bench] in-kernel halo disagrees with the pull path ({p2p_error}); pulling", file=sys.stderr)
+                    print(f"[bench] in-kernel halo failed its first-contact check ({why}); pulling", file=sys.stderr)
                 for m in mats:
                     m.set_halo_sources(n_local, None)
                 peer.pull()
@@ -1046,6 +1080,7 @@ def run_spmv(cx, weak):
                                     "all_gather": "per step: RCCL all_gather(x), padded stride: one collective" + (
                                         " issued by the engine (cask_hip_rccl_allgather)" if native is not None else "")}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
+                       "exchange_selfcheck": selfchecks or None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
                        "matrix_copies_rotated": copies, "launch": launch_mode, "untimed_preroll_replays": preroll, "design_point": design,
                        "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info,
@@ -1109,6 +1144,7 @@ def run_solver(cx):
     forced = capi.make_params(variant=args.variant or 0, tile_width=args.tile, items_per_thread=args.items, wg_size=args.wg)
     bounds = cdist.partition_rows_by_nnz(rp, world)
     halo_frac, exchange = 0.0, "none"
+    selfchecks = {}
     sh = sht = None
     trp = tci = tva = None
     if kind == "bicg":
@@ -1129,8 +1165,13 @@ def run_solver(cx):
                     torch.cuda.synchronize()
                     dist.barrier()
             try:
+                from cask_amd import selfcheck
+                t_sc = time.perf_counter()
                 sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, params=forced, exchange="p2p", fence=fence,
-                                                   fused_halo=True, solver_slots=6 if kind == "bicg" else 3, bounds=bounds)
+                                                   fused_halo=True, solver_slots=6 if kind == "bicg" else 3, bounds=bounds,
+                                                   selfcheck=selfcheck.N_EXCHANGES)
+                selfchecks.update(getattr(sh, "selfcheck", None) or {})
+                cx.phase("sharded operator + exchange self-check (in-kernel halo)", t_sc)
                 if kind == "bicg":
                     sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, params=forced, exchange="p2p",
                                                         fence=fence, fused_halo=True, share_with=sh)
@@ -1138,6 +1179,7 @@ def run_solver(cx):
             except Exception as e:  # noqa: BLE001 - collective: raised on every rank or none
                 if rank == 0:
                     print(f"[bench] in-kernel halos unavailable ({e!r}); all-gathering the operands", file=sys.stderr)
+                selfchecks.setdefault("in_kernel_halo", f"fell back: {e}")
                 sh = sht = None
     if sh is None:
         sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, params=forced, bounds=bounds)
@@ -1194,6 +1236,7 @@ def run_solver(cx):
                                     "all_gather": "per product: RCCL all_gather of the operand (padded stride); dot products all-reduced"}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if world > 1 else None,
                        "pass_form": getattr(sh, "last_pass_form", None),
+                       "exchange_selfcheck": {**selfchecks, **(getattr(sh, "selfcheck", None) or {})} or None,
                        "solve_check": check, "design_point": sh.matrix.params.as_dict(),
                        "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3),
                        "collectives": getattr(sh, "last_collectives", "none")},

@@ -99,7 +99,7 @@ class ShardedSpmv:
     @classmethod
     def from_global(cls, row_ptr, col_ind, values, n_cols, rank, world, params=None, balance="nnz", group=None,
                     exchange="all_gather", fence=None, fused_halo=False, solver_slots=1, share_with=None,
-                    bounds=None):
+                    bounds=None, selfcheck=0):
         """Build this rank's block of a globally known CSR matrix on the current GPU.
 
         exchange="all_gather": block with global columns, x all-gathered per product.
@@ -110,7 +110,12 @@ class ShardedSpmv:
         ``solver_slots`` (p2p + fused_halo): 3 (CG) or 6 (BiCG) vector slots in the shared allocation, the
         layout ``cask_hip_solve_device`` runs its passes on.  ``share_with``: another p2p operator whose
         shared vectors this one reads too (the A^T block of a sharded BiCG; same row partition).
-        ``bounds``: use this row partition instead of computing one."""
+        ``bounds``: use this row partition instead of computing one.
+        ``selfcheck`` = n > 0: first-contact check of the hand-written exchange this operator uses (in-kernel halo loads,
+        push all-gather) with n operands that change every exchange (``cask_amd/selfcheck.py``), agreed collectively; the
+        outcome is ``obj.selfcheck`` = {path: "ok" | "fell back: why"}.  A failing push all-gather is replaced by the
+        collective all-gather, failing in-kernel halos by the halo pull -- or, for solver slots (which need them), raise
+        on every rank so that the caller builds the all-gather form."""
         import torch
         from . import capi
         n = len(row_ptr) - 1
@@ -150,15 +155,49 @@ class ShardedSpmv:
             obj = cls(bounds, rank, world, lambda xe, yl: mat.spmv_device(xe, yl), dev, group, exchange=ex)
             obj.fused_halo = False
             obj.n_halo = n_halo
+            obj.selfcheck = {}
             can_fuse = mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2
             if fused_halo:
                 # every rank or none: a block too small for the MERGE kernel on ONE rank must not leave the others
                 # waiting in a collective
                 can_all = all(gather_objects(bool(can_fuse)))
                 if can_all:
+                    refs = None
+                    if selfcheck and share_with is None:
+                        # reference products from a PRIVATE operand built from the formula, by the plain kernel,
+                        # before the halo sources exist
+                        from . import selfcheck as sc
+                        idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
+                        idx_halo = torch.from_numpy(halo_cols).to(dev)
+                        refs = []
+                        for e in range(selfcheck):
+                            xe = torch.cat([sc.operand(e, idx_own, n), sc.operand(e, idx_halo, n)])
+                            yr = torch.empty(n_local, dtype=torch.float64, device=dev)
+                            mat.spmv_device(xe, yr)
+                            refs.append(yr)
+                        torch.cuda.synchronize()
                     if n_halo:
                         mat.set_halo_sources(n_local, addr)   # the product kernel reads the halo from the peers itself
                     obj.fused_halo = True
+                    if refs is not None:
+                        try:
+                            ok, why = sc.check_fused_halo(torch, lambda yy: mat.spmv_device(ex.x_ext, yy), lambda e: refs[e],
+                                                          ex.x_local, idx_own, fence, n, n=selfcheck)
+                        except Exception as e:  # noqa: BLE001 - agreed on below
+                            ok, why = False, repr(e)
+                        verdicts = gather_objects(None if ok else (why or "mismatch"))
+                        bad = [v for v in verdicts if v]
+                        ex.x_local.zero_()
+                        torch.cuda.synchronize()
+                        gather_objects(None)                   # (a control-plane barrier: every slice is zero again)
+                        obj.selfcheck["in_kernel_halo"] = "ok" if not bad else f"fell back: {bad[0]}"
+                        if bad:
+                            if n_halo:
+                                mat.set_halo_sources(n_local, None)
+                            obj.fused_halo = False
+                            if ex.n_slots != 1:
+                                obj.close()
+                                raise capi.CaskHipError("in-kernel halo failed its first-contact check: " + bad[0])
                 elif ex.n_slots != 1 or share_with is not None:
                     if share_with is None:
                         obj.close()
@@ -178,8 +217,37 @@ class ShardedSpmv:
                     out = [None] * world
                     dist.all_gather_object(out, o, group=group)
                     return out
-                obj.push = p2p.PushExchange(rank, world, obj.S, dev, gather_objects)
-                obj.x_slot = obj.push.x_slot
+                obj.selfcheck = {}
+                try:
+                    obj.push = p2p.PushExchange(rank, world, obj.S, dev, gather_objects)
+                except capi.CaskHipError as e:                 # collective: raised on every rank or on none
+                    if not selfcheck:
+                        raise
+                    obj.push = None                            # (e.g. a peer's handle could not be opened): collective all-gather
+                    obj.selfcheck["push_allgather"] = f"fell back: {e}"
+                if obj.push is not None and selfcheck:
+                    from . import selfcheck as sc
+                    pos = torch.arange(obj.n_full, device=dev)
+                    owner, off = pos // obj.S, pos % obj.S
+                    valid = off < torch.tensor(obj.sizes, device=dev)[owner]
+                    idx_all = torch.where(valid, torch.tensor(obj.bounds[:-1], device=dev)[owner] + off, torch.zeros_like(pos))
+                    idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
+                    try:
+                        ok, why = sc.check_push_allgather(torch, obj.push, n_local, idx_own, idx_all, valid, n, n=selfcheck)
+                    except Exception as e:  # noqa: BLE001 - agreed on below
+                        ok, why = False, repr(e)
+                    bad = [v for v in gather_objects(None if ok else (why or "mismatch")) if v]
+                    obj.selfcheck["push_allgather"] = "ok" if not bad else f"fell back: {bad[0]}"
+                    if bad:
+                        push, obj.push = obj.push, None
+                        torch.cuda.synchronize()
+                        for g, ptr in list(push.peers.items()):
+                            p2p.close_peer(ptr)
+                        push.peers = {}
+                        gather_objects(None)                   # owners free only after every peer has unmapped
+                        push.close()
+                if obj.push is not None:
+                    obj.x_slot = obj.push.x_slot
         else:
             raise ValueError(f"unknown exchange {exchange!r}")
         obj.matrix = mat
@@ -334,9 +402,6 @@ class ShardedSpmv:
         self._spush_tried, self._spush = True, None
         if not os.environ.get("CASK_PEER_ALLREDUCE") or self.device.type != "cuda":
             return None
-        if getattr(self, "push", None) is not None:               # the vector exchange's region has the tables too
-            self._spush = self.push
-            return self._spush
         from . import p2p
 
         def gather_objects(o):
@@ -345,6 +410,9 @@ class ShardedSpmv:
             out = [None] * self.world
             dist.all_gather_object(out, o, group=self.group)
             return out
+        if getattr(self, "push", None) is not None:               # the vector exchange's region has the tables too
+            self._spush = self.push
+            return self._check_scalar_push(gather_objects)
         try:
             self._spush = p2p.PushExchange(self.rank, self.world, 2, self.device, gather_objects)
             self._spush_owned = True
@@ -352,6 +420,42 @@ class ShardedSpmv:
             if self.rank == 0:
                 import sys
                 print(f"[cask_amd.dist] peer-store all-reduce unavailable ({e!r}); using RCCL", file=sys.stderr)
+            self._spush = None
+            self._note_selfcheck("peer_store_allreduce", f"fell back: {e}")
+        return self._check_scalar_push(gather_objects)
+
+    def _note_selfcheck(self, path, verdict):
+        if not isinstance(getattr(self, "selfcheck", None), dict):
+            self.selfcheck = {}
+        self.selfcheck[path] = verdict
+
+    def _check_scalar_push(self, gather_objects):
+        """First contact of the peer-store all-reduce: 50 reductions of changing scalars against their rank-order sums on
+        every rank (cask_amd/selfcheck.py); any rank that disagrees sends every rank back to RCCL."""
+        sp = self._spush
+        if sp is None:
+            return None
+        from . import p2p
+        from . import selfcheck as sc
+        try:
+            ok, why = sc.check_push_allreduce(self.torch, sp, self.rank, self.world, self.device)
+        except Exception as e:  # noqa: BLE001 - agreed on below
+            ok, why = False, repr(e)
+        bad = [v for v in gather_objects(None if ok else (why or "mismatch")) if v]
+        self._note_selfcheck("peer_store_allreduce", "ok" if not bad else f"fell back: {bad[0]}")
+        if bad:
+            if self.rank == 0:
+                import sys
+                print(f"[cask_amd.dist] peer-store all-reduce failed its first-contact check ({bad[0]}); using RCCL",
+                      file=sys.stderr)
+            if getattr(self, "_spush_owned", False):
+                self.torch.cuda.synchronize()
+                for g, ptr in list(sp.peers.items()):
+                    p2p.close_peer(ptr)
+                sp.peers = {}
+                gather_objects(None)
+                sp.close()
+                self._spush_owned = False
             self._spush = None
         return self._spush
 

@@ -316,7 +316,11 @@ class PushExchange:
         if bad:
             self.close()
             raise capi.CaskHipError("push all-gather setup failed (" + "; ".join(bad) + ")")
+        # The signature sits in element 0 of this rank's region = rank 0's x[0] slot of gathered vector 0, a slot the
+        # PEERS store to.  It is cleared here, and nobody may push before everybody has cleared (a fast rank
+        # 0's first exchange could otherwise be overwritten by a slow rank's reset): a third control-plane round.
         self.shared.write([0.0])
+        exchange_objects(None)
         bases = [self.shared.ptr if g == rank else self.peers[g] for g in range(world)]
         full = np.array([b for b in bases] + [b + 8 * n_vec for b in bases], dtype=np.uint64)
         flags = np.array([b + 16 * n_vec for b in bases], dtype=np.uint64)

@@ -73,6 +73,35 @@ def test_two_rank_dry_run_reads_halos_in_kernel():
     assert rec["config"]["exchange"].startswith("inside the product kernel"), rec["config"]["exchange"]
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     assert rec["config"]["rows"] == 2 * 62451
+    # the first-contact self-check ran (50 exchanges, the operand changes every time) and passed
+    assert rec["config"]["exchange_selfcheck"] == {"in_kernel_halo": "ok"}
+
+
+def test_stale_halo_fault_sends_every_rank_to_the_fallback():
+    """CASK_FAULT_STALE_HALO makes a rank serve the PREVIOUS operand on odd exchanges -- what a
+    missed fence or a stale line looks like to its peers.  The self-check must see it on every path, every rank must
+    take the fallback together, and the run must still be right."""
+    # (a) in-kernel halo -> the halo pull
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--no-tune", "--copies", "2", "--no-cpu-baseline"],
+                    dict(SHARE, CASK_FAULT_STALE_HALO="halo"), world=2)
+    assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"].startswith("fell back: in-kernel halo:")
+    assert rec["config"]["exchange"].startswith("per step: pull of"), rec["config"]["exchange"]
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    # (b) push all-gather -> the collective
+    args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
+    rec = run_bench(args, dict(SHARE, CASK_FAULT_STALE_HALO="push"), world=3)
+    assert rec["config"]["exchange_selfcheck"]["push_allgather"].startswith("fell back: push all-gather:")
+    assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)")
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    # (c) sharded solver: in-kernel halos -> all-gathered operands, peer-store all-reduce -> the collective
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
+                    dict(SHARE, CASK_FAULT_STALE_HALO="1", CASK_PEER_ALLREDUCE="1"), world=2)
+    sc = rec["config"]["exchange_selfcheck"]
+    assert sc["in_kernel_halo"].startswith("fell back") and sc["peer_store_allreduce"].startswith("fell back"), sc
+    assert rec["config"]["exchange"].startswith("per product: RCCL all_gather")
+    assert not rec["config"]["collectives"].startswith("peer-store")
+    chk = rec["config"]["solve_check"]
+    assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
 
 
 def test_rccl_collectives_run_at_world_one():
@@ -116,6 +145,7 @@ def test_config4_webbase_row_partitioned_dry_run():
     assert rec["config"]["exchange"].startswith("per step: every rank stores its x slice"), rec["config"]["exchange"]
     assert rec["config"]["halo_fraction_max"] > 0.10
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    assert rec["config"]["exchange_selfcheck"] == {"push_allgather": "ok"}
     rec = run_bench(args, dict(SHARE, CASK_BENCH_EXCHANGE="all_gather"), world=4)
     assert rec["config"]["exchange"] == "per step: RCCL all_gather(x), padded stride: one collective"   # gloo dry run
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
@@ -127,6 +157,7 @@ def test_config5_atmosmodd_bicg_sharded_dry_run():
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
                     SHARE, world=4)
     assert rec["n_gpus"] == 4 and rec["config"]["exchange"].startswith("halos read inside the product kernels")
+    assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"] == "ok"
     chk = rec["config"]["solve_check"]
     assert chk["converged"] and chk["oracle_converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
     assert chk["residual_2norm_by_oracle_product"] <= 5e-5 and chk["max_abs_diff_vs_oracle_solution"] <= 1e-5
