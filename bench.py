@@ -1220,6 +1220,13 @@ def run_solver(cx):
         b_it = b_spmv + 96 * n if kind == "cg" else 2 * b_spmv + 152 * n      # SURVEY 8(d), unfused algorithmic bytes
         f_it = 2 * nnz + 12 * n if kind == "cg" else 4 * nnz + 20 * n
         achieved = b_it / world / (step_us * 1e-6) / 1e9                       # per GPU
+        traffic, traffic_source = traffic_record(f"{name}_{kind}") if world == 1 else (None, None)
+        # what a pass touches: the plan's streams (values + packed slots + row offsets) of A (and A^T) + the solver vectors
+        ws = (1 if kind == "cg" else 2) * (9.5 * nnz + 4 * n) + (5 if kind == "cg" else 9) * 8 * n
+        working_set_note = (f"a pass touches ~{ws / 2**20:.0f} MiB per GPU-set (plan streams + solver vectors) against the 256 MiB "
+                            "Infinity Cache: passes replay the same data, so part of it is served by that cache, not HBM; "
+                            "`frac` is on the UNFUSED algorithmic bytes of SURVEY 8(d) (fused kernels move fewer), `traffic` "
+                            "is what the L2 asked the fabric for per pass (cache hits included)")
         rec = {
             "metric": f"{kind.upper()} pass GFLOP/s (fp64, {'2 nnz + 12 n' if kind == 'cg' else '4 nnz + 20 n'} flop per pass), "
                       f"SuiteSparse {name}-like",
@@ -1241,7 +1248,8 @@ def run_solver(cx):
                        "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3),
                        "collectives": getattr(sh, "last_collectives", "none")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "working_set_note": working_set_note,
                          "kernel": f"{kind} pass (k_spmv_merge + update kernels)",
                          "algorithmic_bytes_per_launch": b_it // world, "launch_usec": round(step_us, 3)},
         }

@@ -1540,7 +1540,10 @@ int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint6
     return CASK_HIP_OK;
   }
   if (n_own < 1 || n_own > m->n_cols) return fail(CASK_HIP_ERR_INVALID, "n_own must lie in [1, n_cols]");
-  if (m->plan.prm.variant != CASK_HIP_VARIANT_MERGE || m->nnz < 2)
+  // A handle created with AUTO may have resolved to another family (SCAN for short, heavily skewed rows): with halo
+  // sources AUTO resolves to MERGE (resolve_params), so only an EXPLICITLY requested other variant is refused.
+  const bool auto_variant = m->requested.variant == CASK_HIP_VARIANT_AUTO;
+  if (m->nnz < 2 || (!auto_variant && m->plan.prm.variant != CASK_HIP_VARIANT_MERGE))
     return fail(CASK_HIP_ERR_INVALID, "halo sources need the MERGE variant (and at least 2 nonzeros)");
   m->halo_n_own = n_own;
   m->halo_addr = d_src_addr;

@@ -1816,7 +1816,7 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
     for (int kk = row_ptr[i]; kk < row_ptr[i + 1]; kk++) {
       const int k = col_ind[kk];
       if (k >= i) break;
-      if (diag[k] < 0) continue;
+      if (diag[k] < 0 || a[diag[k]] == 0.0) continue;        // !isNnz(k, k): absent or a stored zero (SparseMatrix.hpp:219-225)
       a[kk] = a[kk] / a[diag[k]];
       const double beta = a[kk];
       int pi = kk + 1, pk = diag[k] + 1;                     // (i, j > k) against (k, j > k), both ascending
@@ -1825,7 +1825,7 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
         if (col_ind[pi] < col_ind[pk]) pi++;
         else if (col_ind[pi] > col_ind[pk]) pk++;
         else {
-          a[pi] = a[pi] - a[pk] * beta;
+          if (a[pk] != 0.0) a[pi] = a[pi] - a[pk] * beta;     // isNnz(k, j) tests the value, not the pattern (:107)
           pi++;
           pk++;
         }

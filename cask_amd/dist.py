@@ -156,7 +156,10 @@ class ShardedSpmv:
             obj.fused_halo = False
             obj.n_halo = n_halo
             obj.selfcheck = {}
-            can_fuse = mat.params.as_dict()["variant"] == "merge" and mat.nnz >= 2
+            # (an AUTO handle that resolved to another family -- SCAN for webbase-like blocks -- is re-planned as MERGE
+            # by cask_hip_csr_set_halo_sources; only an explicitly requested other variant cannot take halo sources)
+            requested_auto = params is None or int(getattr(params, "variant", 0)) == 0
+            can_fuse = (requested_auto or mat.params.as_dict()["variant"] == "merge") and mat.nnz >= 2
             if fused_halo:
                 # every rank or none: a block too small for the MERGE kernel on ONE rank must not leave the others
                 # waiting in a collective

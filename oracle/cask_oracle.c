@@ -237,14 +237,14 @@ void oracle_ilu0(int32_t n, const int32_t *row_ptr, const int32_t *col_ind, doub
             const int32_t k = col_ind[kk];
             if (k >= i) break;
             const int64_t dk = csr_find(row_ptr, col_ind, k, k);
-            if (dk < 0) continue;
+            if (dk < 0 || a[dk] == 0.0) continue;          /* !pc.isNnz(k, k): absent OR a stored zero (SparseMatrix.hpp:219-225) */
             a[kk] = a[kk] / a[dk];
             const double beta = a[kk];
             for (int64_t jj = row_ptr[i]; jj < row_ptr[i + 1]; jj++) {
                 const int32_t j = col_ind[jj];
                 if (j < k + 1) continue;
                 const int64_t kj = csr_find(row_ptr, col_ind, k, j);
-                if (kj >= 0) a[jj] = a[jj] - a[kj] * beta;
+                if (kj >= 0 && a[kj] != 0.0) a[jj] = a[jj] - a[kj] * beta;   /* pc.isNnz(k, j), :107 */
             }
         }
     }

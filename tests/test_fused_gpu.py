@@ -132,6 +132,22 @@ def test_halo_needs_the_merge_variant():
     m.close()
 
 
+def test_an_auto_handle_that_resolved_to_scan_accepts_halo_sources():
+    """AUTO resolves to the SCAN kernel for short, heavily skewed rows (webbase-like); such a handle must
+    still take halo sources -- with them AUTO resolves to MERGE -- while an explicitly requested SCAN must not."""
+    n, rp, ci, va, _ = synth.load_or_make("webbase-1M")
+    got, want = _with_halo(n, rp, ci, va, n - n // 5, {})         # AUTO
+    oracle.assert_almost_equal(got, want, what="webbase-like, AUTO with halo sources")
+    import torch
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    assert m.params.as_dict()["variant"] == "scan"
+    m.close()
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan"))
+    with pytest.raises((capi.CaskHipError, ValueError)):
+        m.set_halo_sources(n - 16, torch.zeros(16, dtype=torch.int64, device="cuda"))
+    m.close()
+
+
 def test_p2p_symbols_exported():
     lib = capi.load()
     for sym in p2p.P2P_SYMBOLS:

@@ -258,6 +258,19 @@ def test_ilu_factor_and_apply_known_answers(known_answers):
     assert list(oracle.ilu0(m.row_ptr, m.col_ind, m.values)) == c2["factored_csr"]["values"]
 
 
+ZERO_PIVOT = (np.array([0, 2, 5, 7], dtype=np.int32), np.array([0, 1, 0, 1, 2, 1, 2], dtype=np.int32),
+              np.array([0.0, 2.0, 2.0, 4.0, 1.0, 1.0, 3.0]))        # [[0*, 2, .], [2, 4, 1], [., 1, 3]], (0,0) STORED as zero
+ZERO_PIVOT_FACTORED = [0.0, 2.0, 2.0, 4.0, 1.0, 0.25, 2.75]
+
+
+def test_ilu_skips_a_stored_zero_pivot_like_isnnz():
+    """DokMatrix::isNnz (SparseMatrix.hpp:219-225) tests the VALUE: a stored zero on the diagonal is "not there", so
+    ILUPreconditioner (SparseLinearSolvers.hpp:100-101) skips that pivot instead of dividing by it.  Hand-computed: row 1
+    keeps its (1,0) entry, row 2 gets 1/4 and 3 - 1*(1/4)."""
+    rp, ci, va = ZERO_PIVOT
+    assert list(oracle.ilu0(rp, ci, va)) == ZERO_PIVOT_FACTORED
+
+
 def test_unittrsolve_known_answers(known_answers):
     for c in known_answers["unittrsolve"]["cases"]:
         rp, ci, va = _dense_to_csr(c["dense_rows"])

@@ -61,6 +61,16 @@ def test_pcg_ilu_known_answer(known_answers):
     pc.close()
 
 
+def test_ilu_skips_a_stored_zero_pivot_like_isnnz():
+    """The product's factorisation follows DokMatrix::isNnz (value != 0, SparseMatrix.hpp:219-225) like the oracle's:
+    hand-computed answer of tests/test_oracle.py."""
+    from test_oracle import ZERO_PIVOT, ZERO_PIVOT_FACTORED
+    rp, ci, va = ZERO_PIVOT
+    pc = capi.Preconditioner("ilu0", 3, rp, ci, va)
+    assert list(pc.factor_values()) == ZERO_PIVOT_FACTORED
+    pc.close()
+
+
 @pytest.mark.parametrize("name", ["G3_circuit", "cant", "atmosmodd"])
 def test_ilu_factor_and_solves_match_the_oracle(name):
     n, rp, ci, va = synth.small(name)
