@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "atmosmodd"])
+    ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "webbase2", "atmosmodd"])
     ap.add_argument("--solver", default=None, choices=["cg", "bicg"], help="time solver passes instead of products")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager", "windowgraph"],
                     help="graph: the K steps as one HIP graph; sequence: K launches from one C call (no graph start-up "
@@ -484,6 +484,7 @@ def other_workload_specs(world):
     if world == 1:
         return [{"config": "configs[1] second look-alike", "workload": "cant3"},
                 {"config": "configs[3] on 1 GPU", "workload": "webbase-1M"},
+                {"config": "configs[3] second look-alike (hub columns, site-block locality) on 1 GPU", "workload": "webbase2"},
                 {"config": "configs[2]", "workload": "G3_circuit", "solver": "cg"},
                 {"config": "configs[4] on 1 GPU", "workload": "atmosmodd", "solver": "bicg"}]
     return [{"config": "configs[3]", "workload": "webbase-1M"},
@@ -1055,7 +1056,8 @@ def run_spmv(cx, weak):
         gflops = 2.0 * nnz_total / step_us * 1e-3
         achieved = alg_bytes / (step_us * 1e-6) / 1e9      # this rank's launch: its algorithmic bytes / the step time
         traffic, traffic_source = traffic_record(args.workload, design) if world == 1 else (None, None)
-        like = {"cant": "cant-like", "cant3": "cant-like (3x3 node blocks, non-uniform band)"}.get(args.workload, args.workload + "-like")
+        like = {"cant": "cant-like", "cant3": "cant-like (3x3 node blocks, non-uniform band)",
+                "webbase2": "webbase-1M-like (power-law in-degree: hub columns, site-block locality)"}.get(args.workload, args.workload + "-like")
         rec = {
             "metric": f"SpMV GFLOP/s (fp64 CSR, 2*nnz/t), SuiteSparse {like}", "value": round(gflops, 2),
             "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -22,6 +22,7 @@ SPECS = {
     "cant": (62_451, 4_007_383),
     "G3_circuit": (1_585_478, 7_660_826),
     "webbase-1M": (1_000_005, 3_105_536),
+    "webbase2": (1_000_005, 3_105_536),       # the same SuiteSparse matrix, second look-alike (webbase2_like)
     "atmosmodd": (1_270_432, 8_814_880),
 }
 
@@ -103,6 +104,68 @@ def webbase_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, see
     cols = np.where(local, rows + rng.integers(-1000, 1001, size=rows.size),
                     rng.integers(0, n, size=rows.size))
     cols = np.clip(cols, 0, n - 1)
+    vals = rng.random(rows.size)
+    rp, ci, va = _coo_to_csr(n, rows, cols, vals)
+    return n, rp, ci, va
+
+
+def webbase2_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, seed=7, oversample=1.113):
+    """Second webbase-1M look-alike: the same power-law OUT-degrees as ``webbase_like``, but the
+    columns of a web graph instead of uniformly random ones --
+
+    * pages are grouped into SITES (runs of consecutive ids, sizes power-law distributed, 8 .. 20 000 pages);
+    * ~70 % of a page's links stay inside its site (within +-1000 of the page, clipped to the site);
+    * the other ~30 % go to OTHER sites: every site has a handful of favourite external sites (drawn by site popularity,
+      Zipf) that most of its pages' external links go to (site-block locality of the far columns), the rest go to
+      globally popular sites; inside the target site the page is drawn from a Zipf over its pages (the home page first):
+      power-law IN-degree, hub columns.
+
+    Same n, nnz within a few per cent (duplicate links merge), same longest row."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.zipf(alpha, size=n), max_row).astype(np.int64)
+    scale = nnz_target * oversample / lens.sum()
+    lens = np.clip(np.rint(lens * scale), 1, max_row).astype(np.int64)
+    lens[rng.integers(0, n)] = max_row
+    # sites
+    sizes = []
+    total = 0
+    while total < n:
+        chunk = np.clip(rng.zipf(1.6, size=4096) * 8, 8, 20_000)
+        sizes.append(chunk)
+        total += int(chunk.sum())
+    sizes = np.concatenate(sizes)
+    ends = np.cumsum(sizes)
+    n_sites = int(np.searchsorted(ends, n, side="left")) + 1
+    sizes, ends = sizes[:n_sites].copy(), ends[:n_sites].copy()
+    ends[-1] = n
+    starts = np.concatenate([[0], ends[:-1]])
+    sizes = ends - starts
+    site_of_row = np.repeat(np.arange(n_sites), sizes)
+    # site popularity (Zipf over a random order of the sites) and every site's favourite external sites
+    rank_of_site = rng.permutation(n_sites)
+    pop = 1.0 / (1.0 + rank_of_site) ** 1.1
+    cdf = np.cumsum(pop) / pop.sum()
+    n_fav = 4
+    fav = np.searchsorted(cdf, rng.random((n_sites, n_fav))).clip(0, n_sites - 1)
+
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    site = site_of_row[rows]
+    u = rng.random(rows.size)
+    local = u < 0.7
+    # (a page with more links than its neighbourhood has pages -- a directory -- reaches proportionally further, and
+    # not only into its own site: the longest rows keep their length instead of collapsing onto duplicates)
+    reach = np.maximum(1000, 2 * lens)[rows]
+    off = np.rint((rng.random(rows.size) * 2.0 - 1.0) * reach).astype(np.int64)
+    wide = lens[rows] > 200
+    near = np.where(wide, np.clip(rows + off, 0, n - 1), np.clip(rows + off, starts[site], ends[site] - 1))
+    # external links: 80 % to one of the site's favourites, 20 % to a globally popular site
+    pick_fav = rng.random(rows.size) < 0.8
+    target = np.where(pick_fav, fav[site, rng.integers(0, n_fav, size=rows.size)],
+                      np.searchsorted(cdf, rng.random(rows.size)).clip(0, n_sites - 1))
+    # page inside the target site: Zipf over its pages, wrapped into the site
+    page = (rng.zipf(1.5, size=rows.size) - 1) % sizes[target]
+    far = starts[target] + page
+    cols = np.where(local, near, far)
     vals = rng.random(rows.size)
     rp, ci, va = _coo_to_csr(n, rows, cols, vals)
     return n, rp, ci, va
@@ -193,7 +256,8 @@ def cant3_like_shard(rank, world):
     return n, n, rp, ci, va
 
 
-GENERATORS = {"cant": cant_like, "G3_circuit": g3_like, "webbase-1M": webbase_like, "atmosmodd": atmosmodd_like}
+GENERATORS = {"cant": cant_like, "G3_circuit": g3_like, "webbase-1M": webbase_like, "webbase2": webbase2_like,
+              "atmosmodd": atmosmodd_like}
 
 
 def small(name, factor=16):
@@ -206,6 +270,8 @@ def small(name, factor=16):
         return g3_like(n=n, nx=max(8, int(round((n) ** 0.5))))
     if name == "webbase-1M":
         return webbase_like(n=n, nnz_target=int(SPECS[name][1] / factor), max_row=min(4700, n // 2))
+    if name == "webbase2":
+        return webbase2_like(n=n, nnz_target=int(SPECS[name][1] / factor), max_row=min(4700, n // 2))
     if name == "atmosmodd":
         side = max(4, int(round(n ** (1 / 3))))
         return atmosmodd_like(n=n, nx=side, ny=side)

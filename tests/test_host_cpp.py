@@ -134,7 +134,7 @@ def test_dse_executable_writes_dse_out(plain_mtx_dir, tmp_path):
     assert len(doc["best_architectures"]) == 3
     for arch in doc["best_architectures"]:
         assert arch["measured_gflops"] > 0 and arch["points_evaluated"] > 10
-        assert arch["architecture_params"]["variant"] in (1, 2, 3)
+        assert arch["architecture_params"]["variant"] in (1, 2, 3, 4, 5)      # any family may win on a small matrix
         assert arch["measured_usec"] > 0 and arch["measured_usec_warm"] > 0 and arch["matrix_copies_rotated"] >= 1
     # and the generator accepts what the DSE wrote
     subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dse", str(tmp_path / "dse_out.json"),
