@@ -82,6 +82,9 @@ struct Plan {
   DevBuf<double> partials;
   DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz), or
   bool packed12 = false;           //   12-byte records of eight 12-bit slots per thread, [block][thread] (1.5 B/nnz)
+  bool runs = false;               //   or (r4) run records: per wave and pass a 128-bit run-start mask + int16 deltas (pack_runs)
+  DevBuf<int2v> run_desc;          //   run records: per block {first dword of its records in ci16, dwords of deltas per record}
+  double slot_bytes_per_nnz = 0.0; //   what the slot stream costs (reported)
   DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
   bool one_window = false;         // every tiled block's chunks are consecutive (KIND_CONTIG): paired window loads
   int maxch = 0;
@@ -187,7 +190,8 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.xcd_remap == 0) out.xcd_remap = 1;
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.index16 == 0) out.index16 = 1;
-  if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
+  if (out.index16 > 4)
+    return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed), 2 (16-bit only), 3 (12-bit, no run records) or 4 (run records)");
   if (out.far_columns < -1 || out.far_columns > 2) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0, 1 or 2");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE || out.variant == CASK_HIP_VARIANT_SCAN) {
@@ -447,6 +451,96 @@ void pack_slots12(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks
     for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
     for (auto &th : pool) th.join();
   }
+}
+
+// Run records for the IPT = 8 merge kernel (merge_kernel.hpp, CRUN).  In pass u a wave's 64 lanes take
+// the 128 consecutive elements 2p, 2p+1, p = first + u*wg + 64*wave + lane (clamped to `last` like merge_load does).
+// Their LDS slots are written as RUNS of consecutive slots: bit i of a 128-bit mask is set where element i starts a
+// run, and run r carries delta_r = (its first slot) - (its first element), so slot(i) = i + delta[run(i)].  Elements
+// that are not the block's own (the lead of an odd start, the foreign half of the last pair, clamped duplicates) may
+// use any slot inside the tile -- their products land where no row looks -- and simply continue the run they follow.
+// Per block all records have one size: 4 dwords of mask + RD dwords of deltas (two int16 each), RD = the block's
+// longest record rounded up to 4 dwords.  Returns false when some block has more than RUN_MAX runs in a pass (rows of
+// scattered columns: the 12-bit records are smaller) -- the plan then keeps the packed 12-bit slots.
+constexpr int RUN_MAX = 64;
+bool pack_runs(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks, const std::vector<unsigned short> &ci16,
+               int wg, int limit_slots, std::vector<unsigned> &stream, std::vector<int2v> &desc) {
+  const int max_gpair = (int)((m.nnz + 1) / 2) - 1;
+  const int wpw = wg / 64, groups = 4 * wpw;
+  const size_t nb = blocks.size();
+  desc.assign(nb, int2v{0, 0});
+  std::vector<std::vector<unsigned>> recs(nb);                // per block: its records, fixed size
+  std::vector<char> bad(nb, 0);
+  auto work = [&](size_t b0, size_t b1) {
+    std::vector<int> slot(128);
+    std::vector<unsigned> masks, deltas;                      // per group: 4 dwords; per group: its runs' deltas
+    std::vector<int> n_runs;
+    for (size_t b = b0; b < b1; b++) {
+      const BlockDesc &d = blocks[b];
+      if ((d.kind_g & KIND_LONG) || d.cwidth <= 0) continue;  // long pieces and untiled blocks read 32-bit indices
+      const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;
+      const int npairs = (total + 1) >> 1, first = base >> 1;
+      const int last = std::min(first + std::max(npairs - 1, 0), max_gpair);
+      const int own0 = d.nnz_start, own1 = d.nnz_start + d.nnz_count;
+      masks.assign((size_t)groups * 4, 0u);
+      deltas.clear();
+      n_runs.assign(groups, 0);
+      std::vector<std::vector<short>> gd(groups);
+      int rmax = 0;
+      for (int g = 0; g < groups; g++) {
+        const int u = g / wpw, w = g % wpw;
+        int prev = -2;
+        for (int i = 0; i < 128; i++) {
+          const int pr = first + u * wg + 64 * w + (i >> 1);
+          const int e = 2 * pr + (i & 1);
+          const bool own = pr <= last && e >= own0 && e < own1;
+          int sl;
+          if (own) sl = ci16[e];
+          else     sl = (prev >= 0 && prev + 1 < limit_slots) ? prev + 1 : 0;   // free element: continue the run
+          if (i == 0 || sl != prev + 1) {
+            masks[(size_t)g * 4 + (i >> 5)] |= 1u << (i & 31);
+            gd[g].push_back((short)(sl - i));
+          }
+          prev = sl;
+        }
+        n_runs[g] = (int)gd[g].size();
+        rmax = std::max(rmax, n_runs[g]);
+      }
+      if (rmax > RUN_MAX) { bad[b] = 1; continue; }
+      const int rd = ((rmax + 1) / 2 + 3) & ~3;               // dwords of deltas per record, a multiple of 4
+      std::vector<unsigned> &out = recs[b];
+      out.assign((size_t)groups * (4 + rd), 0u);
+      for (int g = 0; g < groups; g++) {
+        unsigned *rec = out.data() + (size_t)g * (4 + rd);
+        for (int k = 0; k < 4; k++) rec[k] = masks[(size_t)g * 4 + k];
+        for (int r = 0; r < n_runs[g]; r++)
+          rec[4 + (r >> 1)] |= (unsigned)(unsigned short)gd[g][r] << (16 * (r & 1));
+      }
+      desc[b].y = rd;
+    }
+  };
+  size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
+  if (n_threads <= 1) {
+    work(0, nb);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
+    for (auto &th : pool) th.join();
+  }
+  for (size_t b = 0; b < nb; b++)
+    if (bad[b]) return false;
+  size_t total = 0;
+  for (size_t b = 0; b < nb; b++) total += recs[b].size();
+  if (total >= (size_t)1 << 30) return false;
+  stream.clear();
+  stream.reserve(total + 4);
+  for (size_t b = 0; b < nb; b++) {
+    desc[b].x = (int)stream.size();
+    stream.insert(stream.end(), recs[b].begin(), recs[b].end());
+  }
+  stream.resize(stream.size() + 4, 0u);                       // (a clamped 16-byte read at the very end stays inside)
+  return true;
 }
 
 // Host twin of logical_block() (spmv_kernels.hpp).
@@ -737,6 +831,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.long_blocks.release();
   pl.ci16.release();
   pl.packed12 = false;
+  pl.runs = false;
+  pl.run_desc.release();
   pl.one_window = false;
   pl.xchunk.release();
   pl.maxch = 0;
@@ -903,14 +999,41 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
           if (!(d.kind_g & KIND_LONG) && d.cwidth > 0 && !(d.kind_g & KIND_CONTIG)) pl.one_window = false;
         // index16 = 1 packs the slots 12 bits each where the kernel has that layout (8 items per thread, tile of
         // at most 4096 slots): 1.5 instead of 2 bytes per nonzero; index16 = 2 keeps 16-bit slots
-        pl.packed12 = prm.index16 == 1 && prm.items_per_thread == 8 && pl.prm.tile_width <= 4096;
-        if (pl.packed12) {
+        pl.packed12 = (prm.index16 == 1 || prm.index16 == 3 || prm.index16 == 4) && prm.items_per_thread == 8 &&
+                      pl.prm.tile_width <= 4096;
+        // ... or, r4, as run records where the block's slots come in runs (FEM matrices with several unknowns per
+        // node): OPT-IN, index16 = 4 (whenever they can be built).  They are a measured loss: on the cant3 look-alike
+        // the slot stream falls from 1.5 to 0.38 bytes per nonzero (44.0 -> 39.2 MB per launch) and the launch goes
+        // from 8.80 to 9.83 us -- the decode (popcounts, two ds_bpermute and selects per pass: ~100 VALU instructions
+        // per thread on top of ~350) costs more issue slots than the bytes buy (profiles/r04_run_records.txt).  AUTO
+        // (0/1) and 3 never take them.
+        pl.runs = false;
+        pl.slot_bytes_per_nnz = pl.packed12 ? 1.5 : 2.0;
+        if (pl.packed12 && prm.index16 == 4 && prm.nontemporal > 0 && !pl.any_skew && pl.n_far == 0) {
+          std::vector<unsigned> rstream;
+          std::vector<int2v> rdesc;
+          const double bytes12 = 12.0 * prm.wg_size * (double)blocks.size();
+          if (pack_runs(m, blocks, ci16, prm.wg_size, xu * prm.wg_size, rstream, rdesc) &&
+              4.0 * rstream.size() < bytes12) {
+            pl.runs = true;
+            pl.packed12 = false;
+            pl.slot_bytes_per_nnz = m.nnz ? 4.0 * rstream.size() / (double)m.nnz : 0.0;
+            std::vector<unsigned short> as16(rstream.size() * 2);
+            std::memcpy(as16.data(), rstream.data(), rstream.size() * 4);
+            HIP_TRY(pl.ci16.upload(as16));
+            HIP_TRY(pl.run_desc.upload(rdesc));
+          }
+        }
+        if (pl.runs) {
+          // uploaded above
+        } else if (pl.packed12) {
           std::vector<unsigned short> packed;
           pack_slots12(m, blocks, ci16, prm.wg_size, packed);
           HIP_TRY(pl.ci16.upload(packed));
         } else {
           HIP_TRY(pl.ci16.upload(ci16));
         }
+        pl.prm.index16 = pl.runs ? 4 : pl.packed12 ? 1 : 2;  // reported: what the plan streams
       }
       HIP_TRY(pl.blocks.upload(blocks));               // cwidth now holds the slots each block uses
     } else if (tile > 0 && m.nnz > 0) {
@@ -996,6 +1119,7 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
     return fail(CASK_HIP_ERR_INVALID, "clone_plan: different matrices");
   d.prm = s.prm; d.grid = s.grid; d.lds_bytes = s.lds_bytes; d.ldsx = s.ldsx; d.xu = s.xu;
   d.n_blocks = s.n_blocks; d.n_long_blocks = s.n_long_blocks; d.packed12 = s.packed12; d.one_window = s.one_window;
+  d.runs = s.runs; d.slot_bytes_per_nnz = s.slot_bytes_per_nnz; HIP_TRY(d.run_desc.copy_from(s.run_desc));
   d.maxch = s.maxch; d.any_skew = s.any_skew; d.pair_ok = s.pair_ok; d.n_long_rows = s.n_long_rows;
   d.n_split_rows = s.n_split_rows; d.n_far = s.n_far; d.far_grid = s.far_grid; d.far_panels = s.far_panels;
   d.scan_far = s.scan_far;
@@ -1073,6 +1197,7 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.ci = m.d_ci;
   l.ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
   l.packed12 = pl.packed12;
+  l.run_desc = pl.runs ? pl.run_desc.p : nullptr;
   l.one_window = pl.one_window;
   l.xchunk = pl.xchunk.p;
   l.val = m.d_val;

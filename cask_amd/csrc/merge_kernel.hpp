@@ -229,8 +229,8 @@ __device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassSc
   }
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool FAR>
-__device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool FAR, bool CRUN = false>
+__device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
@@ -354,11 +354,34 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
     c12[1] = stream_load<NT>(rec + 1);
     c12[2] = stream_load<NT>(rec + 2);
   }
+  // CRUN (r4): the slots as RUNS of consecutive slots.  The 128 elements a wave takes in one pass u (lane l: elements
+  // 2l, 2l+1 of the pass) are described by one record: a 128-bit mask of the elements that start a run and, per run,
+  // delta = (first slot - first element) as int16, two per dword -- slot(e) = e + delta[run(e)].  FEM matrices with
+  // several unknowns per node (cant: 3 x 3 blocks) have ~15 runs per 128 elements: 0.4 instead of 1.5 bytes per
+  // nonzero.  The mask is the same for the whole wave (scalar loads), lane j fetches dword j of the deltas.
+  typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+  uint4v rmask[CRUN ? IPT / 2 : 1];
+  unsigned rtab[CRUN ? IPT / 2 : 1];
+  if (CRUN) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+    const int stride = 4 + rdesc.y;                           // dwords: mask + deltas
+    const int jd = min(lane, rdesc.y - 1);
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      const unsigned *rec = ci16 + (size_t)__builtin_amdgcn_readfirstlane(rdesc.x + (u * wpw + wave) * stride);
+      rmask[CRUN ? u : 0] = *reinterpret_cast<const uint4v *>(rec);
+      rtab[CRUN ? u : 0] = stream_load<NT>(rec + 4 + jd);
+    }
+  }
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
+#if defined(CASK_ABL) && (CASK_ABL & 8)                       // diagnostic build: what do thread-consecutive (64-byte strided) stream loads cost?
+    const int p = min(first + (IPT / 2) * tid + u, last);
+#else
     const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
+#endif
     v[u] = stream_load<NT>(val2 + p);
-    if (C12) continue;
+    if (C12 || CRUN) continue;
     if (C16) c16[u] = stream_load<NT>(ci16 + p);
     else     c[u] = stream_load<NT>(ci2 + p);
   }
@@ -441,6 +464,24 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
       c[IPT / 2 > 3 ? 3 : 0].x = (int)((q2 >> 8) & 0xfffu);
       c[IPT / 2 > 3 ? 3 : 0].y = (int)(q2 >> 20);
     }
+  } else if (CRUN) {                                          // the slots from the run records (the stream is still landing)
+    const int lane = tid & 63;
+    const unsigned e0 = 2u * (unsigned)lane, sel = (unsigned)lane >> 4, bit = e0 & 31u;
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      const uint4v mk = rmask[CRUN ? u : 0];
+      const unsigned c0 = __builtin_popcount(mk.x), c01 = c0 + __builtin_popcount(mk.y), c012 = c01 + __builtin_popcount(mk.z);
+      const unsigned mw = sel == 0 ? mk.x : sel == 1 ? mk.y : sel == 2 ? mk.z : mk.w;
+      const unsigned pre = sel == 0 ? 0u : sel == 1 ? c0 : sel == 2 ? c01 : c012;
+      const unsigned r0 = pre + __builtin_popcount(mw & ((2u << bit) - 1u)) - 1u;       // run of element e0 (bit 0 of a pass is set)
+      const unsigned r1 = r0 + ((mw >> (bit + 1u)) & 1u);                                // ... of e0 + 1
+      const int t0 = __builtin_amdgcn_ds_bpermute((int)((r0 >> 1) << 2), (int)rtab[CRUN ? u : 0]);
+      const int t1 = __builtin_amdgcn_ds_bpermute((int)((r1 >> 1) << 2), (int)rtab[CRUN ? u : 0]);
+      const int d0 = (r0 & 1u) ? (t0 >> 16) : (int)(short)(t0 & 0xffff);
+      const int d1 = (r1 & 1u) ? (t1 >> 16) : (int)(short)(t1 & 0xffff);
+      c[u].x = (int)e0 + d0;
+      c[u].y = (int)e0 + 1 + d1;
+    }
   } else if (C16) {                                           // unpack the 16-bit slots only now
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
@@ -452,7 +493,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   // foreign elements: give them a column this block owns, so their gather stays
   // inside the x window / inside x (their products land in slots no row uses); the packed records
   // come with that done
-  if (!C12) {
+  if (!C12 && !CRUN) {
     if (lead && tid == 0) c[0].x = c[0].y;
     if (total & 1) {
 #pragma unroll
@@ -516,7 +557,11 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(3);
 #endif
 #pragma unroll
+#if defined(CASK_ABL) && (CASK_ABL & 8)
+  for (int u = 0; u < IPT / 2; u++) prod2[(IPT / 2) * tid + u] = v[u] * xv[u];
+#else
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
+#endif
   if ((EXT == 1 && w) || (EXT == 2 && w)) {                   // solver pass: w != NULL means "leave the dot shares behind"
     wl[tid] = w0;
     wl[tid + WG] = w1;
@@ -525,8 +570,8 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR>
-__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR, bool CRUN = false>
+__device__ __forceinline__ void merge_block(const BlockDesc &d, const int2v rdesc, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
@@ -546,10 +591,10 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, false, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                             halo, wsrc, wl, lb, sp, ps, farx, far_col);
   else
-    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                              halo, wsrc, wl, lb, sp, ps, farx, far_col);
   const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
 
@@ -583,15 +628,16 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 // memory system's limits pays for every extra branch, register and byte of LDS (measured while adding them:
 // +1 to +6 %).
 // FAR: the plan has blocks with far slots (KIND_FAR; plans without any run the instantiation without that code).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR, bool CRUN = false>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
                              PassArg<EXT> pass_arg, const double *__restrict__ farx,
-                             const int *__restrict__ far_col) {
+                             const int *__restrict__ far_col, const int2v *__restrict__ run_desc) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
+  static_assert(!CRUN || (C16 && !C12 && IPT == 8 && XU > 0), "run records: tiled blocks, 8 items per thread");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
@@ -601,6 +647,8 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   CASK_STAMP(0);
   const int lb = logical_block(blockIdx.x, n_blocks, remap);
   const BlockDesc d = blocks[lb];
+  int2v rdesc = {0, 0};
+  if (CRUN) rdesc = run_desc[lb];                             // where the block's run records start, how long they are
   const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
 
   const SolverPass sp = pass_of(pass_arg);                    // EXT < 2: all zeros, every use folds away
@@ -698,10 +746,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                              xs, halo, dot, lb, sp, ps, farx, far_col);
   else
-    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false, false>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                               xs, halo, dot, lb, sp, ps, farx, far_col);
   CASK_STAMP(5);
 }

@@ -17,6 +17,7 @@ struct MergeLaunch {
   const int *rp, *ci;
   const unsigned *ci16;            // NULL: 32-bit indices; else 16-bit slots per nonzero, or (packed12) 12-byte records
   bool packed12;                   //   of eight 12-bit slots per thread, [block][thread]
+  const int2v *run_desc;           // non-NULL: ci16 holds RUN RECORDS (merge_kernel.hpp, CRUN); per block {first dword, dwords of deltas}
   bool one_window;                 // every tiled block's tile is one contiguous window (paired window loads)
   const int *xchunk;
   const double *val;

@@ -9,10 +9,11 @@ namespace caskhip {
 template <int IPT, int XU>
 static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
   const dim3 grid(l.grid), block(l.wg_size);
-#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS)                                                   \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR>), grid, block, l.lds_bytes, s,      \
+#define CASK_LAUNCH_KR(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS, CRUN)                                            \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR, CRUN>), grid, block, l.lds_bytes, s, \
                      l.blocks, l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, \
-                     y, l.partials, l.halo, l.dot, PASS, l.farx, l.far_col)
+                     y, l.partials, l.halo, l.dot, PASS, l.farx, l.far_col, l.run_desc)
+#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS) CASK_LAUNCH_KR(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS, false)
   // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one, a solver
   // pass the one that composes its operand
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
@@ -29,12 +30,22 @@ static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hi
     if (ext) CASK_LAUNCH_K(NT, C16, C12, false, SKEW, 1, true, PassArg<1>{});                \
     else     CASK_LAUNCH_K(NT, C16, C12, false, SKEW, 0, true, PassArg<0>{});                \
   } while (0)
+  // run records (r4): streaming loads, no skewed blocks, no far slots (the planner only builds them for such plans)
+#define CASK_LAUNCH_R(WIDE)                                                                             \
+  do {                                                                                                  \
+    if (l.solver_pass) CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 2, false, pass2, CAN12);         \
+    else if (ext)      CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 1, false, PassArg<1>{}, CAN12);  \
+    else               CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 0, false, PassArg<0>{}, CAN12);  \
+  } while (0)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = l.nontemporal || l.any_skew;
   constexpr bool TILED = XU > 0;
   constexpr bool CAN12 = TILED && IPT == 8;                   // 12-bit packed slots exist for 8 items per thread
   constexpr bool CANWIDE = CAN12 && XU >= 2;                  // paired window loads: packed plans whose tiles are one window
-  if (TILED && l.ci16 && l.far && l.packed12 && CAN12) {
+  if (TILED && l.ci16 && l.run_desc && CAN12) {
+    if (l.one_window && CANWIDE) CASK_LAUNCH_R(CANWIDE);
+    else                         CASK_LAUNCH_R(false);
+  } else if (TILED && l.ci16 && l.far && l.packed12 && CAN12) {
     if (l.any_skew) CASK_LAUNCH_F(true, TILED, CAN12, true);
     else if (nt)    CASK_LAUNCH_F(true, TILED, CAN12, false);
     else            CASK_LAUNCH_F(false, TILED, CAN12, false);
@@ -60,6 +71,8 @@ static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hi
     else            CASK_LAUNCH_M(false, false, false, false, false);
   }
 #undef CASK_LAUNCH_K
+#undef CASK_LAUNCH_KR
+#undef CASK_LAUNCH_R
 #undef CASK_LAUNCH_M
 #undef CASK_LAUNCH_F
 }

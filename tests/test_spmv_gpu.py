@@ -116,6 +116,73 @@ def test_baseline_configs_full_size(name):
         np.testing.assert_allclose(y1.sum(), colsum @ x1, rtol=1e-9, atol=1e-8 * np.abs(y1).sum())
 
 
+def _cant3_small():
+    return synth.cant3_like(nx=9, ny=9, nz=33)                  # 8 019 rows, the full matrix's 3 x 3 node blocks
+
+
+@pytest.mark.parametrize("shape", [dict(wg_size=256, tile_width=1024), dict(wg_size=512, tile_width=4096),
+                                   dict(wg_size=128, tile_width=2048)], ids=["w256", "w512", "w128"])
+def test_run_records_give_the_bits_of_the_packed_slots(shape):
+    """the column stream as RUNS of consecutive LDS slots (index16 = 4; merge_kernel.hpp CRUN,
+    cask_hip.hip pack_runs) must gather exactly what the 12-bit packed slots gather (index16 = 3): same products in the
+    same order, bit-identical rows; both against the oracle.  Full-size cant3 (runs of 9) and a small instance whose
+    last block ends in clamped duplicates."""
+    for gen in (synth.cant3_like, _cant3_small):
+        n, rp, ci, va = gen()
+        x = np.random.default_rng(21).uniform(-1, 1, n)
+        want = oracle.csr_spmv(rp, ci, va, x)
+        ys = {}
+        for i16 in (4, 3):
+            m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=i16, **shape))
+            ys[i16] = m.spmv(x)
+            assert m.params.as_dict()["index16"] == (4 if i16 == 4 else 1), m.params.as_dict()
+            assert np.array_equal(ys[i16], m.spmv(x))
+            m.close()
+        oracle.assert_almost_equal(ys[4], want, what=f"run records {shape}")
+        assert np.array_equal(ys[4], ys[3])
+
+
+def test_run_records_are_not_taken_where_columns_scatter():
+    """Rows of scattered columns (the cant-like band: 1.09 columns per run) have ~118 runs per 128 elements -- more
+    bytes than 12-bit slots: asking for run records falls back to the packed records (and AUTO never takes run
+    records: they are a measured loss, profiles/r04_run_records.txt)."""
+    n, rp, ci, va = synth.small("cant", factor=4)
+    x = mmio.test_vector(n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    for i16 in (0, 4):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=i16))
+        assert m.params.as_dict()["index16"] == 1
+        oracle.assert_almost_equal(m.spmv(x), want, what=f"cant-like index16={i16}")
+        m.close()
+
+
+def test_run_records_with_a_dot_epilogue_and_in_a_solver_pass():
+    """The extended instantiations (EXT = 1: dot epilogue; EXT = 2: composed solver pass) decode the same records."""
+    import torch
+    n, rp, ci, va = _cant3_small()
+    rng = np.random.default_rng(4)
+    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=4))
+    assert m.params.as_dict()["index16"] == 4
+    xt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    yt = torch.empty(n, dtype=torch.float64, device="cuda")
+    dt = torch.zeros(1, dtype=torch.float64, device="cuda")
+    m.spmv_dot_device(xt, yt, wt, dt)
+    torch.cuda.synchronize()
+    want = oracle.csr_spmv(rp, ci, va, x)
+    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="run records + dot epilogue")
+    assert abs(float(dt[0]) - float(w @ want)) <= 1e-9 * max(1.0, abs(float(w @ want)))
+    b = torch.from_numpy(oracle.csr_spmv(rp, ci, va, np.ones(n))).cuda()
+    sols = []
+    for mode in (capi.SOLVER_CLASSIC, capi.SOLVER_COMPOSED):
+        xs = torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, conv, _ = m.solve_device(b, xs, kind="cg", mode=mode, maxiters=2000, tol=1e-9)
+        torch.cuda.synchronize()
+        sols.append(xs.cpu().numpy())
+        assert conv and np.abs(sols[-1] - 1.0).max() < 1e-6, (mode, it)
+    m.close()
+
+
 def test_edge_shapes():
     # no rows at all
     m = capi.CsrMatrix.from_host(0, 0, [0], [], [])
@@ -465,7 +532,7 @@ def test_cant3_fem_blocks_wide_band():
         assert np.array_equal(y, again)
         np.testing.assert_allclose(y.sum(), colsum @ x, rtol=1e-9, atol=1e-8 * np.abs(y).sum())
         if not dp:
-            assert prm["variant"] == "merge" and prm["index16"] == 1 and prm["tile_width"] > 0   # slots, tiled
+            assert prm["variant"] == "merge" and prm["index16"] == 1 and prm["tile_width"] > 0   # 12-bit slots, tiled
     # the narrow-band numbering of the same mesh
     n2, rp2, ci2, va2 = synth.cant3_like(order="x_fastest")
     x2 = rng.uniform(-1, 1, n2)
