@@ -2467,6 +2467,108 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
 // preconditioner applied on the device: r = b - A x ; z = M^-1 r ; p = z ; rsold = r.z ; then per pass
 // Ap = A p ; alpha = rsold / p.Ap ; x += alpha p ; r -= alpha Ap ; z = M^-1 r ; rsnew = r.z ;
 // stop if rsnew <= tol^2 ; p = z + (rsnew/rsold) p.  `iterations` as the reference counts them.
+// out[i] = in[perm[i]] (into colour order) / out[perm[i]] = in[i] (back)
+__global__ void k_permute_in(int64_t n, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
+}
+__global__ void k_permute_out(int64_t n, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[perm[i]] = in[i];
+}
+
+// PCG with the multicolour ILU(0) (CASK_HIP_PRECOND_ILU0_MC, r4): the whole solve runs in COLOUR ORDER.  b and the
+// initial guess are permuted once on the way in, x once on the way out; the product is the engine's own kernel on
+// P A P^T (a handle built once and kept on the preconditioner); the x / r update of a pass rides in the forward sweeps
+// and the shares of r.z come out of the backward sweeps, so a pass is   product + p.Ap  |  C forward  |  C backward  |
+// p update   = 2 C + 2 launches with no permutation pass and no separate dot (round 3: 8 sweeps + 2 permutations + a
+// generic pass = 134 us on the G3_circuit-like system; this form: see profiles/r04_pcg_mc.txt).  Recurrence, stopping
+// rule and `iterations` as pcg (SparseLinearSolvers.hpp:162-239).
+static int pcg_multicolour(cask_hip_matrix *m, cask_hip_precond *precond, const cask_hip_mc_view &mc, const double *rhs,
+                           double *x, int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
+                           double *usec_per_iteration) {
+  const int64_t n = m->n_rows;
+  hipStream_t s = m->stream;
+  int rc;
+  if (!*mc.product) {
+    cask_hip_params prm{};
+    prm.variant = CASK_HIP_VARIANT_MERGE;                      // (the fused dot epilogue lives in the merge kernel)
+    rc = cask_hip_csr_create(m->n_rows, m->n_cols, m->nnz, mc.h_rp, mc.h_ci, mc.h_va, &prm, mc.product);
+    if (rc) return rc;
+  }
+  cask_hip_matrix *mp = *mc.product;
+  DevBuf<double> dx, db, xin, r, z, p, Ap, part_rz, scal;
+  DevBuf<int> flags;
+  HIP_TRY(xin.upload(x, n)); HIP_TRY(db.upload(rhs, n));
+  HIP_TRY(dx.alloc(n)); HIP_TRY(r.alloc(n)); HIP_TRY(z.alloc(n + 1)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
+  HIP_TRY(part_rz.alloc((size_t)std::max(mc.n_part_rz, 1))); HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(z.p + n, 0, sizeof(double), s));
+  double *rs[2] = {scal.p, scal.p + 1};
+  int *done = flags.p, *iters = flags.p + 1;
+  const int g = blas_grid(n);
+  const dim3 bg(g), bw(BLAS_WG);
+  hipLaunchKernelGGL(k_permute_in, bg, bw, 0, s, n, mc.d_perm, xin.p, dx.p);
+  hipLaunchKernelGGL(k_permute_in, bg, bw, 0, s, n, mc.d_perm, db.p, xin.p);             // xin now holds P b
+  rc = launch_spmv(*mp, dx.p, r.p, s);                                                   // :189-190
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, xin.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
+                     r.p, (const int *)nullptr);
+  cask_hip_mc_sweep_args sw{};
+  sw.r = r.p;
+  sw.z = z.p;
+  sw.part_rz = part_rz.p;
+  rc = cask_hip_precond_mc_sweeps(precond, &sw, s);                                      // :193, with the shares of r.z
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(p.p, z.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));    // :195
+  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, mc.n_part_rz, part_rz.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+
+  DevEvent e0, e1;
+  HIP_TRY(e0.create()); HIP_TRY(e1.create());
+  HIP_TRY(hipEventRecord(e0, s));
+  const int check_every = 16;
+  int h_flags[2] = {0, 0};
+  int launched = 0;
+  double clean_us = 0.0;
+  if (!plan_fuses_dot(mp->plan)) return fail(CASK_HIP_ERR_RUNTIME, "the permuted matrix's plan has no dot epilogue");
+  for (int i = 0; i < maxiters; i++) {
+    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
+    rc = launch_spmv(*mp, p.p, Ap.p, s, p.p);                                            // :206-208
+    if (rc) return rc;
+    sw.rsold = rsold;                                                                    // :210-212 inside the forward sweeps
+    sw.part_pAp = mp->plan.dot_part.p;
+    sw.n_pAp = dot_part_count(mp->plan);
+    sw.p = p.p;
+    sw.Ap = Ap.p;
+    sw.x = dx.p;
+    sw.done = done;
+    rc = cask_hip_precond_mc_sweeps(precond, &sw, s);                                    // :215, :218
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, part_rz.p, mc.n_part_rz, rsold, rsnew, tol * tol, i, z.p, p.p, done,
+                       iters);                                                           // :220-231
+    launched = i + 1;
+    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h_flags[0]) break;
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / launched;
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  hipLaunchKernelGGL(k_permute_out, bg, bw, 0, s, n, mc.d_perm, dx.p, xin.p);
+  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(x, xin.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (iterations) *iterations = h_flags[1];
+  if (converged) *converged = h_flags[0] != 0;
+  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
+  return CASK_HIP_OK;
+}
+
 int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x, int32_t maxiters,
                  double tol, int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
   int rc = solver_common_checks(m, rhs, x, maxiters, tol);
@@ -2475,6 +2577,11 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   if (cask_hip_precond_rows(precond) != m->n_rows)
     return fail(CASK_HIP_ERR_INVALID, "the preconditioner was built for a matrix of a different order");
   HIP_TRY(hipSetDevice(m->device));
+  {
+    cask_hip_mc_view mc{};
+    if (cask_hip_precond_mc_view(precond, &mc) && m->n_rows > 0 && m->nnz >= 2 && !std::getenv("CASK_HIP_PCG_MC_GENERIC"))
+      return pcg_multicolour(m, precond, mc, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+  }
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;
   DevBuf<double> dx, db, r, z, p, Ap, partials, partials_rz, scal;

@@ -8,6 +8,8 @@ bitwise equal to the oracle; triangular solves run the same per-row substitution
 contracts "s -= v*x" into an FMA -> the reference's almost_equal(1e-8, 1e-11) against the oracle
 (exact on the known answers); pcg sums dots in a different (tree) order -> relative 1e-10 against the oracle at
 convergence, and 1e-9 relative after the 2000 stagnating passes of the reference's ILU test."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -363,6 +365,28 @@ def test_multicolour_ilu_apply_and_pcg():
     x, it_mc, conv_mc, _ = m.pcg(pc, b, tol=1e-9)
     assert conv_plain and conv_mc and it_mc < it_plain, (it_mc, it_plain)
     np.testing.assert_allclose(x, x0, rtol=1e-6, atol=1e-8)
+    # r4: cask_hip_pcg runs this preconditioner's solve ENTIRELY in colour order (permuted matrix, sliced-ELL sweeps with
+    # the x / r update and the r.z shares fused).  Against the oracle's pcg with the textbook ILU(0) on the PERMUTED
+    # system (which is what a multicolour ILU is): same iteration count, same iterate; and against the round-3 form
+    # (natural-order vectors, generic pass) of the same library.
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    pa = a[perm][:, perm].tocsr()
+    pa.sort_indices()
+    prp, pci, pva = pa.indptr.astype(np.int32), pa.indices.astype(np.int32), pa.data.astype(np.float64)
+    xo, it_o, conv_o = oracle.pcg_precond(prp, pci, pva, b[perm], kind="ilu0_unit", tol=1e-9, full=True)
+    want_x = np.empty(n)
+    want_x[perm] = xo
+    assert conv_o and abs(it_mc - it_o) <= 1, (it_mc, it_o)
+    np.testing.assert_allclose(x, want_x, rtol=1e-7, atol=1e-9)
+    os.environ["CASK_HIP_PCG_MC_GENERIC"] = "1"
+    try:
+        xg, it_g, conv_g, _ = m.pcg(pc, b, tol=1e-9)
+    finally:
+        del os.environ["CASK_HIP_PCG_MC_GENERIC"]
+    assert conv_g and abs(it_g - it_mc) <= 1
+    np.testing.assert_allclose(x, xg, rtol=1e-7, atol=1e-9)
+    x2, it2, _, _ = m.pcg(pc, b, tol=1e-9)                      # reproducible run to run, and the handle is reused
+    assert it2 == it_mc and np.array_equal(x, x2)
     m.close()
     pc.close()
     # a structurally unsymmetric matrix is refused
