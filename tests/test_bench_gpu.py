@@ -61,6 +61,9 @@ def test_single_rank_line():
     assert cpu["kind"] in ("mkl", "port") and cpu["parity_gpu_vs_cpu_mismatches"] == 0 and cpu["cores"] >= 1
     if cpu["kind"] == "mkl":
         assert cpu["mismatches_vs_oracle"] == 0 and cpu["port"]["kind"] == "port" and cpu["port"]["cores"] == 1
+    # ms_per_step is the MEDIAN of >= 31 back-to-back K-step windows; spread and clocks in the line
+    assert rec["windows"] >= 31 and rec["ms_per_step_min"] <= rec["ms_per_step_p10"] <= rec["ms_per_step"] <= rec["ms_per_step_p90"] <= rec["ms_per_step_max"]
+    assert "MEDIAN" in rec["clock"] and "gpu_clocks_mhz" in rec
     assert rec["config"]["plan_seconds"] > 0 and rec["config"]["upload_seconds"] > 0
     assert "workload" in rec["config"] and "model" not in rec["config"]
 
@@ -191,15 +194,19 @@ def test_default_line_carries_the_other_baseline_configs():
     rec = run_bench(["--steps", "20", "--warmup", "4", "--copies", "3", "--cpu-seconds", "0.5", "--other-steps", "40",
                      "--with-others"])
     others = rec["config"]["other_workloads"]
-    assert [o.get("error") for o in others] == [None] * 4, others
+    assert [o.get("error") for o in others] == [None] * 5, others
+    assert "appended_workloads_failed" not in rec
     names = [o["workload"] for o in others]
-    assert "cant" in names[0] and "webbase-1M" in names[1] and "G3_circuit" in names[2] and "atmosmodd" in names[3]
-    for o in others[:2]:
+    assert "cant" in names[0] and "webbase-1M" in names[1] and "hub columns" in names[2] and "G3_circuit" in names[3] \
+        and "atmosmodd" in names[4]
+    for o in others[:3]:
         assert o["rows_wrong"] == 0 and 0 < o["frac"] < 1 and o["usec"] > 0
-    for o in others[2:]:
+        assert o["windows"] >= 31 and o["usec_p10"] <= o["usec"] <= o["usec_p90"]
+    for o in others[3:]:
         chk = o["solve_check"]
         assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
         assert chk["residual_2norm_by_oracle_product"] <= 5e-5 and 0 < o["frac"] < 1
+        assert o["traffic"] and "profiles/traffic_" in o["traffic_source"]          # no "traffic": null
     # the headline is the cant line, on its own clock, unchanged by what follows
     assert rec["config"]["workload"].startswith("cant-like") and rec["steps"] == 20
 
