@@ -412,7 +412,9 @@ def main():
             return run_solver(c)
         return run_spmv(c, weak=a.workload in ("cant", "cant3"))
 
+    t_head = time.perf_counter()
     rec = run_one(args)
+    phase("headline (everything above, + post-run check, warm-cache figures, CPU baseline)", t_head)
     # ---- the other BASELINE configs next to the headline (default cant run only) ------------------------------
     if args.workload == "cant" and not args.solver and not args.no_others:
         import threading
@@ -441,6 +443,7 @@ def main():
             t0 = time.perf_counter()
             try:
                 sub = run_one(a)
+                phase(f"appended workload {spec['workload']}" + (f" --solver {spec['solver']}" if spec.get("solver") else ""), t0)
                 if rank == 0:
                     others.append(summarise_other(spec, sub, time.perf_counter() - t0))
             except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
@@ -805,6 +808,7 @@ def run_spmv(cx, weak):
                     push.close()
                     push = None
     gen_seconds = time.perf_counter() - t_gen
+    phase(f"{args.workload}: generate + partition + exchange set-up", t_gen)
     # bytes the local kernel must move: x entries = the columns this block can reference
     alg_bytes = synth.algorithmic_bytes(n_local, n_cols_alg, nnz_local)
     matrix_bytes = 12 * nnz_local + 4 * (n_local + 1)
@@ -892,7 +896,9 @@ def run_spmv(cx, weak):
         x_in = torch.from_numpy(x_host).to(dev)
     y = torch.zeros(n_local, dtype=torch.float64, device=dev)
 
+    phase(f"{args.workload}: upload + plans of {copies} rotating copies", t_up)
     # ---- measured DSE (cold: on the rotating copies), best point left active --------
+    t_tune = time.perf_counter()
     tune_info = None
     if not args.no_tune and args.variant is None:
         from cask_amd import dse
@@ -907,6 +913,8 @@ def run_spmv(cx, weak):
         tune_info = {"points": len(rows), "best_usec_cold": best["usec"], "seconds": round(took, 2)}
     design = mats[0].params.as_dict()
     info = mats[0].info
+    phase(f"{args.workload}: measured DSE", t_tune)
+    t_timed = time.perf_counter()
 
     def step(i):
         if exchange == "push":
@@ -1018,6 +1026,7 @@ def run_spmv(cx, weak):
         if graph is not None else
         "; K launches + one timing event (no system-scope fence) per window from one C call, an untimed sequence of K "
         "launches queued in front of the first event" if sequence else "")
+    phase(f"{args.workload}: warm-up, pre-roll and {tw['windows']} timed windows", t_timed)
     y_gpu = y.cpu().numpy()
     # post-run check: every rank's whole block against the CPU oracle (the global x is a formula, nothing to gather)
     import oracle
@@ -1137,6 +1146,7 @@ def run_solver(cx):
     args, rank, world, dev, use_dist = cx.args, cx.rank, cx.world, cx.dev, cx.use_dist
     kind = args.solver
     name = args.workload
+    t_all = time.perf_counter()
     n, rp, ci, va, source = synth.load_or_make(name)
     nnz = int(ci.size)
     x_true = np.random.default_rng(5).uniform(-1, 1, n)          # b = A x_true: the reference harness (test_utils.hpp:61-70)
@@ -1195,7 +1205,9 @@ def run_solver(cx):
             return sh.bicg(sht, bl, maxiters=maxiters, tol=tol)
         return sh.cg(bl, maxiters=maxiters, tol=tol)
 
+    cx.phase(f"{name} --solver {kind}: generate + sharded operators", t_all)
     # ---- the real solve, checked against the oracle ---------------------------------
+    t_chk = time.perf_counter()
     xs, it, conv = solve(2000, 1e-5)
     torch.cuda.synchronize()
     x_all = xs.cpu().numpy()
@@ -1210,11 +1222,14 @@ def run_solver(cx):
         want_x, want_it, want_conv = (oracle.cg_full if kind == "cg" else oracle.bicg)(rp, ci, va, b)
         check = {"iterations": it, "converged": conv, "oracle_iterations": want_it, "oracle_converged": want_conv,
                  "residual_2norm_by_oracle_product": res, "max_abs_diff_vs_oracle_solution": float(np.abs(x_all - want_x).max())}
+    cx.phase(f"{name} --solver {kind}: the real solve + oracle check (rank 0)", t_chk)
     # ---- warm-up + timed region: exactly K passes (tol = 0 never converges) -----------
+    t_timed = time.perf_counter()
     if args.warmup:
         solve(args.warmup, 0.0)
     tw = timed_windows(cx, lambda: solve(args.steps, 0.0), windows=n_windows(args))
     dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
+    cx.phase(f"{name} --solver {kind}: warm-up + {tw['windows']} timed solves of {args.steps} passes", t_timed)
     rec = None
     if rank == 0:
         step_us = dev_ms * 1e3 / args.steps
