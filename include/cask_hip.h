@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 5   /* 5: cask_hip_spmv_windows_device, run-encoded slots (index16 = 3); 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
+#define CASK_HIP_ABI_VERSION 5   /* 5: cask_hip_spmv_windows_device, run records (index16 = 3 / 4); 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
 
 /* status codes */
 #define CASK_HIP_OK               0
@@ -65,7 +65,12 @@ typedef struct cask_hip_params {
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
   int32_t index16;          /* MERGE with an x tile: 1 = stream tile-relative slot indices instead of 32-bit columns
                              * (12 bits each, packed per thread, where the kernel has that layout; else 16 bits),
-                             * 2 = 16-bit slots only, -1 = off */
+                             * 2 = 16-bit slots only, -1 = off; r4: 3 = 12-bit and never run records, 4 = RUN RECORDS where
+                             * they can be built (per 128 elements a run-start mask + an int16 delta per run of consecutive
+                             * slots: FEM matrices with several unknowns per node; opt-in, a measured loss -- DESIGN.md 13).
+                             * cask_hip_csr_get_params reports what the plan streams: 1 = 12-bit, 2 = 16-bit, 4 = runs.
+                             * The reference's own stream compaction is the RLE of empty-row runs,
+                             * src/runtime/Spmv.hpp:213-250 */
   int32_t far_columns;      /* MERGE with slot indices: nonzeros whose columns lie outside a block's tile ("far") are
                              * served from a side buffer that a pre-gather launch fills column panel by column panel
                              * (one panel of x per XCD's L2) -- the reference's column blocking (SparseMatrix.hpp:459-482)
