@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cant", choices=["cant", "cant3", "G3_circuit", "webbase-1M", "webbase2", "atmosmodd"])
     ap.add_argument("--solver", default=None, choices=["cg", "bicg"], help="time solver passes instead of products")
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager", "windowgraph"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "sequence", "eager"],
                     help="graph: the K steps as one HIP graph; sequence: K launches from one C call (no graph start-up "
                          "inside a short timed region); eager: per-step calls; auto: sequence below 200 steps, else graph")
     ap.add_argument("--windows", type=int, default=0,
@@ -605,55 +605,6 @@ def timed_windows(cx, run_steps, lead_in=None, windows=31, native=None):
     return out
 
 
-def timed_window_graph(cx, step, steps, windows):
-    """All R windows as ONE HIP graph: R x K kernel nodes with an event-record node at every window boundary (external
-    events), replayed once untimed and once timed between the brackets.  Graph nodes are the cheapest launches the
-    runtime has (no per-launch host work, no graph start inside a window)."""
-    import torch
-    import torch.distributed as dist
-    ev = [torch.cuda.Event(enable_timing=True, external=True) for _ in range(windows + 1)]
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for i in range(3):
-            step(i)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        ev[0].record()
-        for r in range(windows):
-            for i in range(steps):
-                step(r * steps + i)
-            ev[r + 1].record()
-    g.replay()
-    torch.cuda.synchronize()
-    for _ in range(2):                                          # ~40 ms of load in front of the timed replay
-        g.replay()
-    cx.host_barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    g.replay()
-    g.replay()                                                  # the events keep the LAST replay's times
-    clocks_busy = gpu_clocks(cx.dev.index or 0)
-    cx.host_barrier()
-    wall = (time.perf_counter() - t0) / 2
-    ms = [ev[r].elapsed_time(ev[r + 1]) for r in range(windows)]
-    total = ev[0].elapsed_time(ev[windows])
-    srt = sorted(ms)
-    q = lambda f: srt[min(windows - 1, max(0, int(round(f * (windows - 1)))))]   # noqa: E731
-    med = float(np.median(ms))
-    out = {"windows": windows, "ms": ms, "median": med, "min": srt[0], "p10": q(0.10), "p90": q(0.90), "max": srt[-1],
-           "mean": total / windows, "first": ms[0], "host_submit_s": 0.0, "clocks_during": clocks_busy}
-    if cx.use_dist:
-        out["dev_ms"] = cx.all_reduce_scalar(med, dist.ReduceOp.MAX)
-        out["mean_max"] = cx.all_reduce_scalar(out["mean"], dist.ReduceOp.MAX)
-        out["wall"] = cx.all_reduce_scalar(wall, dist.ReduceOp.MAX) * windows
-    else:
-        out["dev_ms"], out["mean_max"], out["wall"] = med, out["mean"], wall * windows
-    return out
-
-
 def window_fields(tw, steps):
     """The spread of the timed windows for the JSON line (ms per step, like ms_per_step)."""
     k = max(steps, 1)
@@ -935,8 +886,6 @@ def run_spmv(cx, weak):
     torch.cuda.synchronize()
 
     launch_mode = args.launch if exchange not in ("all_gather", "push") else "eager"
-    if args.launch == "windowgraph" and exchange in ("all_gather", "push"):
-        launch_mode = "eager"
     if exchange == "push" and args.launch in ("auto", "graph") and args.steps % 2 == 0:
         # the push exchange is plain kernel launches: capturable.  Its two gathered vectors alternate per exchange and
         # the product's operand pointer is frozen into the graph, so a replay must return to the parity it started
@@ -1010,14 +959,13 @@ def run_spmv(cx, weak):
         for _ in range(preroll):
             run_steps()
     clocks_before = gpu_clocks(dev.index or 0)                  # the pre-roll is still running: clocks under load
-    if launch_mode == "windowgraph":
-        tw = timed_window_graph(cx, step, args.steps, n_windows(args))
-    else:
-        native_windows = None
-        if sequence and not os.environ.get("CASK_BENCH_TORCH_EVENTS"):
-            native_windows = lambda r: capi.spmv_windows_device(mats, x_in, y, args.steps, r)   # noqa: E731
-        tw = timed_windows(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None),
-                           windows=n_windows(args), native=native_windows)
+    # (one graph holding ALL windows with event-record nodes between them would time graph-node launches per window:
+    # torch on ROCm refuses external events during capture -- DESIGN.md 13)
+    native_windows = None
+    if sequence and not os.environ.get("CASK_BENCH_TORCH_EVENTS"):
+        native_windows = lambda r: capi.spmv_windows_device(mats, x_in, y, args.steps, r)   # noqa: E731
+    tw = timed_windows(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None),
+                       windows=n_windows(args), native=native_windows)
     clocks_after = gpu_clocks(dev.index or 0)
     dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
     clock = (f"MEDIAN of {tw['windows']} back-to-back windows of K = {args.steps} steps, each between two HIP events on the "
