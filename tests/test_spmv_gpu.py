@@ -354,25 +354,24 @@ def test_tune_measures_the_lane_count_nearest_the_row_length_first():
 
 
 def test_tune_keeps_a_family_that_is_within_reach():
-    """A test_dense_128-like fixture scaled up (2048 rows of 128 consecutive nonzeros, 3 MB: timed warm): the row-mapped
-    family is within 1.5x of the merge kernels there, so none of its points may be dropped."""
-    n, k = 2048, 128
-    rp = np.arange(n + 1, dtype=np.int32) * k
-    start = np.minimum(np.arange(n), n - k)
-    ci = (start[:, None] + np.arange(k)[None, :]).astype(np.int32).ravel()
-    va = np.random.default_rng(11).standard_normal(n * k)
+    """A family whose best guesses are within 1.5x of the incumbent keeps ALL its points: the row-mapped family against
+    the persistent-wave merge kernel alone (cant-like: 13.4 vs 12.1 us at full size) -- neither may lose a point.
+    (On this chip the row-mapped family is never within 1.5x of the workgroup-level merge kernel: a scaled-up
+    test_dense_128 -- 2048 rows of 128 consecutive nonzeros, timed warm -- measures 3.7 against 2.4 us.)"""
+    n, rp, ci, va = synth.small("cant", factor=4)
     x = mmio.test_vector(n)
     m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
-    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE], lanes=[4, 8, 16, 32], tiles=[-1, 1024],
-                       wg_sizes=[256], items=[8])
-    vec = [p for p in pts if p["params"]["variant"] == "vector"]
+    pts, best = m.tune(variants=[capi.VARIANT_VECTOR, capi.VARIANT_MERGE_WAVE], lanes=[4, 8, 16, 32], tiles=[-1, 1024],
+                       wg_sizes=[256], items=[4, 8])
     top = min(p["usec"] for p in pts if p["valid"])
-    vbest = min(p["usec"] for p in vec if p["valid"])
-    if vbest <= 1.5 * top:
-        assert all(p["valid"] and p["usec"] > 0 for p in vec), [(p["params"]["lanes_per_row"], p["usec"]) for p in vec]
-    else:                                                        # (not expected; keep the evidence in the failure message)
-        raise AssertionError(f"row-mapped family {vbest:.2f} us against {top:.2f}: not the fixture this test wants")
-    oracle.assert_almost_equal(m.spmv(x), oracle.csr_spmv(rp, ci, va, x), what="after tune, dense-128-like")
+    for fam in ("vector", "merge_wave"):
+        mine = [p for p in pts if p["params"]["variant"] == fam]
+        two_best = sorted(p["usec"] for p in mine if p["valid"])[:2]
+        if min(two_best) <= 1.5 * top:
+            assert all(p["valid"] and p["usec"] > 0 for p in mine), (fam, [(p["params"]["lanes_per_row"], p["usec"]) for p in mine])
+    fams = {p["params"]["variant"] for p in pts if p["valid"]}
+    assert fams == {"vector", "merge_wave"}
+    oracle.assert_almost_equal(m.spmv(x), oracle.csr_spmv(rp, ci, va, x), what="after tune")
     m.close()
 
 
