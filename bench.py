@@ -958,6 +958,19 @@ def run_spmv(cx, weak):
         preroll = int(min(2000, max(2, 40.0 / max(e0.elapsed_time(e1), 1e-3))))
         for _ in range(preroll):
             run_steps()
+    # windows: what the arguments ask for, bounded to ~4 s of timed work -- agreed over the ranks from one probe of K steps
+    # (an exchange that is host-staged in a dry run, or slow on first contact with a fabric, must not eat the run)
+    cx.host_barrier()
+    t_probe = time.perf_counter()
+    run_steps()
+    cx.host_barrier()
+    t_probe = time.perf_counter() - t_probe
+    if use_dist:
+        t_probe = cx.all_reduce_scalar(t_probe, dist.ReduceOp.MAX)
+    n_win = max(3, min(n_windows(args), int(4.0 / max(t_probe, 1e-6))))
+    if graph is not None or sequence:                           # the probe drained the stream: a short pre-roll again
+        for _ in range(min(preroll, 50)):
+            run_steps()
     clocks_before = gpu_clocks(dev.index or 0)                  # the pre-roll is still running: clocks under load
     # (one graph holding ALL windows with event-record nodes between them would time graph-node launches per window:
     # torch on ROCm refuses external events during capture -- DESIGN.md 13)
@@ -965,7 +978,7 @@ def run_spmv(cx, weak):
     if sequence and not os.environ.get("CASK_BENCH_TORCH_EVENTS"):
         native_windows = lambda r: capi.spmv_windows_device(mats, x_in, y, args.steps, r)   # noqa: E731
     tw = timed_windows(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None),
-                       windows=n_windows(args), native=native_windows)
+                       windows=n_win, native=native_windows)
     clocks_after = gpu_clocks(dev.index or 0)
     dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
     clock = (f"MEDIAN of {tw['windows']} back-to-back windows of K = {args.steps} steps, each between two HIP events on the "
@@ -1175,7 +1188,16 @@ def run_solver(cx):
     t_timed = time.perf_counter()
     if args.warmup:
         solve(args.warmup, 0.0)
-    tw = timed_windows(cx, lambda: solve(args.steps, 0.0), windows=n_windows(args))
+    # windows: as many as the arguments ask for, but no more than fit ~4 s of solves -- agreed over the ranks from one
+    # probe solve (a dry run whose all-reduces are host-staged takes milliseconds per pass; so might a first contact with
+    # a slow fabric); never fewer than 3
+    cx.host_barrier()
+    t_probe = time.perf_counter()
+    solve(args.steps, 0.0)
+    cx.host_barrier()
+    t_probe = cx.all_reduce_scalar(time.perf_counter() - t_probe, dist.ReduceOp.MAX) if use_dist else time.perf_counter() - t_probe
+    windows = max(3, min(n_windows(args), int(4.0 / max(t_probe, 1e-6))))
+    tw = timed_windows(cx, lambda: solve(args.steps, 0.0), windows=windows)
     dev_ms, wall = tw["dev_ms"], tw["wall"] / tw["windows"]
     cx.phase(f"{name} --solver {kind}: warm-up + {tw['windows']} timed solves of {args.steps} passes", t_timed)
     rec = None
