@@ -349,7 +349,11 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   // by a slot the block owns -- into record lb*WG + tid: one 12-byte load instead of four 4-byte ones, 1.5
   // instead of 2 bytes per nonzero
   if (C12) {
+#if defined(CASK_ABL) && (CASK_ABL & 16)                      // diagnostic build: what would a FREE slot stream buy? (every block reads block 0's records)
+    const unsigned *rec = ci16 + (size_t)tid * 3;
+#else
     const unsigned *rec = ci16 + ((size_t)lb * WG + tid) * 3;  // (a 3-vector type would be padded to 16 bytes)
+#endif
     c12[0] = stream_load<NT>(rec);
     c12[1] = stream_load<NT>(rec + 1);
     c12[2] = stream_load<NT>(rec + 2);
@@ -377,6 +381,8 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   for (int u = 0; u < IPT / 2; u++) {
 #if defined(CASK_ABL) && (CASK_ABL & 8)                       // diagnostic build: what do thread-consecutive (64-byte strided) stream loads cost?
     const int p = min(first + (IPT / 2) * tid + u, last);
+#elif defined(CASK_ABL) && (CASK_ABL & 32)                    // diagnostic build: FREE values (every block streams block 0's: L2 hits) -- is the launch HBM-bound at all?
+    const int p = min(u * WG + tid, last);
 #else
     const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
 #endif
