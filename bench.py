@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of K steps each, back to back behind one pre-roll; ms_per_step is the MEDIAN window "
                          "/ K (0 = auto: at least 31, more while K*windows < 2000 steps, at most 101)")
+    ap.add_argument("--preroll-ms", type=float, default=300.0,
+                    help="sustained untimed load in front of the timed windows (the step time settles ~150 ms after the GPU "
+                         "leaves idle, the shader clock ~500 ms: tools/drift_probe.py)")
     ap.add_argument("--no-tune", action="store_true", help="skip the measured DSE, use the AUTO design point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -911,16 +914,17 @@ def run_spmv(cx, weak):
                     step(i)
             graph.replay()                                  # one untimed replay (graph upload)
             torch.cuda.synchronize()
-            # The GPU leaves its idle power state only after ~10 ms of sustained load (tools/replay_series.py:
-            # the first replays after a host-side pause run 3-4 % slower than the following ones), and the
-            # capture above is such a pause.  Pre-roll ~40 ms of untimed replays so the K timed steps run at
-            # the steady-state clock a solver loop sees.
+            # The GPU leaves its idle power state only under sustained load, and the capture above is a pause.  Round 4
+            # (tools/drift_probe.py, profiles/r04_drift.txt): under back-to-back load the step time of this kernel is
+            # constant to 0.1 % -- after the first ~150 ms, which run 1.5-2 % slower (the shader clock climbs for
+            # ~500 ms); rounds 1-3 pre-rolled 40 ms.  Pre-roll --preroll-ms (300) of untimed replays so that the timed
+            # windows run at the steady state a solver loop sees.
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             graph.replay()
             e1.record()
             torch.cuda.synchronize()
-            preroll = int(min(200, max(2, 40.0 / max(e0.elapsed_time(e1), 1e-3))))
+            preroll = int(min(5000, max(2, args.preroll_ms / max(e0.elapsed_time(e1), 1e-3))))
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph, launch_mode = None, "eager"
@@ -934,11 +938,7 @@ def run_spmv(cx, weak):
         if launch_mode == "eager":
             graph = None
 
-    # ---- timed region: exactly K steps -------------------------------------------
-    if graph is not None:
-        for _ in range(preroll):
-            graph.replay()
-
+    # ---- timed region: windows of exactly K steps ---------------------------------
     sequence = launch_mode == "sequence" and exchange in ("none", "p2p_fused")     # a step is exactly one launch
 
     def run_steps():
@@ -949,15 +949,6 @@ def run_spmv(cx, weak):
         else:
             for i in range(args.steps):
                 step(i)
-    if sequence:                                                # the same ~40 ms of sustained load in front of the region
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        run_steps()
-        e1.record()
-        torch.cuda.synchronize()
-        preroll = int(min(2000, max(2, 40.0 / max(e0.elapsed_time(e1), 1e-3))))
-        for _ in range(preroll):
-            run_steps()
     # windows: what the arguments ask for, bounded to ~4 s of timed work -- agreed over the ranks from one probe of K steps
     # (an exchange that is host-staged in a dry run, or slow on first contact with a fabric, must not eat the run)
     cx.host_barrier()
@@ -968,15 +959,34 @@ def run_spmv(cx, weak):
     if use_dist:
         t_probe = cx.all_reduce_scalar(t_probe, dist.ReduceOp.MAX)
     n_win = max(3, min(n_windows(args), int(4.0 / max(t_probe, 1e-6))))
-    if graph is not None or sequence:                           # the probe drained the stream: a short pre-roll again
-        for _ in range(min(preroll, 50)):
+    if sequence:                                                # the same sustained load in front of the region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run_steps()
+        e1.record()
+        torch.cuda.synchronize()
+        preroll = int(min(20000, max(2, args.preroll_ms / max(e0.elapsed_time(e1), 1e-3))))
+    if graph is not None or sequence:
+        for _ in range(preroll):
             run_steps()
     clocks_before = gpu_clocks(dev.index or 0)                  # the pre-roll is still running: clocks under load
-    # (one graph holding ALL windows with event-record nodes between them would time graph-node launches per window:
-    # torch on ROCm refuses external events during capture -- DESIGN.md 13)
     native_windows = None
+    window_form = {"form": None, "note": None}
     if sequence and not os.environ.get("CASK_BENCH_TORCH_EVENTS"):
-        native_windows = lambda r: capi.spmv_windows_device(mats, x_in, y, args.steps, r)   # noqa: E731
+        def native_windows(r):
+            # stream launches + one event per window (the default); CASK_BENCH_WINDOW_FORM=graph: the K launches of every
+            # window as kernel nodes of ONE graph with event-record nodes at the window boundaries (cask_hip_spmv_windows_device,
+            # as_graph: native HIP -- torch refuses external events in a capture on ROCm).  Interleaved on one box the two
+            # forms are level within the run-to-run noise (profiles/r04_launch_forms.txt).
+            if os.environ.get("CASK_BENCH_WINDOW_FORM", "stream") == "graph":
+                try:
+                    u = capi.spmv_windows_device(mats, x_in, y, args.steps, r, as_graph=True)
+                    window_form["form"] = "graph nodes + event-record nodes (one graph, launched twice: lead-in + timed)"
+                    return u
+                except capi.CaskHipError as e:
+                    window_form["note"] = repr(e)
+            window_form["form"] = "stream launches + events"
+            return capi.spmv_windows_device(mats, x_in, y, args.steps, r, as_graph=False)
     tw = timed_windows(cx, run_steps, lead_in=graph.replay if graph is not None else (run_steps if sequence else None),
                        windows=n_win, native=native_windows)
     clocks_after = gpu_clocks(dev.index or 0)
@@ -1054,7 +1064,8 @@ def run_spmv(cx, weak):
                        "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
                        "exchange_selfcheck": selfchecks or None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
-                       "matrix_copies_rotated": copies, "launch": launch_mode, "untimed_preroll_replays": preroll, "design_point": design,
+                       "matrix_copies_rotated": copies, "launch": launch_mode, "window_form": window_form["form"],
+                       "window_form_note": window_form["note"], "untimed_preroll_replays": preroll, "design_point": design,
                        "grid": info.grid, "lds_bytes": info.lds_bytes, "tune": tune_info,
                        "upload_seconds": round(upload_seconds, 4), "plan_seconds": round(plan_seconds, 4),
                        "generate_seconds": round(gen_seconds, 2)},

@@ -134,7 +134,7 @@ def load() -> ctypes.CDLL:
     if hasattr(L, "cask_hip_spmv_sequence_device"):
         L.cask_hip_spmv_sequence_device.argtypes = [vp, i32, vp, vp, i32, vp]
     if hasattr(L, "cask_hip_spmv_windows_device"):
-        L.cask_hip_spmv_windows_device.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
+        L.cask_hip_spmv_windows_device.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp]
     if hasattr(L, "cask_hip_solve_device"):
         L.cask_hip_solve_device.argtypes = [vp, vp, POINTER(SolverConfig), vp, vp, i32, dbl, POINTER(i32), POINTER(i32),
                                             POINTER(dbl), vp]
@@ -509,13 +509,15 @@ def spmv_sequence_device(mats, x_t, y_t, k, stream=None):
                                                 int(k), c_void_p(_stream_ptr(stream))))
 
 
-def spmv_windows_device(mats, x_t, y_t, k, windows, stream=None):
+def spmv_windows_device(mats, x_t, y_t, k, windows, as_graph=False, stream=None):
     """`windows` timed windows of k products each from one call (cask_hip_spmv_windows_device); returns after the last
-    one has completed with the device microseconds of every window."""
+    one has completed with the device microseconds of every window.  ``as_graph``: the launches are the kernel nodes of
+    one graph with event-record nodes at the window boundaries (raises CaskHipError where the runtime cannot do that)."""
     arr = (c_void_p * len(mats))(*[m._h for m in mats])
     usec = np.zeros(int(windows), dtype=np.float64)
     _check(load().cask_hip_spmv_windows_device(arr, len(mats), c_void_p(x_t.data_ptr()), c_void_p(y_t.data_ptr()),
-                                               int(k), int(windows), _p(usec), c_void_p(_stream_ptr(stream))))
+                                               int(k), int(windows), int(bool(as_graph)), _p(usec),
+                                               c_void_p(_stream_ptr(stream))))
     return usec
 
 

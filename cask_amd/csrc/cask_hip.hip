@@ -1599,7 +1599,7 @@ int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, 
 }
 
 int cask_hip_spmv_windows_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
-                                 int32_t k, int32_t windows, double *usec, void *stream) {
+                                 int32_t k, int32_t windows, int32_t as_graph, double *usec, void *stream) {
   if (!mats || n_mats <= 0 || k <= 0 || windows <= 0 || !usec) return fail(CASK_HIP_ERR_INVALID, "bad argument");
   for (int i = 0; i < n_mats; i++) {
     if (!mats[i]) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
@@ -1616,19 +1616,74 @@ int cask_hip_spmv_windows_device(cask_hip_matrix *const *mats, int32_t n_mats, c
   evs.e.reserve((size_t)windows + 1);
   for (int r = 0; r <= windows; r++) {
     hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&ev, as_graph ? hipEventDefault : hipEventDisableSystemFence));
     evs.e.push_back(ev);
   }
-  HIP_TRY(hipEventRecord(evs.e[0], s));
-  int64_t i = 0;
-  for (int r = 0; r < windows; r++) {
-    for (int j = 0; j < k; j++, i++) {
-      int rc = launch_spmv(*mats[i % n_mats], d_x, d_y, s);
-      if (rc) return rc;
+  if (as_graph) {
+    // ONE graph: windows x k kernel nodes with an event-record node at every window boundary (hipEventRecordWithFlags
+    // ..External inside a stream capture).  Graph nodes are the cheapest launches the runtime has (a stream launch
+    // measures 0.14 us more per product, and a graph START ~9 us -- so no graph per window); the event nodes make the
+    // windows visible inside it.  Launched twice: the events keep the second launch's times, the first is the lead-in.
+    struct Capture {
+      hipStream_t cs = nullptr;
+      hipGraph_t g = nullptr;
+      hipGraphExec_t x = nullptr;
+      ~Capture() {
+        if (x) (void)hipGraphExecDestroy(x);
+        if (g) (void)hipGraphDestroy(g);
+        if (cs) (void)hipStreamDestroy(cs);
+      }
+    } cap;
+    // ONE capture; at every window boundary an event-record node is added to the graph being captured, behind the
+    // capture's current dependency set (hipStreamGetCaptureInfo_v2 + hipGraphAddEventRecordNode), and made the new
+    // dependency set (hipStreamUpdateCaptureDependencies) so that the next window's first kernel node follows it.
+    // (hipEventRecordWithFlags(.., hipEventRecordExternal) inside a capture returns "invalid argument" on ROCm 7.2 --
+    // which is why torch refuses external events there; a child graph per window works but costs ~2.6 us per window.)
+    HIP_TRY(hipStreamCreateWithFlags(&cap.cs, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(cap.cs, hipStreamCaptureModeThreadLocal));
+    int rc = CASK_HIP_OK;
+    hipError_t ge = hipSuccess;
+    auto record_node = [&](hipEvent_t ev) -> hipError_t {
+      hipStreamCaptureStatus st;
+      hipGraph_t g = nullptr;
+      const hipGraphNode_t *deps = nullptr;
+      size_t n_deps = 0;
+      hipError_t e = hipStreamGetCaptureInfo_v2(cap.cs, &st, nullptr, &g, &deps, &n_deps);
+      if (e != hipSuccess) return e;
+      hipGraphNode_t node = nullptr;
+      e = hipGraphAddEventRecordNode(&node, g, deps, n_deps, ev);
+      if (e != hipSuccess) return e;
+      return hipStreamUpdateCaptureDependencies(cap.cs, &node, 1, hipStreamSetCaptureDependencies);
+    };
+    ge = record_node(evs.e[0]);
+    int64_t i = 0;
+    for (int r = 0; r < windows && ge == hipSuccess && rc == CASK_HIP_OK; r++) {
+      for (int j = 0; j < k && rc == CASK_HIP_OK; j++, i++) rc = launch_spmv(*mats[i % n_mats], d_x, d_y, cap.cs);
+      if (rc == CASK_HIP_OK) ge = record_node(evs.e[(size_t)r + 1]);
     }
-    HIP_TRY(hipEventRecord(evs.e[(size_t)r + 1], s));
+    hipError_t ee = hipStreamEndCapture(cap.cs, &cap.g);      // always ended, whatever happened inside
+    if (rc) return rc;
+    if (ge != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(CASK_HIP_ERR_RUNTIME, std::string("event-record node inside a capture: ") + hipGetErrorString(ge));
+    }
+    HIP_TRY(ee);
+    HIP_TRY(hipGraphInstantiate(&cap.x, cap.g, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(cap.x, s));
+    HIP_TRY(hipGraphLaunch(cap.x, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    HIP_TRY(hipEventRecord(evs.e[0], s));
+    int64_t i = 0;
+    for (int r = 0; r < windows; r++) {
+      for (int j = 0; j < k; j++, i++) {
+        int rc = launch_spmv(*mats[i % n_mats], d_x, d_y, s);
+        if (rc) return rc;
+      }
+      HIP_TRY(hipEventRecord(evs.e[(size_t)r + 1], s));
+    }
+    HIP_TRY(hipEventSynchronize(evs.e[(size_t)windows]));
   }
-  HIP_TRY(hipEventSynchronize(evs.e[(size_t)windows]));
   for (int r = 0; r < windows; r++) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, evs.e[(size_t)r], evs.e[(size_t)r + 1]));

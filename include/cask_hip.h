@@ -178,11 +178,15 @@ int cask_hip_spmv_sequence_device(cask_hip_matrix *const *mats, int32_t n_mats, 
  * events (created with hipEventDisableSystemFence: a timing event needs no system-scope fence, and that fence
  * costs ~4 us per record between dependent launches), event r -> event r + 1 brackets exactly the k launches of
  * window r; product i of the whole call is y = A_(i mod n_mats) x.  Returns after the last event has completed
- * with usec[r] = the device time of window r in microseconds.  Replaces the reference's timed loop
+ * with usec[r] = the device time of window r in microseconds.  as_graph = 1: the windows x k launches are the
+ * kernel nodes of ONE graph with an event-record node at every window boundary (captured once, launched twice: the
+ * first launch is the lead-in, the events keep the second's times) -- graph nodes are the cheapest launches the
+ * runtime has; fails with CASK_HIP_ERR_RUNTIME where the runtime cannot record an external event inside a capture
+ * (the caller falls back to as_graph = 0: stream launches).  Replaces the reference's timed loop
  * (src/runtime/Spmv.cpp:265-301: impl.Spmv x nIterations between two clock reads, divided by nIterations) with a
  * distribution instead of one sample. */
 int cask_hip_spmv_windows_device(cask_hip_matrix *const *mats, int32_t n_mats, const double *d_x, double *d_y,
-                                 int32_t k, int32_t windows, double *usec, void *stream);
+                                 int32_t k, int32_t windows, int32_t as_graph, double *usec, void *stream);
 
 /* y = A x and *d_result = w . y in one pass (device vectors, asynchronous on `stream`): with a
  * MERGE design point every workgroup leaves its rows' share of the dot behind and a one-workgroup
