@@ -561,6 +561,30 @@ def test_sequence_of_products_from_one_call():
         m.close()
 
 
+@pytest.mark.parametrize("as_graph", [False, True], ids=["stream", "one-graph"])
+def test_timed_windows_from_one_call(as_graph):
+    """cask_hip_spmv_windows_device (r4): `windows` back-to-back groups of k products, each between two timing events --
+    as stream launches, or as the kernel nodes of ONE graph with event-record nodes at the window boundaries; returns
+    every window's microseconds after the last has completed.  The last product's y is handle (windows*k - 1) % 3's."""
+    import torch
+    n, rp, ci, va = synth.small("cant", factor=32)
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    mats = [capi.CsrMatrix.from_host(n, n, rp, ci, va * s) for s in (1.0, 2.0, 3.0)]
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    base = oracle.csr_spmv(rp, ci, va, x)
+    us = capi.spmv_windows_device(mats, xt, yt, 5, 7, as_graph=as_graph)           # 35 products: the last uses handle 34 % 3 = 1
+    assert us.shape == (7,) and np.all(us > 0) and np.all(us < 1e5)
+    oracle.assert_almost_equal(yt.cpu().numpy(), 2.0 * base, what="windows: the last product")
+    assert us.max() < 20 * us.min()                              # windows of equal work
+    with pytest.raises(ValueError):
+        capi.spmv_windows_device(mats, xt, yt, 0, 3, as_graph=as_graph)
+    capi.spmv_windows_device(mats, xt, yt, 2, 2, as_graph=False)                    # the handle and the stream stay usable
+    torch.cuda.synchronize()
+    for m in mats:
+        m.close()
+
+
 def test_scan_kernel_rows_that_span_threads_waves_and_holes():
     """The segmented-scan kernel (variant SCAN) where its carries matter: rows that span many threads and several
     waves, rows that end exactly on a thread's / a wave's last product, 1-nonzero rows, empty rows between them
