@@ -966,9 +966,10 @@ def run_spmv(cx, weak):
         e1.record()
         torch.cuda.synchronize()
         preroll = int(min(20000, max(2, args.preroll_ms / max(e0.elapsed_time(e1), 1e-3))))
-    if graph is not None or sequence:
-        for _ in range(preroll):
-            run_steps()
+    elif graph is None:                                         # eager steps (collectives at N > 1): the same count on every
+        preroll = int(min(500, max(1, args.preroll_ms * 1e-3 / max(t_probe, 1e-6))))   # rank -- t_probe is the ranks' maximum
+    for _ in range(preroll):
+        run_steps()
     clocks_before = gpu_clocks(dev.index or 0)                  # the pre-roll is still running: clocks under load
     native_windows = None
     window_form = {"form": None, "note": None}

@@ -168,8 +168,11 @@ class ShardedSpmv:
                     refs = None
                     if selfcheck and share_with is None:
                         # reference products from a PRIVATE operand built from the formula, by the plain kernel,
-                        # before the halo sources exist
+                        # before the halo sources exist -- by the MERGE kernel, which is what runs with them (an AUTO handle
+                        # may have resolved to another family, whose sums are not bit-identical to MERGE's)
                         from . import selfcheck as sc
+                        if mat.params.as_dict()["variant"] != "merge":
+                            mat.set_params(capi.make_params(variant="merge"))
                         idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
                         idx_halo = torch.from_numpy(halo_cols).to(dev)
                         refs = []
