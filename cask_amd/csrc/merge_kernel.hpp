@@ -603,6 +603,9 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, const int2v rdes
     merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                              halo, wsrc, wl, lb, sp, ps, farx, far_col);
   const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
+#if defined(CASK_ABL) && (CASK_ABL & 64)                      // diagnostic build: what does the tail (row sums + y) cost?
+  if (!EXT) { if (tid == 0 && prod[0] == 1.2345e300) y[d.row_start] = 0.0; return; }
+#endif
 
   double dsum;
   switch (d.kind_g & 0xff) {
@@ -652,7 +655,13 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
 
   CASK_STAMP(0);
   const int lb = logical_block(blockIdx.x, n_blocks, remap);
+#if defined(CASK_ABL) && (CASK_ABL & 128)                     // diagnostic build: what does the descriptor round trip cost? (a made-up block of the
+  BlockDesc d;                                                // cant-like shape computed from lb alone; results wrong by design)
+  d.row_start = min(lb * 31, 62451 - 31); d.n_rows = 31; d.nnz_start = min(lb * 1984, nnz - 1984) & ~1; d.nnz_count = 1984;
+  d.cmin = max(0, d.row_start - 420) & ~1; d.cwidth = 1024; d.kind_g = 8 | KIND_CONTIG; d.aux = 0;
+#else
   const BlockDesc d = blocks[lb];
+#endif
   int2v rdesc = {0, 0};
   if (CRUN) rdesc = run_desc[lb];                             // where the block's run records start, how long they are
   const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
