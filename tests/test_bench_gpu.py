@@ -34,6 +34,8 @@ def run_bench(extra, env=None, world=1, timeout=900, launcher=True):
     if "--solver" not in extra and "--workload" not in extra and "--with-others" not in extra:
         extra = extra + ["--no-others"]                     # the appended workloads have their own test below
     extra = [e for e in extra if e != "--with-others"]
+    if "--preroll-ms" not in extra:
+        extra = extra + ["--preroll-ms", "40"]              # (the 300 ms default is for measurements, not for these checks)
     if world > 1 and launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                 "--master-port", str(free_port())]
@@ -217,7 +219,7 @@ def test_two_rank_line_appends_the_strong_scaling_configs():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SHARE)
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--copies", "2",
-           "--no-cpu-baseline", "--no-tune", "--other-steps", "20"]
+           "--no-cpu-baseline", "--no-tune", "--other-steps", "20", "--preroll-ms", "40"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = last_json_line(out.stdout)
