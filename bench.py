@@ -359,6 +359,7 @@ def main():
     # CASK_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all_gather, all_reduce) with a single
     # rank: the RCCL path on a 1-GPU box.
     use_dist = world > 1 or bool(os.environ.get("CASK_BENCH_FORCE_DIST"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL and the shared x slices need on this pool
     os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
