@@ -1005,7 +1005,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         // node): OPT-IN, index16 = 4 (whenever they can be built).  They are a measured loss: on the cant3 look-alike
         // the slot stream falls from 1.5 to 0.38 bytes per nonzero (44.0 -> 39.2 MB per launch) and the launch goes
         // from 8.80 to 9.83 us -- the decode (popcounts, two ds_bpermute and selects per pass: ~100 VALU instructions
-        // per thread on top of ~350) costs more issue slots than the bytes buy (profiles/r04_run_records.txt).  AUTO
+        // per wave on top of 155) costs more issue slots than the bytes buy (profiles/r04_run_records.txt).  AUTO
         // (0/1) and 3 never take them.
         pl.runs = false;
         pl.slot_bytes_per_nnz = pl.packed12 ? 1.5 : 2.0;
