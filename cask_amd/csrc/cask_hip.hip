@@ -2634,7 +2634,11 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipSetDevice(m->device));
   {
     cask_hip_mc_view mc{};
-    if (cask_hip_precond_mc_view(precond, &mc) && m->n_rows > 0 && m->nnz >= 2 && !std::getenv("CASK_HIP_PCG_MC_GENERIC"))
+    // (the colour-ordered solve multiplies with the matrix the preconditioner was built from, permuted: only when that
+    // is `m`'s matrix by shape and nonzero count -- a caller who preconditions one matrix with another's factors gets
+    // the generic pass, which multiplies with `m`)
+    if (cask_hip_precond_mc_view(precond, &mc) && m->n_rows > 0 && m->nnz >= 2 && m->n_rows == m->n_cols &&
+        mc.n == m->n_rows && (int64_t)mc.h_rp[mc.n] == m->nnz && !std::getenv("CASK_HIP_PCG_MC_GENERIC"))
       return pcg_multicolour(m, precond, mc, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
   }
   const int64_t n = m->n_rows;
