@@ -339,7 +339,10 @@ int cask_hip_precond_apply_device(cask_hip_precond *p, const double *d_r, double
 int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32_t *col_ind,
                      const double *values, int32_t lower, const double *rhs, double *x);
 /* Preconditioned CG on a full symmetric CSR handle; precond == NULL is cask_hip_cg.  The test is
- * r.z <= tol^2 like the reference's. */
+ * r.z <= tol^2 like the reference's.  With a CASK_HIP_PRECOND_ILU0_MC preconditioner built from the handle's own
+ * matrix the whole solve runs in the preconditioner's colour order (r4: rhs and the initial guess permuted once on the
+ * way in, x once on the way out; the product is the engine's kernel on the permuted matrix): same recurrence, same
+ * stopping rule, the iterates of pcg on the permuted system. */
 int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x,
                  int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
                  double *usec_per_iteration);
