@@ -789,7 +789,8 @@ def run_spmv(cx, weak):
     x_local = None
     if exchange == "p2p":
         x_in = peer.x_ext                                        # [own slice | halo]
-        if not os.environ.get("CASK_BENCH_NO_FUSED_HALO") and peer.n_halo:
+        # (collective below: every rank enters or none -- a rank whose block happens to reference no remote column too)
+        if not os.environ.get("CASK_BENCH_NO_FUSED_HALO") and cx.all_reduce_scalar(peer.n_halo, dist.ReduceOp.MAX) > 0:
             # Fold the exchange into the product kernel: the workgroups at a seam read the halo from the
             # peers' slices themselves (cask_hip_csr_set_halo_sources), a step is ONE launch.  Checked
             # against the pull path first; any rank that disagrees sends every rank back to the pull.
