@@ -85,7 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--strict-exit", action="store_true",
                     help="exit with status 3 (after printing the headline line) when an appended workload failed or hung")
     ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each appended workload")
-    ap.add_argument("--other-seconds", type=float, default=150.0,
+    ap.add_argument("--other-seconds", type=float, default=200.0,
                     help="watchdog for the appended workloads as a whole: past it the headline line is printed without them")
     return ap.parse_args(argv)
 
