@@ -818,7 +818,7 @@ def run_spmv(cx, weak):
             except Exception as e:  # noqa: BLE001
                 fused_ok, p2p_error = False, repr(e)
             del refs
-            fused_ok, why = selfcheck.agree(fused_ok, p2p_error, lambda v: cx.all_reduce_scalar(v, dist.ReduceOp.MIN))
+            fused_ok, why = selfcheck.agree(fused_ok, p2p_error, lambda v: cx.all_reduce_scalar(v, dist.ReduceOp.MIN), gather_objects)
             selfchecks["in_kernel_halo"] = "ok" if fused_ok else f"fell back: {why}"
             peer.x_local.copy_(torch.from_numpy(x_slice).to(dev))    # the benchmark's operand again
             cx.host_barrier()

@@ -192,7 +192,7 @@ class ShardedSpmv:
                         except Exception as e:  # noqa: BLE001 - agreed on below
                             ok, why = False, repr(e)
                         verdicts = gather_objects(None if ok else (why or "mismatch"))
-                        bad = [v for v in verdicts if v]
+                        bad = [f"rank {g}: {v}" for g, v in enumerate(verdicts) if v]
                         ex.x_local.zero_()
                         torch.cuda.synchronize()
                         gather_objects(None)                   # (a control-plane barrier: every slice is zero again)
@@ -242,7 +242,7 @@ class ShardedSpmv:
                         ok, why = sc.check_push_allgather(torch, obj.push, n_local, idx_own, idx_all, valid, n, n=selfcheck)
                     except Exception as e:  # noqa: BLE001 - agreed on below
                         ok, why = False, repr(e)
-                    bad = [v for v in gather_objects(None if ok else (why or "mismatch")) if v]
+                    bad = [f"rank {g}: {v}" for g, v in enumerate(gather_objects(None if ok else (why or "mismatch"))) if v]
                     obj.selfcheck["push_allgather"] = "ok" if not bad else f"fell back: {bad[0]}"
                     if bad:
                         push, obj.push = obj.push, None
@@ -447,7 +447,7 @@ class ShardedSpmv:
             ok, why = sc.check_push_allreduce(self.torch, sp, self.rank, self.world, self.device)
         except Exception as e:  # noqa: BLE001 - agreed on below
             ok, why = False, repr(e)
-        bad = [v for v in gather_objects(None if ok else (why or "mismatch")) if v]
+        bad = [f"rank {g}: {v}" for g, v in enumerate(gather_objects(None if ok else (why or "mismatch"))) if v]
         self._note_selfcheck("peer_store_allreduce", "ok" if not bad else f"fell back: {bad[0]}")
         if bad:
             if self.rank == 0:

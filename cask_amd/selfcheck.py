@@ -38,10 +38,11 @@ def agree(ok: bool, why, all_reduce_min, gather_objects=None):
     if all_ok:
         return True, None
     reason = why or "a peer failed"
-    if gather_objects is not None:
-        reasons = [r for r in gather_objects(None if ok else (why or "mismatch")) if r]
-        if reasons:
-            reason = reasons[0]
+    if gather_objects is not None:                           # every failing rank's reason: a diagnosis, not just a verdict
+        reasons = gather_objects(None if ok else (why or "mismatch"))
+        failing = [f"rank {g}: {r}" for g, r in enumerate(reasons) if r]
+        if failing:
+            reason = "; ".join(failing[:8])
     return False, reason
 
 

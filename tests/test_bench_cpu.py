@@ -160,4 +160,4 @@ def test_selfcheck_formulas_and_fault_injection(monkeypatch):
     assert not ok and "reduction 1" in why
     # the collective verdict: one failing rank sends everybody to the fallback, with its reason
     assert sc.agree(True, None, lambda v: v) == (True, None)
-    assert sc.agree(True, None, lambda v: 0.0, lambda o: [None, "rank 1: stale", None]) == (False, "rank 1: stale")
+    assert sc.agree(True, None, lambda v: 0.0, lambda o: [None, "stale", "late"]) == (False, "rank 1: stale; rank 2: late")

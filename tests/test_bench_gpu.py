@@ -89,13 +89,15 @@ def test_stale_halo_fault_sends_every_rank_to_the_fallback():
     # (a) in-kernel halo -> the halo pull
     rec = run_bench(["--steps", "10", "--warmup", "2", "--no-tune", "--copies", "2", "--no-cpu-baseline"],
                     dict(SHARE, CASK_FAULT_STALE_HALO="halo"), world=2)
-    assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"].startswith("fell back: in-kernel halo:")
+    assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"].startswith("fell back: rank ") and \
+        "in-kernel halo:" in rec["config"]["exchange_selfcheck"]["in_kernel_halo"]          # every failing rank's reason
     assert rec["config"]["exchange"].startswith("per step: pull of"), rec["config"]["exchange"]
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     # (b) push all-gather -> the collective
     args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
     rec = run_bench(args, dict(SHARE, CASK_FAULT_STALE_HALO="push"), world=3)
-    assert rec["config"]["exchange_selfcheck"]["push_allgather"].startswith("fell back: push all-gather:")
+    assert rec["config"]["exchange_selfcheck"]["push_allgather"].startswith("fell back: rank ") and \
+        "push all-gather:" in rec["config"]["exchange_selfcheck"]["push_allgather"]
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)")
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     # (c) sharded solver: in-kernel halos -> all-gathered operands, peer-store all-reduce -> the collective
