@@ -59,7 +59,7 @@ clients: build/test_spmv_hip build/test_precond_hip build/test_bicg_hip build/te
 
 # libcask_hip.so: one object per translation unit so that `make -j` compiles the merge-kernel
 # instantiations (merge_ipt<N>.hip, the slow part) in parallel
-ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p cask_hip_precond cask_hip_rccl scan_launch merge_pair merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
+ENGINESRC  := cask_hip cask_hip_dfe cask_hip_p2p cask_hip_precond cask_hip_rccl scan_launch merge_ipt2 merge_ipt4 merge_ipt8 merge_ipt16
 ENGINEOBJ  := $(ENGINESRC:%=build/obj/%.o)
 ENGINEHDR  := $(wildcard cask_amd/csrc/*.hpp) include/cask_hip.h include/cask_hip_dfe.h include/cask_hip_p2p.h include/cask_hip_rccl.h
 # header dependencies come from the compiler (-MMD): touching scan_kernel.hpp does not recompile the merge kernels

@@ -47,6 +47,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
+EXIT_NOT_DISTINCT = 4             # N > 1 ranks on fewer than N devices and no CASK_BENCH_SHARE_DEVICE: nothing was timed
 EXIT_OTHERS_FAILED = 3            # the headline line was printed, an appended workload failed or hung (never a restart in-process)
 HALO_FRACTION_FOR_ALLGATHER = 0.10   # a block that references more than this share of x gets the all-gather:
 #   per-element remote loads pay a fabric packet per 8 useful bytes, the all-gather moves whole slices (webbase-like
@@ -102,8 +103,10 @@ def load_mkl():
     return None
 
 
-def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
-    """MKL mkl_cspblas_dcsrgemv on pinned threads (primary: the reference's CPU library) and the 1-core oracle."""
+def cpu_baseline(rp, ci, va, x, y_gpu, seconds, quick=False):
+    """MKL mkl_cspblas_dcsrgemv on pinned threads (primary: the reference's CPU library) and the 1-core oracle.
+    `quick` (the appended workloads of the default line: a bounded ~0.5 s each): ONE team size (16 threads, the size the
+    headline's sweep picks on this host class), the full-matrix routine only, a short sample of the 1-core port."""
     import oracle
     n = rp.size - 1
     nnz = int(ci.size)
@@ -111,7 +114,7 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
     bad, _ = oracle.mismatches(y_gpu, y) if y_gpu is not None else (None, None)
     t0 = time.perf_counter()
     calls = 0
-    budget = min(seconds, 5.0)
+    budget = min(seconds, 5.0) if not quick else min(seconds, 0.15)
     while True:
         oracle.csr_spmv(rp, ci, va, x)
         calls += 1
@@ -135,7 +138,7 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
             # (SparseLinearSolvers.hpp:189); both count the full matrix's 2*nnz flops
             routines = {"mkl_cspblas_dcsrgemv": (mkl.mkl_cspblas_dcsrgemv,
                                                  (ctypes.byref(tr), ctypes.byref(nn), p(va), p(rp), p(ci), p(x), p(ym)))}
-            if is_symmetric(rp, ci, va):
+            if not quick and is_symmetric(rp, ci, va):
                 lo = ctypes.c_char(b"l")
                 lrp, lci, lva = lower_triangle_1based(rp, ci, va)
                 ys = np.zeros(n)
@@ -144,6 +147,8 @@ def cpu_baseline(rp, ci, va, x, y_gpu, seconds):
             # the host is shared and a 62 K-row product does not feed 128 threads: time a few team sizes for
             # a slice of the budget each and report the best one (threads pinned: OMP_PROC_BIND/OMP_PLACES below)
             counts = sorted({t for t in (8, 16, 32, 64, 128, 256) if 0 < t <= max_threads} | {min(max_threads, 16)})
+            if quick:
+                counts = [min(max_threads, 16)]
             by_routine, best = {}, None
             for name, (fn, args) in routines.items():
                 by_threads = by_routine.setdefault(name, {})
@@ -244,13 +249,14 @@ def mkl_solver_passes(mkl, kind, rp, ci, va, b, passes, threads, sym=None):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
-    """MKL (the reference's CPU path: pcg on mkl_dcsrsymv + cblas, SparseLinearSolvers.hpp:162-239) on pinned threads,
+def cpu_baseline_solver(kind, rp, ci, va, b, seconds, quick=False):
+    """`quick`: the appended workloads' bounded sample -- 16 pinned threads, the full-matrix product only, no 1-core port.
+    MKL (the reference's CPU path: pcg on mkl_dcsrsymv + cblas, SparseLinearSolvers.hpp:162-239) on pinned threads,
     and the oracle's CG / BiCG (1 core) as the secondary figure; a bounded number of passes each; GFLOP/s on the same
     flop count as `value` (the full matrix's 2*nnz per product, whichever routine ran).  CG is timed with both products
     the reference's CPU code knows -- mkl_dcsrsymv('l') on the stored triangle (what pcg calls) and
     mkl_cspblas_dcsrgemv on the full matrix -- and the faster one is `value`."""
-    port = cpu_baseline_solver_port(kind, rp, ci, va, b, min(seconds, 4.0))
+    port = cpu_baseline_solver_port(kind, rp, ci, va, b, min(seconds, 4.0)) if not quick else None
     mkl = load_mkl()
     if mkl is None:
         return port
@@ -260,15 +266,17 @@ def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
         mkl.MKL_Get_Max_Threads.restype = ctypes.c_int
         max_threads = int(mkl.MKL_Get_Max_Threads())
         routines = {"mkl_cspblas_dcsrgemv": None}
-        if kind == "cg":
+        if kind == "cg" and not quick:
             routines["mkl_dcsrsymv('l')"] = lower_triangle_1based(rp, ci, va)
         counts = sorted({t for t in (8, 16, 32, 64, 128, 256) if t <= max_threads} | {min(16, max_threads)})
+        if quick:
+            counts = [min(16, max_threads)]
         by_routine, best = {}, None
         for name, sym in routines.items():
             by_threads = by_routine.setdefault(name, {})
             for t in counts:
-                mkl_solver_passes(mkl, kind, rp, ci, va, b, 3, t, sym)                # warm-up
-                passes = 20
+                mkl_solver_passes(mkl, kind, rp, ci, va, b, 2 if quick else 3, t, sym)   # warm-up
+                passes = 4 if quick else 20
                 el = mkl_solver_passes(mkl, kind, rp, ci, va, b, passes, t, sym)
                 share = seconds / len(routines)
                 if el < share / 8:
@@ -283,6 +291,7 @@ def cpu_baseline_solver(kind, rp, ci, va, b, seconds):
                 "host_cores": os.cpu_count(), "sample": f"{best[2]} passes with {best[1]} threads in {best[3]:.1f} s",
                 "gflops_by_routine_and_threads": by_routine, "port": port}
     except Exception as e:  # pragma: no cover - diagnostic only
+        port = port or {}
         port["mkl_error"] = repr(e)
         return port
 
@@ -400,6 +409,7 @@ def main():
             dist.barrier()
     cx.all_reduce_scalar, cx.host_barrier = all_reduce_scalar, host_barrier
     t_start = time.perf_counter()
+    cx.rccl = rccl_census(cx, dist, capi, local_rank) if use_dist else None
 
     def phase(name, since):
         """Per-phase wall budget on stderr (rank 0): a multi-GPU run that comes close to the harness's limit says where."""
@@ -442,7 +452,10 @@ def main():
             a = argparse.Namespace(**vars(args))
             a.workload, a.solver = spec["workload"], spec.get("solver")
             a.steps, a.warmup = args.other_steps, max(2, args.other_steps // 10)
-            a.no_cpu_baseline, a.launch, a.copies = True, "auto", 0
+            # the MKL column next to every appended workload too (N = 1): a bounded ~0.5 s sample each,
+            # 16 pinned threads, inside the watchdog's budget
+            a.no_cpu_baseline, a.launch, a.copies = args.no_cpu_baseline or world > 1, "auto", 0
+            a.cpu_seconds, a.cpu_quick = 0.5, True
             a.variant, a.lanes, a.tile, a.items, a.wg, a.far = None, 0, 0, 0, 0, 0
             t0 = time.perf_counter()
             try:
@@ -475,6 +488,74 @@ def main():
         dist.destroy_process_group()
     if failed and others_exit_status(args):
         sys.exit(others_exit_status(args))
+
+
+def rccl_census(cx, dist, capi, local_rank):
+    """What the collectives layer really saw, gathered before anything is timed: the backend, the
+    world size of the process group, ncclCommCount / the device of the ENGINE's own communicator (the one the sharded
+    solvers issue their all-reduces on), and the PCI bus id of every rank's GPU.  A run whose ranks do not sit on
+    `world` distinct devices is refused -- non-zero exit, no timing -- unless CASK_BENCH_SHARE_DEVICE says it is a dry
+    run on a shared device.  The line's config.rccl makes "RCCL saw N ranks on N devices" checkable from the JSON alone."""
+    rank, world = cx.rank, cx.world
+    try:
+        pci = capi.device_pci_bus_id(local_rank)
+    except Exception as e:  # noqa: BLE001
+        pci = f"unknown ({e!r})"
+    mine = {"rank": rank, "local_rank": local_rank, "pci_bus_id": pci, "host": os.uname().nodename}
+    comm = None
+    if cx.backend == "nccl" and not os.environ.get("CASK_NO_NATIVE_RCCL"):
+        uid = [None]
+        if rank == 0:
+            try:
+                uid[0] = capi.NativeComm.unique_id()
+            except Exception as e:  # noqa: BLE001 - agreed on below
+                mine["engine_comm_error"] = repr(e)
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is not None:
+            try:
+                comm = capi.NativeComm(uid[0], rank, world)
+                mine.update(comm.info())
+            except Exception as e:  # noqa: BLE001
+                mine["engine_comm_error"] = repr(e)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if comm is not None:
+        comm.close()
+    devices = [f"{e['host']}:{e['pci_bus_id']}" for e in everyone]
+    counts = sorted({e.get("comm_nranks") for e in everyone if e.get("comm_nranks") is not None})
+    info = {"backend": cx.backend + (" (RCCL)" if cx.backend == "nccl" else ""), "world_size_seen": dist.get_world_size(),
+            "comm_nranks": counts[0] if len(counts) == 1 else (counts or None),
+            "comm_devices": [e.get("device") for e in everyone] if counts else None,
+            "devices": devices, "distinct_devices": len(set(devices)),
+            "shared_device_dry_run": bool(os.environ.get("CASK_BENCH_SHARE_DEVICE")),
+            "errors": [f"rank {e['rank']}: {e['engine_comm_error']}" for e in everyone if e.get("engine_comm_error")] or None}
+    if info["distinct_devices"] < world and not info["shared_device_dry_run"]:
+        if rank == 0:
+            print(f"[bench] {world} ranks on {info['distinct_devices']} distinct devices ({devices}): refusing to time a "
+                  "multi-GPU run that is not one (set CASK_BENCH_SHARE_DEVICE=1 for a dry run on a shared device)",
+                  file=sys.stderr, flush=True)
+        raise SystemExit(EXIT_NOT_DISTINCT)
+    return info
+
+
+def xgmi_fields(exchange, world, step_us, stride=0, halo_by_owner=None):
+    """Bytes a step moves over xGMI per GPU and per link, and the rate that is at the measured step time (SURVEY 8d/8e:
+    the all-gather receives 8 n_cols (G - 1) / G bytes per GPU -- one slice over each of the G - 1 direct links; the
+    in-kernel halo / pull only the referenced entries, from the neighbours that own them)."""
+    if world <= 1 or exchange == "none":
+        return None
+    if exchange in ("all_gather", "push"):
+        per_link = 8 * int(stride)
+        received = per_link * (world - 1)
+        what = f"{exchange}: a slice of {stride} doubles (padded stride) from each of {world - 1} peers, one direct link each"
+    else:
+        by = [int(v) for v in (halo_by_owner or [])]
+        per_link = 8 * max(by) if by else 0
+        received = 8 * sum(by)
+        what = f"{exchange}: {sum(by)} halo entries from {sum(1 for v in by if v)} peers (rank 0's block)"
+    return {"what": what, "bytes_received_per_step_per_gpu": received, "bytes_per_link_max": per_link,
+            "gbs_per_link_at_step_time": round(per_link / (step_us * 1e-6) / 1e9, 2) if step_us > 0 else None,
+            "link_peak_gbs": 153.0}
 
 
 def others_exit_status(args):
@@ -510,6 +591,11 @@ def summarise_other(spec, sub, seconds):
            "usec_p90": round(sub.get("ms_per_step_p90", 0) * 1e3, 3), "seconds_in_bench": round(seconds, 1)}
     if roof.get("working_set_note"):
         out["working_set_note"] = roof["working_set_note"]
+    cb = sub.get("cpu_baseline")
+    if cb:                                                   # the MKL column of this workload (bounded sample, 16 threads)
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "routine", "sample", "host_cores",
+                                                       "mismatches_vs_oracle", "parity_gpu_vs_cpu_mismatches", "mkl_error")
+                               if cb.get(k) is not None}
     if "solve_check" in c:
         out["solve_check"] = c["solve_check"]
         out["collectives"] = c.get("collectives")
@@ -801,6 +887,14 @@ def run_spmv(cx, weak):
             t_sc = time.perf_counter()
             idx_own = torch.arange(bounds[rank], bounds[rank + 1], device=dev)
             idx_halo = torch.from_numpy(halo_cols).to(dev)
+            # a handle with halo sources runs the MERGE family only (set_halo_sources re-plans an AUTO handle that
+            # resolved to another one): the reference products must come from that family too, or their sums are not
+            # the attached kernel's bit for bit and a healthy exchange "fails" (cask_amd/dist.py does the same)
+            saved_params = None
+            if mats[0].params.as_dict()["variant"] != "merge":
+                saved_params = [m.params for m in mats]
+                for m in mats:
+                    m.set_params(capi.make_params(variant="merge"))
             refs = []
             for e in range(selfcheck.N_EXCHANGES):
                 xe = torch.cat([selfcheck.operand(e, idx_own, n_global), selfcheck.operand(e, idx_halo, n_global)])
@@ -830,6 +924,9 @@ def run_spmv(cx, weak):
                     print(f"[bench] in-kernel halo failed its first-contact check ({why}); pulling", file=sys.stderr)
                 for m in mats:
                     m.set_halo_sources(n_local, None)
+                if saved_params is not None:                     # the pull path has no family constraint: the caller's point again
+                    for m, prm in zip(mats, saved_params):
+                        m.set_params(prm)
                 peer.pull()
     elif exchange == "push":
         # the operand of the benchmark does not change: it sits in place in BOTH gathered vectors (slot [rank]), so an
@@ -1065,6 +1162,9 @@ def run_spmv(cx, weak):
                                     "all_gather": "per step: RCCL all_gather(x), padded stride: one collective" + (
                                         " issued by the engine (cask_hip_rccl_allgather)" if native is not None else "")}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if use_dist else None,
+                       "rccl": cx.rccl,
+                       "xgmi": xgmi_fields(exchange, world, step_us, stride=gather.S if gather is not None else 0,
+                                           halo_by_owner=np.bincount(halo_owner, minlength=world).tolist() if peer is not None else None),
                        "exchange_selfcheck": selfchecks or None,
                        "rows_wrong_vs_oracle_all_ranks": rows_wrong,
                        "matrix_copies_rotated": copies, "launch": launch_mode, "window_form": window_form["form"],
@@ -1087,7 +1187,8 @@ def run_spmv(cx, weak):
         }
         if not args.no_cpu_baseline:
             if weak or world == 1:
-                rec["cpu_baseline"] = cpu_baseline(rp, ci, va, x_host, y_gpu if world == 1 else None, args.cpu_seconds)
+                rec["cpu_baseline"] = cpu_baseline(rp, ci, va, x_host, y_gpu if world == 1 else None, args.cpu_seconds,
+                                                   quick=getattr(args, "cpu_quick", False))
             else:
                 rec["cpu_baseline"] = cpu_baseline(grp, gci, gva, x_host, None, args.cpu_seconds)
         else:
@@ -1139,7 +1240,7 @@ def run_solver(cx):
     if world > 1 or use_dist:                                       # (one forced rank: the sharded code path at world 1)
         from cask_amd import p2p
         lci = cdist.slice_rows(rp, ci, va, bounds[rank], bounds[rank + 1])[1]
-        _, halo_cols, _, _ = p2p.plan_halo(lci, bounds, rank)
+        _, halo_cols, halo_owner_s, _ = p2p.plan_halo(lci, bounds, rank)
         halo_frac = cx.all_reduce_scalar(halo_cols.size / n, dist.ReduceOp.MAX)
         want = os.environ.get("CASK_BENCH_EXCHANGE", "auto")
         if want == "auto":
@@ -1243,6 +1344,11 @@ def run_solver(cx):
                                     "all-reduced device scalars (2 reductions per pass: config.collectives says how)",
                                     "all_gather": "per product: RCCL all_gather of the operand (padded stride); dot products all-reduced"}[exchange],
                        "halo_fraction_max": round(halo_frac, 4) if world > 1 else None,
+                       "rccl": cx.rccl,
+                       # per PRODUCT (a CG pass has one, a BiCG pass two) + 8-16 bytes per all-reduced dot
+                       "xgmi": xgmi_fields(exchange, world, step_us, stride=getattr(sh, "S", 0),
+                                           halo_by_owner=np.bincount(halo_owner_s, minlength=world).tolist()
+                                           if (world > 1 or use_dist) and exchange != "all_gather" else None),
                        "pass_form": getattr(sh, "last_pass_form", None),
                        "exchange_selfcheck": {**selfchecks, **(getattr(sh, "selfcheck", None) or {})} or None,
                        "solve_check": check, "design_point": sh.matrix.params.as_dict(),
@@ -1254,7 +1360,8 @@ def run_solver(cx):
                          "kernel": f"{kind} pass (k_spmv_merge + update kernels)",
                          "algorithmic_bytes_per_launch": b_it // world, "launch_usec": round(step_us, 3)},
         }
-        rec["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_solver(kind, rp, ci, va, b, args.cpu_seconds)
+        rec["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_solver(kind, rp, ci, va, b, args.cpu_seconds,
+                                                                                    quick=getattr(args, "cpu_quick", False))
     if world > 1 or use_dist:
         cx.host_barrier()
         if sht is not None and sht.exchange is sh.exchange:

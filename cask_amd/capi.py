@@ -14,10 +14,10 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
 
-VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN, VARIANT_MERGE_PAIR = 0, 1, 2, 3, 4, 5
-# (merge_pair is a spelling of merge with xcd_remap = 2: handles report "merge")
+VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN = 0, 1, 2, 3, 4
+VARIANT_MERGE_PAIR_REMOVED = 5      # ABI 4-5; rejected since ABI 6 (tests/test_capi_cpu.py, test_spmv_gpu.py)
 VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge",
-                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan", VARIANT_MERGE_PAIR: "merge_pair"}
+                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan"}
 
 # Every symbol include/cask_hip.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = (
@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
     "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
     "cask_hip_solve_device", "cask_hip_spmv_sequence_device", "cask_hip_spmv_windows_device",
+    "cask_hip_device_pci_bus_id",
 )
 SOLVER_CG, SOLVER_BICG = 1, 2
 SOLVER_AUTO, SOLVER_COMPOSED, SOLVER_CLASSIC = 0, 1, 2
@@ -169,6 +170,14 @@ def device_props(device: int = 0) -> dict:
     return {"name": p.name.decode(), "arch": p.arch.decode(), "compute_units": p.compute_units,
             "lds_bytes_per_cu": p.lds_bytes_per_cu, "wavefront_size": p.wavefront_size,
             "clock_mhz": p.clock_mhz, "hbm_bytes": p.hbm_bytes, "l2_bytes": p.l2_bytes}
+
+
+def device_pci_bus_id(device: int = 0) -> str:
+    L = load()
+    L.cask_hip_device_pci_bus_id.argtypes = [c_int32, c_void_p, c_int32]
+    buf = ctypes.create_string_buffer(64)
+    _check(L.cask_hip_device_pci_bus_id(device, buf, 64))
+    return buf.value.decode()
 
 
 def make_params(variant=0, lanes_per_row=0, tile_width=0, wg_size=0, items_per_thread=0,
@@ -386,7 +395,8 @@ class CsrMatrix:
 
 
 RCCL_SYMBOLS = ("cask_hip_rccl_unique_id", "cask_hip_rccl_comm_create", "cask_hip_rccl_comm_destroy",
-                "cask_hip_rccl_allreduce", "cask_hip_rccl_allgather", "cask_hip_rccl_comm_set_stride")
+                "cask_hip_rccl_allreduce", "cask_hip_rccl_allgather", "cask_hip_rccl_comm_set_stride",
+                "cask_hip_rccl_comm_info")
 
 
 class NativeComm:
@@ -404,6 +414,7 @@ class NativeComm:
             L.cask_hip_rccl_allreduce.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
             L.cask_hip_rccl_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
             L.cask_hip_rccl_comm_set_stride.argtypes = [c_void_p, c_int64]
+            L.cask_hip_rccl_comm_info.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_void_p, c_int32]
             for name in RCCL_SYMBOLS:
                 getattr(L, name).restype = ctypes.c_int
             L._rccl_bound = True
@@ -426,6 +437,13 @@ class NativeComm:
         self.handle = h
         if stride:
             _check(L.cask_hip_rccl_comm_set_stride(h, int(stride)))
+
+    def info(self) -> dict:
+        """What RCCL reports for this communicator: ranks, this rank, its device and that device's PCI bus id."""
+        n, r, d = c_int32(-1), c_int32(-1), c_int32(-1)
+        pci = ctypes.create_string_buffer(64)
+        _check(self._lib().cask_hip_rccl_comm_info(self.handle, byref(n), byref(r), byref(d), pci, 64))
+        return {"comm_nranks": n.value, "comm_rank": r.value, "device": d.value, "pci_bus_id": pci.value.decode()}
 
     def allreduce(self, t, stream=None):
         _check(self._lib().cask_hip_rccl_allreduce(c_void_p(t.data_ptr()), t.numel(), c_void_p(_stream_ptr(stream)), self.handle))

@@ -22,7 +22,6 @@
 #include "spmv_kernels.hpp"
 #ifdef CASK_UNITY   // single-translation-unit build (diagnostic builds: tools/stamps.py)
 #include "scan_launch.hip"
-#include "merge_pair.hip"
 #include "merge_launch_impl.hpp"
 namespace caskhip {
 template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
@@ -82,23 +81,14 @@ struct Plan {
   DevBuf<double> partials;
   DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz), or
   bool packed12 = false;           //   12-byte records of eight 12-bit slots per thread, [block][thread] (1.5 B/nnz)
-  bool runs = false;               //   or (r4) run records: per wave and pass a 128-bit run-start mask + int16 deltas (pack_runs)
-  DevBuf<int2v> run_desc;          //   run records: per block {first dword of its records in ci16, dwords of deltas per record}
   double slot_bytes_per_nnz = 0.0; //   what the slot stream costs (reported)
   DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
   bool one_window = false;         // every tiled block's chunks are consecutive (KIND_CONTIG): paired window loads
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
-  bool pair_ok = false;            // MERGE: every block is a tiled, 12-bit packed block: the paired-block kernel may run it
   int n_long_rows = 0, n_split_rows = 0;
   DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y
-  // far columns (MERGE with slot indices): x values of the nonzeros outside their block's tile, pre-gathered
-  // column panel by column panel (k_far_gather) into farx, block-major
-  int n_far = 0, far_grid = 0;
-  FarPanels far_panels{};
-  DevBuf<int> far_col, far_dst;
-  DevBuf<int> far_col_block;       // far_columns = 2: the far columns block-major (gathered by the product kernel itself)
-  DevBuf<double> farx;
+  int n_far = 0;                   // SCAN far plans: nonzeros served from scan_farx
   // VECTOR
   DevBuf<int2v> xspan;
   // SCAN (scan_kernel.hpp): per-thread row-end words, the row map of blocks that span empty rows, and -- far plans --
@@ -108,6 +98,7 @@ struct Plan {
   DevBuf<double> scan_farx;
   DevBuf<int> scan_sync, scan_needs;   // fused far pre-gather: producer flags + block epochs; producers each block waits for
   ScanFar scan_far{};
+  bool scan_alias = false;         // SCAN: the x window shares the product area's LDS
 };
 
 // Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
@@ -143,6 +134,8 @@ struct cask_hip_matrix {
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
+  bool has_fingerprint = false;    // content fingerprint of the device CSR (internal.hpp csr_fp_*), computed on first need
+  uint64_t fingerprint = 0;
   ~cask_hip_matrix() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -161,10 +154,9 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     out.variant = CASK_HIP_VARIANT_MERGE;
     if (!m.halo_addr && mean < 4.0 && m.max_row > 256 && m.nnz >= (1 << 20)) out.variant = CASK_HIP_VARIANT_SCAN;
   }
-  if (out.variant == CASK_HIP_VARIANT_MERGE_PAIR) {           // a spelling of MERGE with paired blocks
-    out.variant = CASK_HIP_VARIANT_MERGE;
-    out.xcd_remap = 2;
-  }
+  if (out.variant == CASK_HIP_VARIANT_MERGE_PAIR_REMOVED || out.xcd_remap == 2)
+    return fail(CASK_HIP_ERR_INVALID, "variant MERGE_PAIR (xcd_remap = 2) was removed in ABI 6: a measured loss on every "
+                                      "BASELINE family but one (docs/experiments.md); use CASK_HIP_VARIANT_MERGE");
   if (out.wg_size == 0) out.wg_size = 256;
   if (!(out.wg_size == 64 || out.wg_size == 128 || out.wg_size == 256 || out.wg_size == 512 ||
         out.wg_size == 1024))
@@ -174,6 +166,9 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
   if (m.halo_addr && out.variant != CASK_HIP_VARIANT_MERGE)
     return fail(CASK_HIP_ERR_INVALID, "a matrix with halo sources runs the MERGE variant only");
+  if (out.far_columns >= 1 && out.variant != CASK_HIP_VARIANT_SCAN)
+    return fail(CASK_HIP_ERR_INVALID, "far_columns = 1 / 2 exist for variant SCAN only (the MERGE far slots were removed in "
+                                      "ABI 6: the pre-gather cost more than the line fills it saved, docs/experiments.md)");
   if (m.nnz < 2 && !m.halo_addr) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
   if (out.lanes_per_row == 0) {
     int l = pow2_floor(std::max(1, (int)std::lround(mean / 4.0)));
@@ -190,8 +185,10 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   if (out.xcd_remap == 0) out.xcd_remap = 1;
   if (out.nontemporal == 0) out.nontemporal = 1;
   if (out.index16 == 0) out.index16 = 1;
-  if (out.index16 > 4)
-    return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed), 2 (16-bit only), 3 (12-bit, no run records) or 4 (run records)");
+  if (out.index16 == 3 || out.index16 == 4)
+    return fail(CASK_HIP_ERR_INVALID, "index16 = 3 / 4 (run records and their A/B twin) were removed in ABI 6: the decode cost "
+                                      "more than the bytes bought (docs/experiments.md); use 0 / 1 (12-bit packed slots)");
+  if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
   if (out.far_columns < -1 || out.far_columns > 2) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0, 1 or 2");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
   if (out.variant == CASK_HIP_VARIANT_MERGE || out.variant == CASK_HIP_VARIANT_SCAN) {
@@ -295,93 +292,40 @@ int ensure_host_col_ind(cask_hip_matrix &m) {
   return CASK_HIP_OK;
 }
 
-// With `far` the tile of a block keeps only the chunks several of its nonzeros share; the nonzeros of the other
-// chunks ("far": the scattered columns of a power-law block, the long-range edges of a circuit matrix) get
-// slots of their own behind the chunks, one per nonzero, and their x values arrive through the pre-gather launch.
-// A chunk with r references costs 64 slots and 512 bytes of window loads; r far slots cost r slots and ~30 bytes
-// each -- so chunks with r <= FAR_REFS are always far, and the least referenced ones follow until the block fits.
-// far_of[b] lists the block's far nonzeros in (column panel, nonzero) order; d.cmin = their number.
-constexpr int FAR_REFS = 2;
 void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks, int max_chunks,
-                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16,
-                       bool far, std::vector<std::vector<int>> *far_of) {
+                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16) {
   constexpr int GAP = 32;
   const int *ci = m.h_ci.data();
   ci16.assign((size_t)m.nnz + 8, 0);
   chunk_starts.assign(blocks.size(), {});
-  if (far_of) far_of->assign(blocks.size(), {});
-  const int panel_width = std::max(1, (m.n_cols + FAR_PANELS - 1) / FAR_PANELS);
   auto work = [&](size_t b0, size_t b1) {
-    std::vector<int> uniq, starts, refs, order;
-    std::vector<char> keep;
+    std::vector<int> uniq, starts;
     for (size_t b = b0; b < b1; b++) {
       BlockDesc &d = blocks[b];
       d.cwidth = 0;
       if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
       const int k0 = d.nnz_start, k1 = d.nnz_start + d.nnz_count;
       uniq.assign(ci + k0, ci + k1);
-      std::sort(uniq.begin(), uniq.end());                   // with duplicates: references per chunk are counted below
+      std::sort(uniq.begin(), uniq.end());
+      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
       starts.clear();
-      refs.clear();
       size_t i = 0;
       while (i < uniq.size()) {
         size_t j = i;
         while (j + 1 < uniq.size() && uniq[j + 1] - uniq[j] <= GAP) j++;
-        size_t e = i;                                         // even starts: the kernel loads the tile in 16-byte pairs
-        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) {
-          int r = 0;
-          while (e <= j && uniq[e] < c + 64) { r++; e++; }
-          if (r > 0 || !far) { starts.push_back(c); refs.push_back(r); }
-        }
+        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) starts.push_back(c);   // even starts: the kernel loads the tile in 16-byte pairs
         i = j + 1;
       }
-      int n_far = 0;
-      keep.assign(starts.size(), 1);
-      if (far) {
-        size_t kept = starts.size();
-        for (size_t c = 0; c < starts.size(); c++)
-          if (refs[c] <= FAR_REFS) { keep[c] = 0; kept--; n_far += refs[c]; }
-        if ((long)kept * 64 + n_far > (long)max_chunks * 64) {
-          order.resize(starts.size());
-          for (size_t c = 0; c < starts.size(); c++) order[c] = (int)c;
-          std::sort(order.begin(), order.end(), [&](int a, int bb) { return refs[a] != refs[bb] ? refs[a] < refs[bb] : a < bb; });
-          for (int c : order) {
-            if ((long)kept * 64 + n_far <= (long)max_chunks * 64) break;
-            if (!keep[c]) continue;
-            keep[c] = 0; kept--; n_far += refs[c];
-          }
-        }
-        if ((long)kept * 64 + n_far > (long)max_chunks * 64) continue;     // does not fit even so: gathers from L2
-        size_t w = 0;
-        for (size_t c = 0; c < starts.size(); c++)
-          if (keep[c]) starts[w++] = starts[c];
-        starts.resize(w);
-      } else if ((int)starts.size() > max_chunks) {
-        continue;
-      }
-      const int tile_slots = (int)starts.size() * 64;
+      if ((int)starts.size() > max_chunks) continue;          // does not fit: the block gathers from L2
       d.cmin = starts.empty() ? 0 : starts.front();
-      d.cwidth = tile_slots + n_far;
+      d.cwidth = (int)starts.size() * 64;
       bool contiguous = !starts.empty();
       for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
-      if (contiguous && n_far == 0) d.kind_g |= KIND_CONTIG;
-      std::vector<int> *fl = far_of ? &(*far_of)[b] : nullptr;
+      if (contiguous) d.kind_g |= KIND_CONTIG;
       for (int k = k0; k < k1; k++) {
         const int c = ci[k];
         const int idx = (int)(std::upper_bound(starts.begin(), starts.end(), c) - starts.begin()) - 1;
-        if (idx >= 0 && c < starts[idx] + 64) ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
-        else fl->push_back(k);                                // far (only reachable with `far`)
-      }
-      // chunks of neighbouring ranges may overlap: a nonzero of a dropped chunk that a kept chunk also covers
-      // is served by the tile after all, so the far count is what the lookup above found (never more than planned)
-      n_far = fl ? (int)fl->size() : 0;
-      d.cwidth = tile_slots + n_far;
-      if (n_far > 0) {
-        // (column panel, nonzero) order: the order the pre-gather launch produces them in within a block
-        std::stable_sort(fl->begin(), fl->end(), [&](int a, int bb) { return ci[a] / panel_width < ci[bb] / panel_width; });
-        for (int j = 0; j < n_far; j++) ci16[(*fl)[j]] = (unsigned short)(tile_slots + j);
-        d.kind_g |= KIND_FAR;
-        d.cmin = n_far;                                       // the chunked window path does not use cmin
+        ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
       }
       chunk_starts[b] = starts;
     }
@@ -451,96 +395,6 @@ void pack_slots12(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks
     for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
     for (auto &th : pool) th.join();
   }
-}
-
-// Run records for the IPT = 8 merge kernel (merge_kernel.hpp, CRUN).  In pass u a wave's 64 lanes take
-// the 128 consecutive elements 2p, 2p+1, p = first + u*wg + 64*wave + lane (clamped to `last` like merge_load does).
-// Their LDS slots are written as RUNS of consecutive slots: bit i of a 128-bit mask is set where element i starts a
-// run, and run r carries delta_r = (its first slot) - (its first element), so slot(i) = i + delta[run(i)].  Elements
-// that are not the block's own (the lead of an odd start, the foreign half of the last pair, clamped duplicates) may
-// use any slot inside the tile -- their products land where no row looks -- and simply continue the run they follow.
-// Per block all records have one size: 4 dwords of mask + RD dwords of deltas (two int16 each), RD = the block's
-// longest record rounded up to 4 dwords.  Returns false when some block has more than RUN_MAX runs in a pass (rows of
-// scattered columns: the 12-bit records are smaller) -- the plan then keeps the packed 12-bit slots.
-constexpr int RUN_MAX = 64;
-bool pack_runs(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks, const std::vector<unsigned short> &ci16,
-               int wg, int limit_slots, std::vector<unsigned> &stream, std::vector<int2v> &desc) {
-  const int max_gpair = (int)((m.nnz + 1) / 2) - 1;
-  const int wpw = wg / 64, groups = 4 * wpw;
-  const size_t nb = blocks.size();
-  desc.assign(nb, int2v{0, 0});
-  std::vector<std::vector<unsigned>> recs(nb);                // per block: its records, fixed size
-  std::vector<char> bad(nb, 0);
-  auto work = [&](size_t b0, size_t b1) {
-    std::vector<int> slot(128);
-    std::vector<unsigned> masks, deltas;                      // per group: 4 dwords; per group: its runs' deltas
-    std::vector<int> n_runs;
-    for (size_t b = b0; b < b1; b++) {
-      const BlockDesc &d = blocks[b];
-      if ((d.kind_g & KIND_LONG) || d.cwidth <= 0) continue;  // long pieces and untiled blocks read 32-bit indices
-      const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;
-      const int npairs = (total + 1) >> 1, first = base >> 1;
-      const int last = std::min(first + std::max(npairs - 1, 0), max_gpair);
-      const int own0 = d.nnz_start, own1 = d.nnz_start + d.nnz_count;
-      masks.assign((size_t)groups * 4, 0u);
-      deltas.clear();
-      n_runs.assign(groups, 0);
-      std::vector<std::vector<short>> gd(groups);
-      int rmax = 0;
-      for (int g = 0; g < groups; g++) {
-        const int u = g / wpw, w = g % wpw;
-        int prev = -2;
-        for (int i = 0; i < 128; i++) {
-          const int pr = first + u * wg + 64 * w + (i >> 1);
-          const int e = 2 * pr + (i & 1);
-          const bool own = pr <= last && e >= own0 && e < own1;
-          int sl;
-          if (own) sl = ci16[e];
-          else     sl = (prev >= 0 && prev + 1 < limit_slots) ? prev + 1 : 0;   // free element: continue the run
-          if (i == 0 || sl != prev + 1) {
-            masks[(size_t)g * 4 + (i >> 5)] |= 1u << (i & 31);
-            gd[g].push_back((short)(sl - i));
-          }
-          prev = sl;
-        }
-        n_runs[g] = (int)gd[g].size();
-        rmax = std::max(rmax, n_runs[g]);
-      }
-      if (rmax > RUN_MAX) { bad[b] = 1; continue; }
-      const int rd = ((rmax + 1) / 2 + 3) & ~3;               // dwords of deltas per record, a multiple of 4
-      std::vector<unsigned> &out = recs[b];
-      out.assign((size_t)groups * (4 + rd), 0u);
-      for (int g = 0; g < groups; g++) {
-        unsigned *rec = out.data() + (size_t)g * (4 + rd);
-        for (int k = 0; k < 4; k++) rec[k] = masks[(size_t)g * 4 + k];
-        for (int r = 0; r < n_runs[g]; r++)
-          rec[4 + (r >> 1)] |= (unsigned)(unsigned short)gd[g][r] << (16 * (r & 1));
-      }
-      desc[b].y = rd;
-    }
-  };
-  size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
-  if (n_threads <= 1) {
-    work(0, nb);
-  } else {
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
-    for (auto &th : pool) th.join();
-  }
-  for (size_t b = 0; b < nb; b++)
-    if (bad[b]) return false;
-  size_t total = 0;
-  for (size_t b = 0; b < nb; b++) total += recs[b].size();
-  if (total >= (size_t)1 << 30) return false;
-  stream.clear();
-  stream.reserve(total + 4);
-  for (size_t b = 0; b < nb; b++) {
-    desc[b].x = (int)stream.size();
-    stream.insert(stream.end(), recs[b].begin(), recs[b].end());
-  }
-  stream.resize(stream.size() + 4, 0u);                       // (a clamped 16-byte read at the very end stays inside)
-  return true;
 }
 
 // Host twin of logical_block() (spmv_kernels.hpp).
@@ -816,7 +670,10 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
     }
   }
   HIP_TRY(pl.blocks.upload(blocks));
-  pl.lds_bytes = base_lds + 16 * pl.xu * wg;
+  // r5: a window that fits the product area shares its LDS (scan_kernel.hpp, XA) -- A/B hook CASK_HIP_SCAN_ALIAS=0
+  static const bool alias_on = [] { const char *e = std::getenv("CASK_HIP_SCAN_ALIAS"); return !e || std::atoi(e) != 0; }();
+  pl.scan_alias = alias_on && pl.xu > 0 && 2 * pl.xu <= ipt + 1;
+  pl.lds_bytes = base_lds + (pl.scan_alias ? 0 : 16 * pl.xu * wg);
   pl.ldsx = pl.xu > 0;
   return CASK_HIP_OK;
 }
@@ -831,24 +688,17 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.long_blocks.release();
   pl.ci16.release();
   pl.packed12 = false;
-  pl.runs = false;
-  pl.run_desc.release();
   pl.one_window = false;
   pl.xchunk.release();
   pl.maxch = 0;
   pl.any_skew = false;
-  pl.pair_ok = false;
   pl.n_blocks = pl.n_long_blocks = 0;
   pl.split_rows.release();
   pl.partials.release();
   pl.dot_part.release();
   pl.xspan.release();
   pl.n_long_rows = pl.n_split_rows = 0;
-  pl.n_far = pl.far_grid = 0;
-  pl.far_col.release();
-  pl.far_dst.release();
-  pl.far_col_block.release();
-  pl.farx.release();
+  pl.n_far = 0;
   pl.scan_meta.release();
   pl.scan_rowmap.release();
   pl.scan_ci.release();
@@ -923,65 +773,12 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       int xu_cap = 8;
       while (xu_cap > 0 && base_lds + 8 * xu_cap * prm.wg_size > MAX_LDS_BYTES) xu_cap /= 2;
       const int max_slots = std::min(tile, xu_cap * prm.wg_size);
-      std::vector<std::vector<int>> chunk_starts, far_of;
+      std::vector<std::vector<int>> chunk_starts;
       std::vector<unsigned short> ci16;
-      // far columns: never with halo sources (their x values live on peers).  Opt-in (far_columns = 1): measured
-      // on every BASELINE family (profiles/r02_far_columns.txt) the pre-gather launch costs more than it saves --
-      // webbase-1M-like: product 24.4 -> 19.5-21.3 us, but the gather launch is two dependent memory round trips
-      // with little parallelism (9.4 us for 23 MB), 29-31 us in all; G3_circuit-like 22.1 -> 27.3 us.  It does cut
-      // the fabric traffic, which is what the column panels are for; it does not cut the time.
-      bool far = prm.far_columns >= 1 && !m.halo_addr && max_slots <= 65536;
-      long n_far = 0;
-      if (far) {
-        std::vector<BlockDesc> trial = blocks;
-        build_chunk_tiles(m, trial, max_slots / 64, chunk_starts, ci16, true, &far_of);
-        for (const auto &f : far_of) n_far += (long)f.size();
-        if (n_far == 0 || (prm.far_columns == 0 && n_far * 20 < m.nnz)) {
-          far = false;
-          n_far = 0;
-        } else {
-          blocks = trial;
-        }
-      }
-      if (!far) build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16, false, nullptr);
-      pl.prm.far_columns = far ? prm.far_columns : -1;
-      if (far) {
-        // farx is block-major (one coalesced run per block); the pre-gather walks the far nonzeros sorted by column
-        // panel, then block, then nonzero -- the order far_of already has inside a block
-        const int panel_width = std::max(1, (m.n_cols + FAR_PANELS - 1) / FAR_PANELS);
-        std::vector<int> base(blocks.size() + 1, 0);
-        for (size_t b = 0; b < blocks.size(); b++) base[b + 1] = base[b] + (int)far_of[b].size();
-        std::vector<int> count(FAR_PANELS + 1, 0);
-        for (const auto &f : far_of)
-          for (int k : f) count[m.h_ci[k] / panel_width + 1]++;
-        for (int p = 0; p < FAR_PANELS; p++) count[p + 1] += count[p];
-        std::vector<int> fill(count.begin(), count.end() - 1), fcol((size_t)n_far), fdst((size_t)n_far);
-        for (size_t b = 0; b < blocks.size(); b++) {
-          for (size_t j = 0; j < far_of[b].size(); j++) {
-            const int k = far_of[b][j], p = m.h_ci[k] / panel_width, at = fill[p]++;
-            fcol[at] = m.h_ci[k];
-            fdst[at] = base[b] + (int)j;
-          }
-          if (!far_of[b].empty()) blocks[b].aux = base[b];
-        }
-        int per_panel = 0;
-        for (int p = 0; p <= FAR_PANELS; p++) pl.far_panels.start[p] = count[p];
-        for (int p = 0; p < FAR_PANELS; p++) per_panel = std::max(per_panel, (count[p + 1] - count[p] + FAR_CHUNK - 1) / FAR_CHUNK);
-        pl.n_far = (int)n_far;
-        if (prm.far_columns == 2) {                           // no pre-gather: the product kernel gathers through this list
-          std::vector<int> fcb((size_t)n_far);
-          for (size_t b = 0; b < blocks.size(); b++)
-            for (size_t j = 0; j < far_of[b].size(); j++) fcb[(size_t)base[b] + j] = m.h_ci[far_of[b][j]];
-          HIP_TRY(pl.far_col_block.upload(fcb));
-        } else {
-          pl.far_grid = per_panel * FAR_PANELS;
-          HIP_TRY(pl.far_col.upload(fcol));
-          HIP_TRY(pl.far_dst.upload(fdst));
-          HIP_TRY(pl.farx.alloc((size_t)n_far));
-        }
-      }
+      build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16);
+      pl.prm.far_columns = -1;
       if (m.halo_addr) place_seam_blocks(m, blocks, chunk_starts, prm.xcd_remap > 0);
-      int max_used = 0;                                       // slots of the fullest tile (chunks + far slots)
+      int max_used = 0;                                       // slots of the fullest tile
       for (const BlockDesc &d : blocks)
         if (!(d.kind_g & KIND_LONG)) max_used = std::max(max_used, d.cwidth);
       if (max_used > 0) {
@@ -999,41 +796,16 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
           if (!(d.kind_g & KIND_LONG) && d.cwidth > 0 && !(d.kind_g & KIND_CONTIG)) pl.one_window = false;
         // index16 = 1 packs the slots 12 bits each where the kernel has that layout (8 items per thread, tile of
         // at most 4096 slots): 1.5 instead of 2 bytes per nonzero; index16 = 2 keeps 16-bit slots
-        pl.packed12 = (prm.index16 == 1 || prm.index16 == 3 || prm.index16 == 4) && prm.items_per_thread == 8 &&
-                      pl.prm.tile_width <= 4096;
-        // ... or, r4, as run records where the block's slots come in runs (FEM matrices with several unknowns per
-        // node): OPT-IN, index16 = 4 (whenever they can be built).  They are a measured loss: on the cant3 look-alike
-        // the slot stream falls from 1.5 to 0.38 bytes per nonzero (44.0 -> 39.2 MB per launch) and the launch goes
-        // from 8.80 to 9.83 us -- the decode (popcounts, two ds_bpermute and selects per pass: ~100 VALU instructions
-        // per wave on top of 155) costs more issue slots than the bytes buy (profiles/r04_run_records.txt).  AUTO
-        // (0/1) and 3 never take them.
-        pl.runs = false;
+        pl.packed12 = prm.index16 == 1 && prm.items_per_thread == 8 && pl.prm.tile_width <= 4096;
         pl.slot_bytes_per_nnz = pl.packed12 ? 1.5 : 2.0;
-        if (pl.packed12 && prm.index16 == 4 && prm.nontemporal > 0 && !pl.any_skew && pl.n_far == 0) {
-          std::vector<unsigned> rstream;
-          std::vector<int2v> rdesc;
-          const double bytes12 = 12.0 * prm.wg_size * (double)blocks.size();
-          if (pack_runs(m, blocks, ci16, prm.wg_size, xu * prm.wg_size, rstream, rdesc) &&
-              4.0 * rstream.size() < bytes12) {
-            pl.runs = true;
-            pl.packed12 = false;
-            pl.slot_bytes_per_nnz = m.nnz ? 4.0 * rstream.size() / (double)m.nnz : 0.0;
-            std::vector<unsigned short> as16(rstream.size() * 2);
-            std::memcpy(as16.data(), rstream.data(), rstream.size() * 4);
-            HIP_TRY(pl.ci16.upload(as16));
-            HIP_TRY(pl.run_desc.upload(rdesc));
-          }
-        }
-        if (pl.runs) {
-          // uploaded above
-        } else if (pl.packed12) {
+        if (pl.packed12) {
           std::vector<unsigned short> packed;
           pack_slots12(m, blocks, ci16, prm.wg_size, packed);
           HIP_TRY(pl.ci16.upload(packed));
         } else {
           HIP_TRY(pl.ci16.upload(ci16));
         }
-        pl.prm.index16 = pl.runs ? 4 : pl.packed12 ? 1 : 2;  // reported: what the plan streams
+        pl.prm.index16 = pl.packed12 ? 1 : 2;                 // reported: what the plan streams
       }
       HIP_TRY(pl.blocks.upload(blocks));               // cwidth now holds the slots each block uses
     } else if (tile > 0 && m.nnz > 0) {
@@ -1069,11 +841,6 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       HIP_TRY(pl.blocks.upload(blocks));
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
-    pl.pair_ok = pl.packed12 && !pl.any_skew && pl.n_far == 0 && pl.n_split_rows == 0 && !m.halo_addr &&
-                 prm.nontemporal > 0 && pl.xu > 0 && prm.items_per_thread == 8;
-    for (const BlockDesc &d : blocks)
-      pl.pair_ok = pl.pair_ok && !(d.kind_g & KIND_LONG) && d.cwidth > 0 && d.cwidth <= pl.xu * prm.wg_size;
-    if (pl.prm.xcd_remap == 2 && !pl.pair_ok) pl.prm.xcd_remap = 1;   // reported: the ordinary kernel runs this plan
     // shares of a fused dot (a few KB): allocated with the plan, so that a product with the dot epilogue
     // never allocates -- it may be running under stream capture
     HIP_TRY(pl.dot_part.alloc((size_t)pl.grid + (size_t)pl.n_split_rows));
@@ -1119,15 +886,13 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
     return fail(CASK_HIP_ERR_INVALID, "clone_plan: different matrices");
   d.prm = s.prm; d.grid = s.grid; d.lds_bytes = s.lds_bytes; d.ldsx = s.ldsx; d.xu = s.xu;
   d.n_blocks = s.n_blocks; d.n_long_blocks = s.n_long_blocks; d.packed12 = s.packed12; d.one_window = s.one_window;
-  d.runs = s.runs; d.slot_bytes_per_nnz = s.slot_bytes_per_nnz; HIP_TRY(d.run_desc.copy_from(s.run_desc));
-  d.maxch = s.maxch; d.any_skew = s.any_skew; d.pair_ok = s.pair_ok; d.n_long_rows = s.n_long_rows;
-  d.n_split_rows = s.n_split_rows; d.n_far = s.n_far; d.far_grid = s.far_grid; d.far_panels = s.far_panels;
-  d.scan_far = s.scan_far;
+  d.slot_bytes_per_nnz = s.slot_bytes_per_nnz;
+  d.maxch = s.maxch; d.any_skew = s.any_skew; d.n_long_rows = s.n_long_rows;
+  d.n_split_rows = s.n_split_rows; d.n_far = s.n_far;
+  d.scan_far = s.scan_far; d.scan_alias = s.scan_alias;
   HIP_TRY(d.blocks.copy_from(s.blocks)); HIP_TRY(d.long_blocks.copy_from(s.long_blocks));
   HIP_TRY(d.split_rows.copy_from(s.split_rows)); HIP_TRY(d.partials.copy_from(s.partials));
   HIP_TRY(d.ci16.copy_from(s.ci16)); HIP_TRY(d.xchunk.copy_from(s.xchunk)); HIP_TRY(d.dot_part.copy_from(s.dot_part));
-  HIP_TRY(d.far_col.copy_from(s.far_col)); HIP_TRY(d.far_dst.copy_from(s.far_dst));
-  HIP_TRY(d.far_col_block.copy_from(s.far_col_block)); HIP_TRY(d.farx.copy_from(s.farx));
   HIP_TRY(d.xspan.copy_from(s.xspan));
   HIP_TRY(d.scan_meta.copy_from(s.scan_meta)); HIP_TRY(d.scan_rowmap.copy_from(s.scan_rowmap));
   HIP_TRY(d.scan_ci.copy_from(s.scan_ci)); HIP_TRY(d.scan_fcol.copy_from(s.scan_fcol));
@@ -1164,6 +929,16 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
 // (16 doubles) in dynamic LDS behind the x tile
 int dot_lds_bytes(int wg_size) { return 16 * wg_size + 128; }
 
+// r5 A/B hook: CASK_HIP_MERGE_ROLL = 0 (plain), 1 (rolling row sums), 2 (products aliased over the x window),
+// 3 (both) for the lean MERGE launches; read once.
+int merge_roll_mode() {
+  static const int mode = [] {
+    const char *e = std::getenv("CASK_HIP_MERGE_ROLL");
+    return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
+  }();
+  return mode;
+}
+
 template <int IPT>
 int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot,
                    const SolverPass *pass) {
@@ -1175,16 +950,7 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.lds_bytes = pl.lds_bytes + ((dot.w || pass) ? dot_lds_bytes(pl.prm.wg_size) : 0);
   l.solver_pass = pass != nullptr;
   if (pass) l.pass = *pass;
-  l.farx = nullptr;
-  l.far_col = nullptr;
-  l.far = pl.n_far > 0;
-  if (pl.n_far > 0 && pl.far_col_block.p) {
-    l.far_col = pl.far_col_block.p;
-  } else if (pl.n_far > 0) {                                  // x values of the far nonzeros, panel by panel
-    hipLaunchKernelGGL(k_far_gather, dim3(pl.far_grid), dim3(256), 0, s, pl.far_panels, pl.far_col.p, pl.far_dst.p, x,
-                       pl.farx.p);
-    l.farx = pl.farx.p;
-  }
+  l.roll = merge_roll_mode();
   l.xu = pl.xu;
   l.remap = pl.prm.xcd_remap > 0;
   l.n_cols = m.n_cols;
@@ -1197,17 +963,13 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.ci = m.d_ci;
   l.ci16 = reinterpret_cast<const unsigned *>(pl.ci16.p);
   l.packed12 = pl.packed12;
-  l.run_desc = pl.runs ? pl.run_desc.p : nullptr;
   l.one_window = pl.one_window;
   l.xchunk = pl.xchunk.p;
   l.val = m.d_val;
   l.partials = pl.partials.p;
   l.halo = XHalo{m.halo_n_own, m.halo_addr, m.halo_shift};
   l.dot = dot;
-  if (IPT == 8 && pl.prm.xcd_remap == 2 && pl.pair_ok && !dot.w && !dot.dot_part && !pass && !m.halo_addr)
-    launch_merge_pair(l, x, y, s);
-  else
-    launch_merge_blocks<IPT>(l, x, y, s);
+  launch_merge_blocks<IPT>(l, x, y, s);
   if (pl.n_split_rows > 0 && !(pass && pass->final_only)) {   // (a final_only launch runs no product: nothing to fix up)
     // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
     // launch stored (b_new), or the plain vector the pass names (wa without wb)
@@ -1284,6 +1046,7 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
     l.n_cols = m.n_cols;
     l.xp = pl.xu;
     l.nontemporal = pl.prm.nontemporal > 0;
+    l.alias = pl.scan_alias;
     l.blocks = pl.blocks.p;
     l.rp = m.d_rp;
     l.ci = pl.scan_ci.p ? pl.scan_ci.p : m.d_ci;
@@ -1465,6 +1228,13 @@ int cask_hip_device_props_get(int32_t device, cask_hip_device_props *out) {
   return CASK_HIP_OK;
 }
 
+int cask_hip_device_pci_bus_id(int32_t device, char *out, int32_t len) {
+  if (!out || len < 16) return fail(CASK_HIP_ERR_INVALID, "out must hold at least 16 bytes");
+  out[0] = 0;
+  HIP_TRY(hipDeviceGetPCIBusId(out, len, device));
+  return CASK_HIP_OK;
+}
+
 int cask_hip_csr_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row_ptr,
                         const int32_t *col_ind, const double *values, const cask_hip_params *params,
                         cask_hip_matrix **out) {
@@ -1568,7 +1338,7 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out) {
   out->empty_rows = m->empty_rows;
   out->mean_row_nnz = m->n_rows ? (double)m->nnz / m->n_rows : 0.0;
   out->algorithmic_bytes = 12 * m->nnz + 4 * ((int64_t)m->n_rows + 1) + 8 * (int64_t)m->n_cols + 8 * (int64_t)m->n_rows;
-  out->fuses_dot = plan_fuses_dot(m->plan) && m->plan.n_far == 0 ? 1 : 0;
+  out->fuses_dot = plan_fuses_dot(m->plan) ? 1 : 0;
   return CASK_HIP_OK;
 }
 
@@ -1867,12 +1637,12 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                   cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE,
-                                         CASK_HIP_VARIANT_SCAN, CASK_HIP_VARIANT_MERGE_PAIR};
+                                         CASK_HIP_VARIANT_SCAN};
   static const int32_t def_lanes[] = {4, 8, 16, 32};
   static const int32_t def_tiles[] = {-1, 1024, 4096};
   static const int32_t def_wg[] = {256, 512};
   static const int32_t def_items[] = {4, 8};
-  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 5; }
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 4; }
   if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 4; }
   if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 3; }
   if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 2; }
@@ -1958,9 +1728,7 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             const int variant = variants[iva];
             // SCAN: items per thread like the merge kernels; its tile axis is the near margin of the far pre-gather
             const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE ||
-                                  variant == CASK_HIP_VARIANT_SCAN || variant == CASK_HIP_VARIANT_MERGE_PAIR;
-            // the paired-block kernel exists for 8 items per thread and a tile
-            if (variant == CASK_HIP_VARIANT_MERGE_PAIR && (items[iv] != 8 || tiles[it] <= 0)) continue;
+                                  variant == CASK_HIP_VARIANT_SCAN;
             // a block with halo sources runs the MERGE variant only: a winner from another family could not be applied
             if (saved_halo && variant != CASK_HIP_VARIANT_MERGE) continue;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
@@ -1969,7 +1737,6 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             Cand c{};
             c.pt.params = saved;
             c.pt.params.variant = variant;
-            if (variant != CASK_HIP_VARIANT_MERGE_PAIR && c.pt.params.xcd_remap == 2) c.pt.params.xcd_remap = 1;
             c.pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
             c.pt.params.items_per_thread = is_merge ? items[iv] : 0;
             c.pt.params.tile_width = tiles[it];
@@ -2209,8 +1976,7 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     }
     if (st.At->n_rows != m->n_rows) return fail(CASK_HIP_ERR_INVALID, "A and A^T blocks differ in their row count");
   }
-  const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange &&
-                           m->plan.n_far == 0 && (!bicg || st.At->plan.n_far == 0);   // far slots carry a plain operand
+  const bool can_compose = plan_fuses_dot(m->plan) && (!bicg || plan_fuses_dot(st.At->plan)) && !st.exchange;
   if (cfg.mode == CASK_HIP_SOLVER_COMPOSED && !can_compose)
     return fail(CASK_HIP_ERR_INVALID, "composed passes need MERGE plans with the dot epilogue (and no exchange callback)");
   // AUTO: measured on one GPU (profiles/r02_solver_modes.txt) the composed pass LOSES to the classic one --
@@ -2537,6 +2303,38 @@ __global__ void k_permute_out(int64_t n, const int *__restrict__ perm, const dou
 // p update   = 2 C + 2 launches with no permutation pass and no separate dot (round 3: 8 sweeps + 2 permutations + a
 // generic pass = 134 us on the G3_circuit-like system; this form: see profiles/r04_pcg_mc.txt).  Recurrence, stopping
 // rule and `iterations` as pcg (SparseLinearSolvers.hpp:162-239).
+// The fingerprint of the handle's device arrays (they do not change while the handle exists: cask_hip.h).
+__global__ void k_csr_fingerprint(int n_rows, int64_t nnz, const int *__restrict__ rp, const int *__restrict__ ci,
+                                  const double *__restrict__ val, unsigned long long *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long acc = 0;
+  for (int64_t r = t0; r <= n_rows; r += stride) acc += csr_fp_row((uint64_t)r, (uint64_t)rp[r]);
+  for (int64_t k = t0; k < nnz; k += stride)
+    acc += csr_fp_entry((uint64_t)k, (uint64_t)ci[k], (uint64_t)__double_as_longlong(val[k]));
+  atomicAdd(out, acc);                                          // integer: any order gives the same sum
+}
+static int matrix_fingerprint(cask_hip_matrix *m, uint64_t *fp) {
+  if (!m->has_fingerprint) {
+    DevBuf<unsigned long long> acc;
+    HIP_TRY(acc.alloc(1));
+    HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), m->stream));
+    const int grid = (int)std::min<int64_t>(2048, (m->nnz + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_csr_fingerprint, dim3(grid), dim3(256), 0, m->stream, m->n_rows, m->nnz, m->d_rp, m->d_ci, m->d_val,
+                       acc.p);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, acc.p, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->fingerprint = h;
+    m->has_fingerprint = true;
+  }
+  *fp = m->fingerprint;
+  return CASK_HIP_OK;
+}
+
+// (returns PCG_MC_NOT_APPLICABLE before any work is queued when the permuted matrix's plan cannot leave the shares of
+// p.Ap behind -- LDS budget, a grid of long-row pieces only: the caller then runs the generic pass)
+constexpr int PCG_MC_NOT_APPLICABLE = -1;
 static int pcg_multicolour(cask_hip_matrix *m, cask_hip_precond *precond, const cask_hip_mc_view &mc, const double *rhs,
                            double *x, int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
                            double *usec_per_iteration) {
@@ -2550,6 +2348,7 @@ static int pcg_multicolour(cask_hip_matrix *m, cask_hip_precond *precond, const 
     if (rc) return rc;
   }
   cask_hip_matrix *mp = *mc.product;
+  if (!plan_fuses_dot(mp->plan)) return PCG_MC_NOT_APPLICABLE;
   DevBuf<double> dx, db, xin, r, z, p, Ap, part_rz, scal;
   DevBuf<int> flags;
   HIP_TRY(xin.upload(x, n)); HIP_TRY(db.upload(rhs, n));
@@ -2584,7 +2383,6 @@ static int pcg_multicolour(cask_hip_matrix *m, cask_hip_precond *precond, const 
   int h_flags[2] = {0, 0};
   int launched = 0;
   double clean_us = 0.0;
-  if (!plan_fuses_dot(mp->plan)) return fail(CASK_HIP_ERR_RUNTIME, "the permuted matrix's plan has no dot epilogue");
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
     rc = launch_spmv(*mp, p.p, Ap.p, s, p.p);                                            // :206-208
@@ -2634,12 +2432,20 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipSetDevice(m->device));
   {
     cask_hip_mc_view mc{};
-    // (the colour-ordered solve multiplies with the matrix the preconditioner was built from, permuted: only when that
-    // is `m`'s matrix by shape and nonzero count -- a caller who preconditions one matrix with another's factors gets
-    // the generic pass, which multiplies with `m`)
+    // (the colour-ordered solve multiplies with the preconditioner's cached copy of P A P^T: only when that IS `m`'s
+    // matrix -- same pattern AND values, by content fingerprint.  A caller who preconditions A_new with the factors of
+    // A_old (a lagged or frozen preconditioner: same pattern, other values), or one matrix with another's, gets the
+    // generic pass, which multiplies with `m` as the reference's pcg does)
     if (cask_hip_precond_mc_view(precond, &mc) && m->n_rows > 0 && m->nnz >= 2 && m->n_rows == m->n_cols &&
-        mc.n == m->n_rows && (int64_t)mc.h_rp[mc.n] == m->nnz && !std::getenv("CASK_HIP_PCG_MC_GENERIC"))
-      return pcg_multicolour(m, precond, mc, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+        mc.n == m->n_rows && (int64_t)mc.h_rp[mc.n] == m->nnz && !std::getenv("CASK_HIP_PCG_MC_GENERIC")) {
+      uint64_t fp = 0;
+      rc = matrix_fingerprint(m, &fp);
+      if (rc) return rc;
+      if (fp == mc.fingerprint) {
+        rc = pcg_multicolour(m, precond, mc, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
+        if (rc != PCG_MC_NOT_APPLICABLE) return rc;
+      }
+    }
   }
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;
@@ -2730,7 +2536,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   if (iterations) *iterations = h_flags[1];
   if (converged) *converged = h_flags[0] != 0;          // the flag carries the pass that set it
   if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
-  return cask_hip_precond_check(precond);
+  return CASK_HIP_OK;
 }
 
 }  // extern "C"

@@ -350,226 +350,12 @@ k_trsv_packed(PackedTri t, int c0, int c1, int unit, const double *__restrict__ 
   }
 }
 
-// ---- packed walk, one walker wave (round 3) ------------------------------------------------------------------------
-// k_trsv_packed pays ~500 cycles per level: the four waves take the levels in turn, every level ends in a workgroup
-// barrier, and the three preparation steps of a level (bounds -> right-hand side and entry range -> entries: dependent
-// LDS reads that do NOT depend on x) are done level by level by the waves whose turn it is not.  Here the preparation
-// moves to staging time and the barriers out of the walk:
-//   * after a chunk is staged, all 256 threads REPACK it: position idx gets a 48-byte record {b, diagonal | first two
-//     entry values | their x sources, entry count, first entry} -- three dependent LDS reads per position, once per
-//     chunk, in parallel, instead of once per level on the critical path;
-//   * wave 0 alone walks the chunk's levels: per level one read of the records (three 16-byte reads per lane, independent
-//     of x), the x reads, the row's FMAs in stored order, the ring write.  No barrier: the LDS operations of one wave
-//     execute in order, so a level's x reads see the previous level's ring writes.  The other waves wait at the barrier
-//     that ends the chunk, with the next chunk's prefetch in their registers.
-// Same arithmetic in the same order as k_trsv_packed (and as solve_row): bit-identical results (tested).
-// MEASURED (profiles/r03_trsv.txt, one ILU(0) application): G3_circuit-like 36.5 ms against 32.2 for the four-wave walk,
-// atmosmodd-like 3.52 vs 3.33, cant-like 27.6-32.7 vs 31.3-31.6 -- it LOSES where the levels are narrow and the rows
-// short: one wave issues every instruction of a level itself (~60 of them: records, addresses, the FMAs, an fp64
-// division in the upper solve, the register rotation of the software pipeline) at 4-8 cycles apiece, ~600-700 cycles
-// per level, where the four-wave walk spreads the preparation over three other SIMDs and pays ~500-670 with its
-// barrier.  Opt-in (CASK_HIP_TRSV=walk1); the four-wave walk stays the default.
-constexpr size_t PK1_LDS_BYTES = sizeof(double) * (PK_RING + 2 * PK_ECAP) + 48 * (size_t)PK_CH +
-                                 sizeof(int) * (PK_ECAP + (PK_CH + 1) + (PK_CH + 1));
 typedef double pk_dbl2 __attribute__((ext_vector_type(2)));
 typedef int pk_int4 __attribute__((ext_vector_type(4)));
 
-template <bool LONG>
-__global__ void __launch_bounds__(PK_T)
-k_trsv_walk1(PackedTri t, int c0, int c1, int unit, const double *__restrict__ b, double *x) {
-  extern __shared__ double pk_lds[];
-  double *ring = pk_lds;
-  double *s_val = ring + PK_RING, *s_x = s_val + PK_ECAP;     // (s_src holds byte offsets that assume this order)
-  pk_dbl2 *R0 = reinterpret_cast<pk_dbl2 *>(s_x + PK_ECAP);   // {b[row], diagonal}
-  pk_dbl2 *R1 = R0 + PK_CH;                                   // {value of entry 0, of entry 1}
-  pk_int4 *R2 = reinterpret_cast<pk_int4 *>(R1 + PK_CH);      // {x source of entry 0, of entry 1, entries, first entry}
-  int *s_src = reinterpret_cast<int *>(R2 + PK_CH);
-  int *s_e = s_src + PK_ECAP;
-  int *s_seg = s_e + PK_CH + 1;
-  const char *lds_bytes = reinterpret_cast<const char *>(pk_lds);
-  const int tid = threadIdx.x;
-
-  int r_row[PK_PJ], r_e[PK_PJ + 1], r_seg[PK_PJ + 1];
-  double r_diag[PK_PJ], r_b[PK_PJ], r_val[PK_EJ], r_x[PK_EJ];
-  unsigned r_code[PK_EJ];
-  int4 h0, h1;
-  int w_row[PK_PJ];
-
-  auto load_chunk = [&](int cs, int cnt, int ebase, int ecnt, int sbase, int scnt) {
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) r_row[j] = t.row[cs + min(tid + PK_T * j, cnt - 1)];
-#pragma unroll
-    for (int j = 0; j < PK_EJ; j++) r_code[j] = t.code[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) r_diag[j] = t.diag[cs + min(tid + PK_T * j, cnt - 1)];
-#pragma unroll
-    for (int j = 0; j < PK_PJ + 1; j++) {
-      r_e[j] = t.eptr[cs + min(tid + PK_T * j, cnt)] - ebase;
-      r_seg[j] = t.seg[sbase + min(tid + PK_T * j, scnt - 1)] - cs;
-    }
-#pragma unroll
-    for (int j = 0; j < PK_EJ; j++) r_val[j] = t.val[ebase + min(tid + PK_T * j, max(ecnt - 1, 0))];
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) r_b[j] = b[r_row[j]];
-#pragma unroll
-    for (int j = 0; j < PK_EJ; j++) {
-      const bool early = tid + PK_T * j < ecnt && !(r_code[j] & PK_NEAR);
-      r_x[j] = __hip_atomic_load(x + (early ? r_code[j] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  auto store_chunk = [&](int cnt, int ecnt, int scnt) {
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) {
-      const int idx = tid + PK_T * j;
-      if (idx < cnt) {
-        pk_dbl2 r0;
-        r0.x = r_b[j];
-        r0.y = r_diag[j];
-        R0[idx] = r0;
-      }
-      w_row[j] = r_row[j];
-    }
-#pragma unroll
-    for (int j = 0; j < PK_PJ + 1; j++) {
-      const int idx = tid + PK_T * j;
-      if (idx <= cnt) s_e[idx] = r_e[j];
-      if (idx < scnt) s_seg[idx] = r_seg[j];
-    }
-#pragma unroll
-    for (int j = 0; j < PK_EJ; j++) {
-      const int idx = tid + PK_T * j;
-      if (idx < ecnt) {
-        s_src[idx] = (r_code[j] & PK_NEAR) ? (int)((r_code[j] & (PK_RING - 1)) * 8u)
-                                           : (int)((PK_RING + PK_ECAP + idx) * 8);
-        s_val[idx] = r_val[j];
-        s_x[idx] = r_x[j];
-      }
-    }
-  };
-  // the per-position records: what the four-wave walk's `rows` and `entries` steps read level by level
-  auto repack = [&](int cnt) {
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) {
-      const int idx = tid + PK_T * j;
-      if (idx < cnt) {
-        const int e0 = s_e[idx], ne = s_e[idx + 1] - e0;
-        const int ea = e0, eb = e0 + min(1, max(ne - 1, 0));   // (an absent entry repeats the last one: never used)
-        pk_dbl2 r1;
-        pk_int4 r2;
-        r1.x = s_val[ea];
-        r1.y = s_val[eb];
-        r2.x = s_src[ea];
-        r2.y = s_src[eb];
-        r2.z = ne;
-        r2.w = e0;
-        R1[idx] = r1;
-        R2[idx] = r2;
-      }
-    }
-  };
-
-  h0 = t.hdr[2 * c0];
-  h1 = t.hdr[2 * c0 + 1];
-  int cs = uniform(h0.x), cnt = uniform(h0.y), ebase = uniform(h0.z), ecnt = uniform(h0.w), sbase = uniform(h1.x),
-      scnt = uniform(h1.y);
-  load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
-  if (c0 + 1 < c1) {
-    h0 = t.hdr[2 * c0 + 2];
-    h1 = t.hdr[2 * c0 + 3];
-  }
-  for (int k = c0; k < c1; k++) {
-    // (the ordering of x stores against the next chunks' early loads: exactly as in k_trsv_packed)
-    static_assert(PK_PJ == 4, "the vmcnt immediate below counts the PK_PJ = 4 x stores per thread of the previous chunk");
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    lds_barrier();
-    store_chunk(cnt, ecnt, scnt);
-    const int cur_cs = cs, n_pos = cnt, n_seg = scnt;
-    lds_barrier();
-    repack(n_pos);
-    if (k + 1 < c1) {
-      cs = uniform(h0.x); cnt = uniform(h0.y); ebase = uniform(h0.z); ecnt = uniform(h0.w);
-      sbase = uniform(h1.x); scnt = uniform(h1.y);
-      load_chunk(cs, cnt, ebase, ecnt, sbase, scnt);
-      if (k + 2 < c1) {
-        h0 = t.hdr[2 * k + 4];
-        h1 = t.hdr[2 * k + 5];
-      }
-    }
-    lds_barrier();                                            // the records are complete
-    if (tid < 64) {                                           // the walker wave; no barrier until the chunk is done
-      constexpr int PK_U = 16;
-      const int lane = tid;
-      // Software pipeline: while level lv is solved (x reads -> FMAs -> ring write: the only work that depends on the
-      // previous level), the records of level lv + 1 and the bound of level lv + 2 are already requested -- neither
-      // depends on x.  LDS operations of one wave retire in order, so waiting for the older requests never waits for
-      // a younger one.
-      auto solve_one = [&](int idx, const pk_dbl2 &r0, const pk_dbl2 &r1, const pk_int4 &r2) {
-        const int ne = r2.z, e0 = r2.w;
-        const double x0 = *reinterpret_cast<const double *>(lds_bytes + r2.x);
-        const double x1 = *reinterpret_cast<const double *>(lds_bytes + r2.y);
-        double sacc = r0.x;
-        if (0 < ne) sacc -= r1.x * x0;
-        if (1 < ne) sacc -= r1.y * x1;
-        if constexpr (!LONG) {
-          for (int e = e0 + 2; e < e0 + ne; e++)
-            sacc -= s_val[e] * *reinterpret_cast<const double *>(lds_bytes + s_src[e]);
-        } else {
-          for (int e = e0 + 2; e < e0 + ne; e += PK_U) {
-            double v4[PK_U], x4[PK_U];
-            int a4[PK_U];
-#pragma unroll
-            for (int u = 0; u < PK_U; u++) {
-              const int eu = min(e + u, e0 + ne - 1);
-              a4[u] = s_src[eu];
-              v4[u] = s_val[eu];
-            }
-#pragma unroll
-            for (int u = 0; u < PK_U; u++) x4[u] = *reinterpret_cast<const double *>(lds_bytes + a4[u]);
-#pragma unroll
-            for (int u = 0; u < PK_U; u++)
-              if (e + u < e0 + ne) sacc -= v4[u] * x4[u];
-          }
-        }
-        ring[(cur_cs + idx) & (PK_RING - 1)] = unit ? sacc : sacc / r0.y;
-      };
-      int l_lo = 0, l_hi = uniform(s_seg[0]);
-      int hi_next = s_seg[min(1, n_seg - 1)];                 // requested now, read (as a uniform) one level later
-      pk_dbl2 c0r = {0.0, 1.0}, c1r = {0.0, 0.0};
-      pk_int4 c2r = {0, 0, 0, 0};
-      {
-        const int idx = min(lane, max(l_hi - 1, 0));
-        c0r = R0[idx]; c1r = R1[idx]; c2r = R2[idx];
-      }
-      for (int lv = 0; lv < n_seg; lv++) {
-        // the next level's first 64 records (clamped into the chunk: lanes past the level's end are masked below)
-        const int n_lo = l_hi, n_hi = uniform(hi_next);
-        hi_next = s_seg[min(lv + 2, n_seg - 1)];
-        const int nidx = min(n_lo + lane, n_pos - 1);
-        const pk_dbl2 n0 = R0[nidx], n1 = R1[nidx];
-        const pk_int4 n2 = R2[nidx];
-        // this level
-        if (l_lo + lane < l_hi) solve_one(l_lo + lane, c0r, c1r, c2r);
-        for (int base = l_lo + 64; base < l_hi; base += 64) { // a level wider than a wave: the other rows one trip at a time
-          const int idx = base + lane;
-          if (idx < l_hi) solve_one(idx, R0[idx], R1[idx], R2[idx]);
-        }
-        c0r = n0; c1r = n1; c2r = n2;
-        l_lo = n_lo;
-        l_hi = n_hi;
-      }
-    }
-    lds_barrier();                                            // the chunk's x values are in the ring
-#pragma unroll
-    for (int j = 0; j < PK_PJ; j++) {
-      const int idx = min(tid + PK_T * j, n_pos - 1);
-      __hip_atomic_store(x + w_row[j], ring[(cur_cs + idx) & (PK_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ---- the walk of narrow levels, round 3 (k_trsv_walk2, the default) -------------------------------------------------
-// k_trsv_walk1 showed what one walker wave costs when it issues a level's bookkeeping itself and the other waves idle
-// while it walks.  Here the work is split by kind, and everything that does not depend on x leaves the dependent chain:
+// A first form with ONE walker wave that issued a level's bookkeeping itself while the other waves idled lost to the
+// four-wave packed walk (36.5 vs 32.2 ms, docs/experiments.md; removed in round 5).  Here the work is split by kind, and everything that does not depend on x leaves the dependent chain:
 //   * POSITION SPACE.  The solve runs on bp[i] = b[order[i]] and xp[i] (gathered / scattered by the whole chip around it:
 //     two ~10 us launches), so the one workgroup that walks streams contiguous right-hand sides and results.  A single
 //     CU sustains few misses at a time (~15-30 GB/s from memory): the row-indexed b[row] / x[row] of a chunk were two
@@ -991,106 +777,6 @@ k_trsv_walk2(Walk2Tri t, int c0, int c1, const double *__restrict__ bp, double *
   w2_barrier();
 }
 
-// ---- synchronisation-free triangular solve ---------------------------------------------------------------------
-// Level scheduling pays a barrier (or a launch) per dependency level: 57 436 levels on the G3_circuit-like factor in
-// natural order = 245 ms per application (round 1).  Here ONE launch solves the whole triangle: waves take chunks of
-// 64 consecutive rows (in dependency order: ascending for the lower, descending for the upper solve) from a global
-// counter, one row per lane, and a lane walks its row entry by entry IN STORED ORDER -- the arithmetic of solve_row,
-// bit for bit -- waiting for each x[c] it needs:
-//  * c in the wave's own chunk: the producing lane's result comes by a cross-lane read (ds_bpermute) as soon as
-//    that lane has finished -- a chain of consecutive rows costs a few dozen cycles per row, not a memory round trip;
-//  * c in an earlier chunk: x[] is pre-filled with a NaN sentinel and every result is ONE 8-byte write-through store
-//    (sc1), so "is it ready" and "what is it" are the same 8-byte sc1 load: the value is its own flag, nothing can be
-//    observed half-done (MI355X_MICROARCH: 8-byte granules, hand-off without a separate flag).
-// Progress: a wave only ever waits for rows of chunks handed out BEFORE its own, i.e. held by waves that are already
-// running, whatever order the hardware dispatched workgroups in; the earliest unfinished chunk never waits for anybody.
-// Every wait is bounded (TRSV_MAX_POLLS, far beyond any real wait): on overflow the kernel raises *err and finishes
-// with the values it has, so a launch always drains.
-constexpr unsigned long long TRSV_SENTINEL = 0x7FF8C0DECA5C0DE5ull;   // a quiet NaN no computation produces
-constexpr int TRSV_MAX_POLLS = 1 << 22;
-
-__global__ void k_fill_sentinel(int64_t n, double *x, int *counter) {
-  const double sent = __longlong_as_double((long long)TRSV_SENTINEL);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = sent;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
-}
-
-__device__ __forceinline__ double shfl_f64(double v, int src_lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
-  hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ void __launch_bounds__(256)
-k_trsv_syncfree(int n, int flags, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
-                const double *__restrict__ b, double *x, int *counter, int *err) {
-  const bool lower = flags & 1, unit = flags & 2;
-  const int lane = threadIdx.x & 63;
-  const int n_chunks = (n + 63) >> 6;
-  while (true) {
-    int chunk = 0;
-    if (lane == 0) chunk = atomicAdd(counter, 1);
-    chunk = __builtin_amdgcn_readfirstlane(chunk);
-    if (chunk >= n_chunks) break;
-    const int base = chunk << 6, i = base + lane;              // position in dependency order
-    const bool active = i < n;
-    const int r = active ? (lower ? i : n - 1 - i) : 0;
-    int k = active ? rp[r] : 0;
-    const int end = active ? rp[r + 1] : 0;
-    double s = active ? b[r] : 0.0, diag = 0.0, xr = 0.0;
-    int fin = active ? 0 : 1, polls = 0;
-    // Two kinds of step alternate.  FAST steps (no global load in them): diagonal entries and entries whose producer
-    // is a lane of this wave that has finished -- a run of consecutive dependent rows advances at cross-lane speed.
-    // When no lane can take a fast step any more, ONE poll of x[c] for the lanes that wait on an earlier chunk.
-    int c = 0, kind = 0, src = lane;                            // kind: 0 none, 1 diagonal/skip, 2 in-wave, 3 earlier chunk
-    double v = 0.0;
-    bool fetched = false;                                       // (c, v, kind, src) describe entry k
-    while (__ballot(!fin) != 0ull) {                            // wave-uniform
-      bool progress;
-      do {
-        progress = false;
-        if (!fin && !fetched && k < end) {
-          c = ci[k];
-          v = val[k];
-          if (c == r) kind = 1;
-          else if (lower ? c > r : c < r) kind = 1;             // not in this triangle (extract_triangle leaves none)
-          else {
-            const int pos = lower ? c : n - 1 - c;              // the producer's position in dependency order (< i)
-            if (pos >= base) { kind = 2; src = pos - base; }
-            else kind = 3;
-          }
-          fetched = true;
-        }
-        const int want = (!fin && fetched && kind == 2) ? src : lane;
-        const double x_in = shfl_f64(xr, want);                 // all lanes take part
-        const int fin_in = __builtin_amdgcn_ds_bpermute(want << 2, fin);
-        if (!fin && fetched) {
-          if (kind == 1) {
-            if (c == r) diag = v;
-            k++; fetched = false; progress = true;
-          } else if (kind == 2 && fin_in) {
-            s -= v * x_in;
-            k++; fetched = false; progress = true;
-          }
-        }
-        if (!fin && !fetched && k == end) {
-          xr = unit ? s : s / diag;
-          __hip_atomic_store(x + r, xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 8-byte write-through store
-          fin = 1;
-          progress = true;
-        }
-      } while (__ballot(progress) != 0ull);
-      if (!fin && fetched && kind == 3) {                       // one poll, then back to the fast steps
-        const double xv = __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned long long)__double_as_longlong(xv) != TRSV_SENTINEL) { s -= v * xv; k++; fetched = false; }
-        else if (++polls > TRSV_MAX_POLLS) { *err = 1; s -= v * xv; k++; fetched = false; }
-        else __builtin_amdgcn_s_sleep(1);
-      }
-    }
-  }
-}
-
 __global__ void k_scale(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r, double *__restrict__ z) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     z[i] = r[i] * dinv[i];
@@ -1121,8 +807,6 @@ struct TriFactor {
   bool w2_ok = false, walk2 = false;                // walk2: this factor is solved by k_trsv_walk2 (position space)
   DevBuf<int4> w2_hdr;
   mutable DevBuf<unsigned long long> w2_dbg;
-  DevBuf<int> sync;                                   // [0] chunk counter, [1] error flag of the sync-free solve
-  int sf_grid = 0;
 
   int build(int n_, bool lower_, const std::vector<int> &h_rp, const std::vector<int> &h_ci,
             const std::vector<double> &h_val) {
@@ -1177,14 +861,6 @@ struct TriFactor {
     PC_TRY(val.upload(h_val));
     PC_TRY(order.upload(ord));
     PC_TRY(level_ptr.upload(lp));
-    PC_TRY(sync.alloc(2));
-    PC_TRY(hipMemset(sync.p, 0, 2 * sizeof(int)));
-    int occ = 0, cus = 0, dev = 0;
-    PC_TRY(hipGetDevice(&dev));
-    PC_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trsv_syncfree, 256, 0));
-    PC_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int want = ((n + 63) / 64 + 3) / 4;
-    sf_grid = std::max(1, std::min(want, std::max(1, occ) * cus));
     return CASK_HIP_OK;
   }
 
@@ -1286,11 +962,6 @@ struct TriFactor {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_packed<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK_LDS_BYTES) == hipSuccess;
-    ok = ok && lds_max >= (int)PK1_LDS_BYTES;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk1<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK1_LDS_BYTES) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsv_walk1<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PK1_LDS_BYTES) == hipSuccess;
     if (!ok) {
       (void)hipGetLastError();
       for (Step &st : steps) st.c0 = -1;
@@ -1477,37 +1148,23 @@ struct TriFactor {
     return CASK_HIP_OK;
   }
 
-  // Level-scheduled by default (runs of narrow levels: the packed walk, k_trsv_packed; CASK_HIP_TRSV=levels keeps the
-  // row-indexed walk of round 1); CASK_HIP_TRSV=syncfree selects the one-launch synchronisation-free solve.  Measured
-  // on the G3_circuit-like ILU(0) factors (57 436 levels, profiles/r02_trsv.txt): levels 225 ms, sync-free 210-270 ms
-  // per PCG pass -- no better.  The critical path is 57 K DEPENDENT rows either way, and a dependent step costs
-  // ~2 us in both schedules: in the sync-free kernel every step of a lane re-reads its row entry from L1/L2 and the
-  // wave's loop iteration is as slow as its slowest lane, which is usually one polling a remote x[c].  Getting the
-  // in-wave chain down to cross-lane speed needs the row entries in registers and polls that do not block the wave
-  // (loads issued a loop iteration ahead); until then the sync-free solve is a tested option, not the default.
-  // CASK_HIP_TRSV: 1 = syncfree, 2 = levels (row-indexed walk, r1), 3 = walk1 (one walker wave, r3), 4 = walk2 (walker +
-  // stagers + read-ahead, position space), 5 = packed (the four-wave walk, r2).  Unset (0): walk2.
+  // Schedules of a run of narrow levels, bit-identical to each other (tested): walk2 (walker + stagers + read-ahead in
+  // position space, r3: the default), packed (the four-wave walk, r2), levels (the row-indexed walk, r1).
+  // CASK_HIP_TRSV = levels | walk2 | packed forces one.  The one-launch synchronisation-free solve (r2: 210-270 ms per
+  // application against 225 for `levels`) and the single-walker-wave walk (r3: 36.5 against 32.2 ms) were removed in
+  // round 5: measured losses, docs/experiments.md.
   static int forced_mode() {
     static const int mode = [] {
       const char *force = std::getenv("CASK_HIP_TRSV");
       if (!force) return 0;
       const std::string f(force);
-      return f == "syncfree" ? 1 : f == "levels" ? 2 : f == "walk1" ? 3 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : 0;
+      return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : 0;
     }();
     return mode;
   }
-  bool use_syncfree() const { return forced_mode() == 1; }
 
   int solve(const double *d_b, double *d_x, hipStream_t s) const {
     const int flags = (lower ? 1 : 0) | (unit ? 2 : 0);
-    if (n > 0 && use_syncfree()) {
-      const int fill_grid = (int)std::min<int64_t>(1024, ((int64_t)n + 255) / 256);
-      hipLaunchKernelGGL(k_fill_sentinel, dim3(fill_grid), dim3(256), 0, s, (int64_t)n, d_x, sync.p);
-      hipLaunchKernelGGL(k_trsv_syncfree, dim3(sf_grid), dim3(256), 0, s, n, flags, rp.p, ci.p, val.p, d_b, d_x, sync.p,
-                         sync.p + 1);
-      PC_TRY(hipGetLastError());
-      return CASK_HIP_OK;
-    }
     if (walk2 && n > 0 && w2_bp.p) {                            // the whole solve in position space
       const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_early.p, w2_hdr.p};
       const int pg = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256), u = unit ? 1 : 0;
@@ -1550,10 +1207,6 @@ struct TriFactor {
       if (st.wide)
         hipLaunchKernelGGL(k_trsv_level, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, flags,
                            order.p, rp.p, ci.p, val.p, d_b, d_x);
-      else if (packed_ok && st.c0 >= 0 && forced_mode() == 3 && st.long_rows)     // CASK_HIP_TRSV=walk1: one walker wave (r3)
-        hipLaunchKernelGGL(k_trsv_walk1<true>, dim3(1), dim3(PK_T), PK1_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
-      else if (packed_ok && st.c0 >= 0 && forced_mode() == 3)
-        hipLaunchKernelGGL(k_trsv_walk1<false>, dim3(1), dim3(PK_T), PK1_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else if (packed_ok && st.c0 >= 0 && st.long_rows)
         hipLaunchKernelGGL(k_trsv_packed<true>, dim3(1), dim3(PK_T), PK_LDS_BYTES, s, pk, st.c0, st.c1, unit ? 1 : 0, d_b, d_x);
       else if (packed_ok && st.c0 >= 0)
@@ -1625,6 +1278,8 @@ struct McFactor {
   std::vector<int> h_prp, h_pci;        // P A P^T (unfactored), CSR with ascending columns
   std::vector<double> h_pva;
   cask_hip_matrix *product = nullptr;   // engine handle of P A P^T (owned; built by the PCG driver on first use)
+  uint64_t fingerprint = 0;             // of the arrays this was built from: the PCG driver multiplies with the cached
+                                        //   P A P^T only for a handle whose matrix has the same fingerprint
   ~McFactor() {
     if (product) (void)cask_hip_csr_destroy(product);
   }
@@ -1998,6 +1653,14 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
   if (kind == CASK_HIP_PRECOND_ILU0_MC) {
     rc = build_mc(n, row_ptr, col_ind, values, p->mc);
     if (rc) return rc;
+    uint64_t fp = 0;
+    for (int64_t r = 0; r <= n; r++) fp += csr_fp_row((uint64_t)r, (uint64_t)row_ptr[r]);
+    for (int64_t k = 0; k < nnz; k++) {
+      uint64_t bits;
+      std::memcpy(&bits, values + k, 8);
+      fp += csr_fp_entry((uint64_t)k, (uint64_t)col_ind[k], bits);
+    }
+    p->mc.fingerprint = fp;
     *out = p.release();
     return CASK_HIP_OK;
   }
@@ -2049,6 +1712,7 @@ int cask_hip_precond_mc_view(cask_hip_precond *p, cask_hip_mc_view *v) {
   if (!p || !v || p->kind != CASK_HIP_PRECOND_ILU0_MC) return 0;
   v->n = p->mc.n;
   v->n_colors = p->mc.n_colors;
+  v->fingerprint = p->mc.fingerprint;
   v->d_perm = p->mc.perm.p;
   v->h_rp = p->mc.h_prp.data();
   v->h_ci = p->mc.h_pci.data();
@@ -2121,7 +1785,7 @@ int cask_hip_precond_apply(cask_hip_precond *p, const double *r, double *z) {
   int rc = cask_hip_precond_apply_device(p, p->d_r.p, p->d_z.p, nullptr);
   if (rc) return rc;
   PC_TRY(hipMemcpy(z, p->d_z.p, (size_t)p->n * sizeof(double), hipMemcpyDeviceToHost));
-  return cask_hip_precond_check(p);
+  return CASK_HIP_OK;
 }
 
 int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32_t *col_ind, const double *values,
@@ -2145,9 +1809,6 @@ int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32
   rc = t.solve(b.p, out.p, nullptr);
   if (rc) return rc;
   PC_TRY(hipMemcpy(x, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  int sync_err = 0;
-  PC_TRY(hipMemcpy(&sync_err, t.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
-  if (sync_err) return report_failure(CASK_HIP_ERR_RUNTIME, "triangular solve: a dependency never arrived (poll limit reached)");
   return CASK_HIP_OK;
 }
 
@@ -2157,14 +1818,4 @@ int cask_hip_precond_rows(const cask_hip_precond *p) { return p ? p->n : -1; }
 
 const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p) {
   return p && p->kind == CASK_HIP_PRECOND_JACOBI && p->n > 0 ? p->dinv.p : nullptr;
-}
-
-// After a host synchronisation: did a sync-free triangular solve of this preconditioner give up on a dependency?
-int cask_hip_precond_check(cask_hip_precond *p) {
-  if (!p || p->kind == CASK_HIP_PRECOND_JACOBI || p->kind == CASK_HIP_PRECOND_ILU0_MC) return CASK_HIP_OK;
-  int e[2] = {0, 0};
-  if (p->L.sync.p) PC_TRY(hipMemcpy(&e[0], p->L.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
-  if (p->U.sync.p) PC_TRY(hipMemcpy(&e[1], p->U.sync.p + 1, sizeof(int), hipMemcpyDeviceToHost));
-  if (e[0] || e[1]) return report_failure(CASK_HIP_ERR_RUNTIME, "triangular solve: a dependency never arrived (poll limit reached)");
-  return CASK_HIP_OK;
 }

@@ -28,6 +28,9 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;               // (optional: cask_hip_rccl_comm_info reports -1 without them)
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string error;
 };
 
@@ -53,6 +56,9 @@ void load_rccl(RcclApi &a) {
   CASK_SYM(GroupEnd, ncclGroupEnd);
   CASK_SYM(GetErrorString, ncclGetErrorString);
 #undef CASK_SYM
+  a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.handle, "ncclCommCount"));
+  a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(dlsym(a.handle, "ncclCommCuDevice"));
+  a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.handle, "ncclCommUserRank"));
 }
 
 RcclApi &api() {                                              // loaded once (thread-safe static initialisation)
@@ -124,6 +130,23 @@ int cask_hip_rccl_comm_destroy(cask_hip_comm *c) {
   RcclApi &a = api();
   if (c->comm && a.CommDestroy) (void)a.CommDestroy(c->comm);
   delete c;
+  return CASK_HIP_OK;
+}
+
+int cask_hip_rccl_comm_info(const cask_hip_comm *c, int32_t *nranks, int32_t *rank, int32_t *device, char *pci_bus_id,
+                            int32_t pci_len) {
+  if (!c) return report_failure(CASK_HIP_ERR_INVALID, "communicator is NULL");
+  RcclApi &a = api();
+  int v = -1;
+  if (nranks) *nranks = (a.CommCount && a.CommCount(c->comm, &v) == ncclSuccess) ? v : -1;
+  if (rank) *rank = (a.CommUserRank && a.CommUserRank(c->comm, &v) == ncclSuccess) ? v : -1;
+  int dev = -1;
+  if (!(a.CommCuDevice && a.CommCuDevice(c->comm, &dev) == ncclSuccess)) dev = -1;
+  if (device) *device = dev;
+  if (pci_bus_id && pci_len > 0) {
+    pci_bus_id[0] = 0;
+    if (dev >= 0 && hipDeviceGetPCIBusId(pci_bus_id, pci_len, dev) != hipSuccess) pci_bus_id[0] = 0;
+  }
   return CASK_HIP_OK;
 }
 

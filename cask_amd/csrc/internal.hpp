@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <stdint.h>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -62,9 +64,23 @@ struct DevEvent {
 // Between cask_hip.hip (the PCG driver) and cask_hip_precond.hip.
 struct cask_hip_precond;
 int cask_hip_precond_rows(const cask_hip_precond *p);      // order of the matrix the preconditioner was built from
-int cask_hip_precond_check(cask_hip_precond *p);           // after a host sync: error flag of the sync-free triangular solves
 // Jacobi: the device vector of 1/diag (the PCG driver folds the scaling into its update kernels); NULL otherwise
 const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p);
+
+// Content fingerprint of a CSR matrix: a wrapping 64-bit sum of one mixed word per row pointer and per nonzero
+// (position, column, value bits), so that it can be computed in any order -- on the host over the arrays a
+// preconditioner is built from, on the device over a handle's arrays -- and compared.  It answers "is this the matrix
+// the multicolour preconditioner cached a permuted copy of?" (same pattern with other values must NOT match).
+__host__ __device__ inline uint64_t csr_fp_mix(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t csr_fp_row(uint64_t r, uint64_t rp) { return csr_fp_mix((r << 32) ^ rp ^ 0xA5A5A5A500000000ull); }
+__host__ __device__ inline uint64_t csr_fp_entry(uint64_t k, uint64_t col, uint64_t value_bits) {
+  return csr_fp_mix(csr_fp_mix((k << 32) ^ col) ^ value_bits);
+}
 
 // Multicolour ILU(0): the colour-ordered PCG of cask_hip_pcg.  The view gives the driver the permutation (device), the
 // permuted matrix P A P^T (host CSR, to build its product handle once; the handle is owned by the preconditioner) and the
@@ -72,6 +88,7 @@ const double *cask_hip_precond_jacobi_scale(const cask_hip_precond *p);
 struct cask_hip_matrix;
 struct cask_hip_mc_view {
   int n, n_colors, n_part_rz;
+  uint64_t fingerprint;               // of the CSR arrays the preconditioner was built from (csr_fp_*)
   const int *d_perm;
   const int *h_rp, *h_ci;
   const double *h_va;

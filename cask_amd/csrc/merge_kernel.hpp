@@ -2,6 +2,7 @@
 // header because its instantiations are what takes time to compile: merge_ipt*.hip instantiate one
 // items-per-thread value each, in parallel.
 #pragma once
+#include "diag.hpp"
 #include "spmv_common.hpp"
 
 namespace caskhip {
@@ -190,10 +191,11 @@ __device__ __forceinline__ PassScalars pass_scalars(const SolverPass &sp, int lb
   ps.stop = false;
   ps.update_x = false;
   if (sp.first) return ps;
-#if defined(CASK_ABL) && (CASK_ABL & 1)                       // diagnostic build: what do the partial sums cost?
-  ps.beta = 0.5; ps.alpha_prev = 0.0; ps.update_x = sp.xsol != nullptr;
-  return ps;
-#endif
+  if (diag::NO_PARTIALS) {                                    // diagnostic build: what do the partial sums cost?
+    ps.beta = 0.5;
+    ps.update_x = sp.xsol != nullptr;
+    return ps;
+  }
   const double chk = partials_or_scalar(sp.part_chk, sp.n_chk, red);
   ps.alpha_prev = *sp.alpha_prev;
   ps.update_x = sp.xsol != nullptr;
@@ -229,26 +231,17 @@ __device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassSc
   }
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool FAR, bool CRUN = false>
-__device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc, int n_cols, int xlim, int max_gpair,
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool ALIAS = false>
+__device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
                                            double *prod, int *roff, double *xs, const XHalo &halo,
                                            const double *__restrict__ w, double *wl, int lb,
-                                           const SolverPass &sp, const PassScalars &ps,
-                                           const double *__restrict__ farx, const int *__restrict__ far_col) {
+                                           const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
-#if defined(CASK_ABL) && (CASK_ABL & 2)                       // diagnostic build: what does the second window cost?
-  constexpr bool COMP = false;
-#else
-  constexpr bool COMP = EXT == 2;                             // operand composed on the fly: x[c] + beta * x[c + b_off]
-#endif
-#if defined(CASK_ABL) && (CASK_ABL & 4)                       // diagnostic build: what do the own-row updates cost?
-  constexpr bool OWN = false;
-#else
-  constexpr bool OWN = EXT == 2;
-#endif
+  constexpr bool COMP = EXT == 2 && !diag::NO_SECOND_WINDOW;  // operand composed on the fly: x[c] + beta * x[c + b_off]
+  constexpr bool OWN = EXT == 2 && !diag::NO_OWN_ROWS;        // own-row updates of a solver pass
   // 16-byte loads need an even element index: start one element early if the
   // block starts on an odd nonzero (that element belongs to the previous block;
   // its product lands in prod[0] and no row of this block references it).
@@ -303,20 +296,6 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
           xb[COMP ? 2 * u + 1 : 0] = pb.y;
         }
       }
-    } else if (FAR && (d.kind_g & KIND_FAR)) {                // workgroup-uniform
-      // far slots: behind the block's chunks sit the x values of its far columns (d.cmin of them) -- gathered column
-      // panel by column panel by k_far_gather into farx[d.aux ...] just before this launch, or (far_col != NULL:
-      // far_columns = 2) gathered here from x through the block's list of far columns: the list entries are
-      // requested now, the gathers go out behind the stream like a seam block's remote loads
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
-      const int tile_slots = d.cwidth - d.cmin, last_far = max(d.cmin - 1, 0);
-#pragma unroll
-      for (int u = 0; u < XU; u++) {
-        const int cidx = u * wpw + wave;                      // wave-uniform chunk index; slot = 64*cidx + lane
-        if (cidx * 64 < tile_slots) xw[u] = x[min(xchunk[cidx] + lane, xlim)];
-        else if (far_col)           xsrc[u] = (uint64_t)far_col[d.aux + min(cidx * 64 + lane - tile_slots, last_far)];
-        else                        xw[u] = farx[d.aux + min(cidx * 64 + lane - tile_slots, last_far)];
-      }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
 #pragma unroll
@@ -349,45 +328,18 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   // by a slot the block owns -- into record lb*WG + tid: one 12-byte load instead of four 4-byte ones, 1.5
   // instead of 2 bytes per nonzero
   if (C12) {
-#if defined(CASK_ABL) && (CASK_ABL & 16)                      // diagnostic build: what would a FREE slot stream buy? (every block reads block 0's records)
-    const unsigned *rec = ci16 + (size_t)tid * 3;
-#else
-    const unsigned *rec = ci16 + ((size_t)lb * WG + tid) * 3;  // (a 3-vector type would be padded to 16 bytes)
-#endif
+    // (diagnostic build FREE_SLOTS: every block reads block 0's records -- what would a free slot stream buy?)
+    const unsigned *rec = ci16 + ((size_t)(diag::FREE_SLOTS ? 0 : lb) * WG + tid) * 3;  // (a 3-vector type would be padded to 16 bytes)
     c12[0] = stream_load<NT>(rec);
     c12[1] = stream_load<NT>(rec + 1);
     c12[2] = stream_load<NT>(rec + 2);
   }
-  // CRUN (r4): the slots as RUNS of consecutive slots.  The 128 elements a wave takes in one pass u (lane l: elements
-  // 2l, 2l+1 of the pass) are described by one record: a 128-bit mask of the elements that start a run and, per run,
-  // delta = (first slot - first element) as int16, two per dword -- slot(e) = e + delta[run(e)].  FEM matrices with
-  // several unknowns per node (cant: 3 x 3 blocks) have ~15 runs per 128 elements: 0.4 instead of 1.5 bytes per
-  // nonzero.  The mask is the same for the whole wave (scalar loads), lane j fetches dword j of the deltas.
-  typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-  uint4v rmask[CRUN ? IPT / 2 : 1];
-  unsigned rtab[CRUN ? IPT / 2 : 1];
-  if (CRUN) {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
-    const int stride = 4 + rdesc.y;                           // dwords: mask + deltas
-    const int jd = min(lane, rdesc.y - 1);
-#pragma unroll
-    for (int u = 0; u < IPT / 2; u++) {
-      const unsigned *rec = ci16 + (size_t)__builtin_amdgcn_readfirstlane(rdesc.x + (u * wpw + wave) * stride);
-      rmask[CRUN ? u : 0] = *reinterpret_cast<const uint4v *>(rec);
-      rtab[CRUN ? u : 0] = stream_load<NT>(rec + 4 + jd);
-    }
-  }
 #pragma unroll
   for (int u = 0; u < IPT / 2; u++) {
-#if defined(CASK_ABL) && (CASK_ABL & 8)                       // diagnostic build: what do thread-consecutive (64-byte strided) stream loads cost?
-    const int p = min(first + (IPT / 2) * tid + u, last);
-#elif defined(CASK_ABL) && (CASK_ABL & 32)                    // diagnostic build: FREE values (every block streams block 0's: L2 hits) -- is the launch HBM-bound at all?
-    const int p = min(u * WG + tid, last);
-#else
-    const int p = min(first + u * WG + tid, last);           // clamped: redundant loads hit the same line
-#endif
+    // clamped: redundant loads hit the same line  (diagnostic build FREE_VALUES: every block streams block 0's values)
+    const int p = min((diag::FREE_VALUES ? 0 : first) + u * WG + tid, last);
     v[u] = stream_load<NT>(val2 + p);
-    if (C12 || CRUN) continue;
+    if (C12) continue;
     if (C16) c16[u] = stream_load<NT>(ci16 + p);
     else     c[u] = stream_load<NT>(ci2 + p);
   }
@@ -397,13 +349,6 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
       xw[u] = load_at(xsrc[u]);
       if (COMP) xb[COMP ? u : 0] = load_at(xsrc[u] + 8 * (uint64_t)sp.b_off);
     }
-  }
-  if (FAR && XU > 0 && far_col && (d.kind_g & KIND_FAR)) {    // direct far gathers (workgroup-uniform)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpw = WG >> 6;
-    const int tile_slots = d.cwidth - d.cmin;
-#pragma unroll
-    for (int u = 0; u < XU; u++)
-      if ((u * wpw + wave) * 64 >= tile_slots) xw[u] = x[(int)xsrc[u]];
   }
   // dot epilogue (EXT kernels, launch-uniform test): the block's slice of w, requested behind the stream
   // (youngest loads: nothing waits for them until the products are stored), parked in LDS for the row sums
@@ -470,24 +415,6 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
       c[IPT / 2 > 3 ? 3 : 0].x = (int)((q2 >> 8) & 0xfffu);
       c[IPT / 2 > 3 ? 3 : 0].y = (int)(q2 >> 20);
     }
-  } else if (CRUN) {                                          // the slots from the run records (the stream is still landing)
-    const int lane = tid & 63;
-    const unsigned e0 = 2u * (unsigned)lane, sel = (unsigned)lane >> 4, bit = e0 & 31u;
-#pragma unroll
-    for (int u = 0; u < IPT / 2; u++) {
-      const uint4v mk = rmask[CRUN ? u : 0];
-      const unsigned c0 = __builtin_popcount(mk.x), c01 = c0 + __builtin_popcount(mk.y), c012 = c01 + __builtin_popcount(mk.z);
-      const unsigned mw = sel == 0 ? mk.x : sel == 1 ? mk.y : sel == 2 ? mk.z : mk.w;
-      const unsigned pre = sel == 0 ? 0u : sel == 1 ? c0 : sel == 2 ? c01 : c012;
-      const unsigned r0 = pre + __builtin_popcount(mw & ((2u << bit) - 1u)) - 1u;       // run of element e0 (bit 0 of a pass is set)
-      const unsigned r1 = r0 + ((mw >> (bit + 1u)) & 1u);                                // ... of e0 + 1
-      const int t0 = __builtin_amdgcn_ds_bpermute((int)((r0 >> 1) << 2), (int)rtab[CRUN ? u : 0]);
-      const int t1 = __builtin_amdgcn_ds_bpermute((int)((r1 >> 1) << 2), (int)rtab[CRUN ? u : 0]);
-      const int d0 = (r0 & 1u) ? (t0 >> 16) : (int)(short)(t0 & 0xffff);
-      const int d1 = (r1 & 1u) ? (t1 >> 16) : (int)(short)(t1 & 0xffff);
-      c[u].x = (int)e0 + d0;
-      c[u].y = (int)e0 + 1 + d1;
-    }
   } else if (C16) {                                           // unpack the 16-bit slots only now
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
@@ -499,7 +426,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   // foreign elements: give them a column this block owns, so their gather stays
   // inside the x window / inside x (their products land in slots no row uses); the packed records
   // come with that done
-  if (!C12 && !CRUN) {
+  if (!C12) {
     if (lead && tid == 0) c[0].x = c[0].y;
     if (total & 1) {
 #pragma unroll
@@ -514,6 +441,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
       xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
       xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
     }
+    if (ALIAS) __syncthreads();                               // aliased plans: the window's LDS becomes the products' (merge_block_roll)
   } else if (SEAM) {                                          // gathers, some of them from peers
     uint64_t ex[IPT / 2], ey[IPT / 2];
 #pragma unroll
@@ -563,11 +491,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   CASK_STAMP(3);
 #endif
 #pragma unroll
-#if defined(CASK_ABL) && (CASK_ABL & 8)
-  for (int u = 0; u < IPT / 2; u++) prod2[(IPT / 2) * tid + u] = v[u] * xv[u];
-#else
   for (int u = 0; u < IPT / 2; u++) prod2[u * WG + tid] = v[u] * xv[u];
-#endif
   if ((EXT == 1 && w) || (EXT == 2 && w)) {                   // solver pass: w != NULL means "leave the dot shares behind"
     wl[tid] = w0;
     wl[tid + WG] = w1;
@@ -576,36 +500,37 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, const int2v rdesc
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR, bool CRUN = false>
-__device__ __forceinline__ void merge_block(const BlockDesc &d, const int2v rdesc, int n_cols, int xlim, int max_gpair,
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool ALIAS = false>
+__device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs,
                                             const XHalo &halo, const DotEpilogue &dot, int lb,
-                                            const SolverPass &sp, const PassScalars &ps,
-                                            const double *__restrict__ farx, const int *__restrict__ far_col) {
+                                            const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
   // Launches with a dot epilogue carry 2*WG + 16 doubles more of dynamic LDS: the block's slice of w and
   // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
   // slower (8.75 -> 8.88 us per launch in an interleaved A/B) although the occupancy calculator still
   // reports 6 workgroups per CU for 26 896 bytes (tools/lds_granule.hip); the cause was not established.
-  double *wl = xs + XU * WG, *dot_red = wl + 2 * WG;
+  // (ALIAS: the window shares the products' space, so the slice of w follows the row offsets)
+  double *wl = ALIAS ? reinterpret_cast<double *>(roff + 2 * WG) : xs + XU * WG, *dot_red = wl + 2 * WG;
   // the dot operand: EXT == 1 a vector (dot.w); a solver pass composes it (dot.dot_part != NULL asks for the shares)
   const bool want_dot = EXT == 2 ? dot.dot_part != nullptr : (EXT == 1 && dot.w != nullptr);   // launch-uniform
   const double *wsrc = EXT == 2 ? (want_dot ? x : nullptr) : dot.w;
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, false, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                            halo, wsrc, wl, lb, sp, ps, farx, far_col);
+    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                                       halo, wsrc, wl, lb, sp, ps);
   else
-    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, FAR, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                             halo, wsrc, wl, lb, sp, ps, farx, far_col);
+    merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                                               halo, wsrc, wl, lb, sp, ps);
   const double *wrow = want_dot ? wl : nullptr;               // w[row_start + r] sits in wl[r]
-#if defined(CASK_ABL) && (CASK_ABL & 64)                      // diagnostic build: what does the tail (row sums + y) cost?
-  if (!EXT) { if (tid == 0 && prod[0] == 1.2345e300) y[d.row_start] = 0.0; return; }
-#endif
+  if (diag::NO_TAIL && !EXT) {                                // diagnostic build: what does the tail (row sums + y) cost?
+    if (tid == 0 && prod[0] == 1.2345e300) y[d.row_start] = 0.0;
+    return;
+  }
 
   double dsum;
   switch (d.kind_g & 0xff) {
@@ -629,6 +554,210 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, const int2v rdes
   }
 }
 
+// ------------------------------------------------------------------------------------------ rolling row sums (r5)
+// The lean product (EXT = 0, no skewed blocks) with the row sums ROLLED INTO the stream wait.  The stream of a block
+// arrives in IPT/2 steps (step u = the 16-byte pairs [u*WG, (u+1)*WG) of the block, returned in issue order), spread
+// over the microseconds the memory system needs for everybody's bytes; in k_spmv_merge's plain form the products of
+// every step are parked as they arrive but the row sums wait for the last one, so the whole row-sum phase (barrier,
+// row offsets, a lane's dependent run of LDS reads, DPP butterfly, y stores: ~1 us of the launch, profiles/
+// r04_run_records.txt "no tail") sits exposed behind the block's last bytes.  Here a barrier follows EVERY step and a
+// row is summed in the step that completes it: lane group g = tid / G owns row g (the planner's G makes that one
+// row per group; G = 1 blocks may hold up to 2*WG rows: a second row per thread), sums it with exactly the additions
+// of reduce_rows_plain (same order => the same bits), keeps the sum in a register and stores it once the wave has no
+// load left to wait for (a store issued between the waits would count in vmcnt behind the younger loads and turn the
+// next counted wait into a wait for them too).  After the last step only the rows that END in it are left: a quarter
+// of the phase (IPT = 8), run by the one or two waves that own those rows.
+// ALIAS: the products are parked OVER the x window (dead once every wave has gathered its x values: one more barrier,
+// in the shadow of the stream): 18.4 instead of 26.6 KB of LDS per 256 x 8 block -> 8 instead of 6 workgroups per CU,
+// the whole 2 021-block grid of the cant-like matrix resident in ONE round (r3 stamps: a quarter of the workgroups
+// started after 7.5 us, a second, thin round that pays head and tail again).
+template <int G>
+__device__ __forceinline__ double roll_row_sum(const double *prod, int s, int e, int j) {
+  double acc = 0.0;
+#pragma unroll 4
+  for (int k = s + j; k < e; k += G) acc += prod[k];
+  return group_sum<G>(acc);                                   // all lanes of the group take this path together
+}
+__device__ __forceinline__ double roll_row_sum_g(int G, const double *prod, int s, int e, int j) {   // G: workgroup-uniform
+  switch (G) {
+    case 1:  return roll_row_sum<1>(prod, s, e, j);
+    case 2:  return roll_row_sum<2>(prod, s, e, j);
+    case 4:  return roll_row_sum<4>(prod, s, e, j);
+    case 8:  return roll_row_sum<8>(prod, s, e, j);
+    case 16: return roll_row_sum<16>(prod, s, e, j);
+    case 32: return roll_row_sum<32>(prod, s, e, j);
+    default: return roll_row_sum<64>(prod, s, e, j);
+  }
+}
+
+template <int IPT>
+__device__ __forceinline__ void roll_steps(const BlockDesc &d, const dbl2 (&v)[IPT / 2], const dbl2 (&xv)[IPT / 2],
+                                           double *prod, const int *roff, double *__restrict__ y) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  const int G = d.kind_g & 0xff, lg = __builtin_ctz(G);        // lanes per row (a power of two), workgroup-uniform
+  const int rows_per_pass = WG >> lg, j = tid & (G - 1), g = tid >> lg;
+  // this group's row(s): offsets read once, in the shadow of the stream (roff is parked behind the first barrier)
+  const int r0 = g, r1 = g + rows_per_pass;
+  bool pend0 = r0 < d.n_rows, pend1 = G == 1 && r1 < d.n_rows; // row exists and is not summed yet
+  const bool have0 = pend0, have1 = pend1;
+  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+  if (pend0) { s0 = roff[r0]; e0 = roff[r0 + 1]; }
+  if (pend1) { s1 = roff[r1]; e1 = roff[r1 + 1]; }
+  double acc0 = 0.0, acc1 = 0.0;
+  dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    // the products of step u are formed HERE, behind step u - 1's barrier: without the pin the compiler forms all of
+    // them up front (they are pure register arithmetic) and with them waits for the whole stream before the first
+    // barrier -- the first build of this kernel did exactly that: four barriers and no overlap, 8.3 -> 11.0 us
+    double va = v[u].x, vb = v[u].y;
+    asm volatile("" : "+v"(va), "+v"(vb));                    // (waits for stream step u only: vmcnt retires in order)
+    dbl2 pr;
+    pr.x = va * xv[u].x;
+    pr.y = vb * xv[u].y;
+    prod2[u * WG + tid] = pr;
+    const bool last = u == IPT / 2 - 1;
+    if (last) {                                               // no load left to wait for: the sums this wave already holds
+      if (have0 && !pend0 && j == 0) y[d.row_start + r0] = acc0;
+      if (have1 && !pend1 && j == 0) y[d.row_start + r1] = acc1;
+    }
+    __syncthreads();
+    const int bound = 2 * (u + 1) * WG;                       // products [0, bound) are parked
+    if (pend0 && (last || e0 <= bound)) {                     // group-uniform
+      acc0 = roll_row_sum_g(G, prod, s0, e0, j);
+      pend0 = false;
+      if (last && j == 0) y[d.row_start + r0] = acc0;
+    }
+    if (pend1 && (last || e1 <= bound)) {                     // (G == 1 blocks with more rows than threads only)
+      acc1 = roll_row_sum<1>(prod, s1, e1, j);
+      pend1 = false;
+      if (last) y[d.row_start + r1] = acc1;
+    }
+  }
+  // (a plan whose block holds more rows than two passes cover does not exist -- build_merge_blocks picks G <= WG /
+  // rows and caps a block at 2*WG - 1 rows -- but a wrong y would be silent: finish any such rows the plain way)
+  for (int r = g + (G == 1 ? 2 : 1) * rows_per_pass; r < d.n_rows; r += rows_per_pass) {
+    const double acc = roll_row_sum_g(G, prod, roff[r], roff[r + 1], j);
+    if (j == 0) y[d.row_start + r] = acc;
+  }
+}
+
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool ALIAS>
+__device__ __forceinline__ void merge_block_roll(const BlockDesc &d, int xlim, int max_gpair,
+                                                 const int *__restrict__ rp, const int *__restrict__ ci,
+                                                 const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                                 const double *__restrict__ val, const double *__restrict__ x,
+                                                 double *__restrict__ y, double *prod, int *roff, double *xs, int lb) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;   // (see merge_load)
+  const int npairs = (total + 1) >> 1;
+  // issue order as in merge_load: x window, row offsets, slot record, value stream
+  double xw[XU > 0 ? XU : 1];
+  if (XU > 0) {
+    if (WIDE) {
+      const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x);
+      const int plim = xlim >> 1;
+#pragma unroll
+      for (int u = 0; u < XU / 2; u++) {
+        const dbl2 pr = x2[min((d.cmin >> 1) + u * WG + tid, plim)];
+        xw[2 * u] = pr.x;
+        xw[2 * u + 1] = pr.y;
+      }
+    } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+#pragma unroll
+      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, xlim)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, xlim)];
+    }
+  }
+  const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
+  const int ro1 = rp[d.row_start + min(tid + WG, d.n_rows)] - base;
+  dbl2 v[IPT / 2];
+  int2v c[IPT / 2];
+  unsigned c16[IPT / 2];
+  unsigned c12[3] = {0u, 0u, 0u};
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
+  const int first = base >> 1;
+  const int last = min(first + max(npairs - 1, 0), max_gpair);
+  if (C12) {
+    const unsigned *rec = ci16 + ((size_t)lb * WG + tid) * 3;
+    c12[0] = stream_load<NT>(rec);
+    c12[1] = stream_load<NT>(rec + 1);
+    c12[2] = stream_load<NT>(rec + 2);
+  }
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int p = min(first + u * WG + tid, last);
+    v[u] = stream_load<NT>(val2 + p);
+    if (C12) continue;
+    if (C16) c16[u] = stream_load<NT>(ci16 + p);
+    else     c[u] = stream_load<NT>(ci2 + p);
+  }
+  if (WIDE) {
+    dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
+#pragma unroll
+    for (int u = 0; u < XU / 2; u++) {
+      dbl2 pr;
+      pr.x = xw[2 * u];
+      pr.y = xw[2 * u + 1];
+      xs2[u * WG + tid] = pr;
+    }
+  } else if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
+  }
+  roff[tid] = ro0;
+  roff[tid + WG] = ro1;
+  __syncthreads();                                            // (also for XU = 0: the row offsets are read right below)
+  if (C12) {
+    static_assert(!C12 || IPT == 8, "12-bit packed slots are laid out for 8 items per thread");
+    const unsigned q0 = c12[0], q1 = c12[1], q2 = c12[2];
+    c[0].x = (int)(q0 & 0xfffu);
+    c[0].y = (int)((q0 >> 12) & 0xfffu);
+    c[1].x = (int)((q0 >> 24) | ((q1 & 0xfu) << 8));
+    c[1].y = (int)((q1 >> 4) & 0xfffu);
+    if (IPT / 2 > 2) {
+      c[IPT / 2 > 2 ? 2 : 0].x = (int)((q1 >> 16) & 0xfffu);
+      c[IPT / 2 > 2 ? 2 : 0].y = (int)((q1 >> 28) | ((q2 & 0xffu) << 4));
+      c[IPT / 2 > 3 ? 3 : 0].x = (int)((q2 >> 8) & 0xfffu);
+      c[IPT / 2 > 3 ? 3 : 0].y = (int)(q2 >> 20);
+    }
+  } else if (C16) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      c[u].x = (int)(c16[u] & 0xffffu);
+      c[u].y = (int)(c16[u] >> 16);
+    }
+  }
+  if (!C12) {                                                 // foreign elements: a column this block owns (see merge_load)
+    if (lead && tid == 0) c[0].x = c[0].y;
+    if (total & 1) {
+#pragma unroll
+      for (int u = 0; u < IPT / 2; u++)
+        if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
+    }
+  }
+  dbl2 xv[IPT / 2];
+  if (XU > 0) {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
+      xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
+    }
+    if (ALIAS) __syncthreads();                               // every wave has its x values: the window's LDS is the products' now
+  } else {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = x[c[u].x];
+      xv[u].y = x[c[u].y];
+    }
+  }
+  roll_steps<IPT>(d, v, xv, prod, roff, y);
+}
+
 // SKEW: the plan holds blocks flagged KIND_SKEW (matrices without any run the instantiation that
 // carries no second-pass code at all: 0.13 us per launch on cant).
 // EXT: 0 = the lean kernel of ordinary products; 1 = the launch may carry halo sources and/or a dot epilogue;
@@ -636,34 +765,28 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, const int2v rdes
 // halo sources.  Ordinary products run EXT = 0, which contains none of that code: a kernel this close to the
 // memory system's limits pays for every extra branch, register and byte of LDS (measured while adding them:
 // +1 to +6 %).
-// FAR: the plan has blocks with far slots (KIND_FAR; plans without any run the instantiation without that code).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool FAR, bool CRUN = false>
+// ROLL (EXT = 0, no SKEW): 0 = plain; 1 = rolling row sums; 2 = plain with the products aliased over the x window;
+// 3 = rolling + aliased (merge_block_roll above).
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, int ROLL = 0>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
-                             PassArg<EXT> pass_arg, const double *__restrict__ farx,
-                             const int *__restrict__ far_col, const int2v *__restrict__ run_desc) {
+                             PassArg<EXT> pass_arg) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
-  static_assert(!CRUN || (C16 && !C12 && IPT == 8 && XU > 0), "run records: tiled blocks, 8 items per thread");
+  static_assert((ROLL & 1) == 0 || (EXT == 0 && !SKEW), "rolling row sums: the lean kernel only");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
+  constexpr bool ALIAS = (ROLL & 2) != 0;
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
-  double *xs = reinterpret_cast<double *>(roff + 2 * WG);     // XU*WG doubles
+  double *xs = ALIAS ? prod : reinterpret_cast<double *>(roff + 2 * WG);   // XU*WG doubles (ALIAS: XU <= IPT)
+  static_assert(!ALIAS || XU <= IPT, "aliased window: it must fit the products' space");
 
   CASK_STAMP(0);
   const int lb = logical_block(blockIdx.x, n_blocks, remap);
-#if defined(CASK_ABL) && (CASK_ABL & 128)                     // diagnostic build: what does the descriptor round trip cost? (a made-up block of the
-  BlockDesc d;                                                // cant-like shape computed from lb alone; results wrong by design)
-  d.row_start = min(lb * 31, 62451 - 31); d.n_rows = 31; d.nnz_start = min(lb * 1984, nnz - 1984) & ~1; d.nnz_count = 1984;
-  d.cmin = max(0, d.row_start - 420) & ~1; d.cwidth = 1024; d.kind_g = 8 | KIND_CONTIG; d.aux = 0;
-#else
   const BlockDesc d = blocks[lb];
-#endif
-  int2v rdesc = {0, 0};
-  if (CRUN) rdesc = run_desc[lb];                             // where the block's run records start, how long they are
   const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
 
   const SolverPass sp = pass_of(pass_arg);                    // EXT < 2: all zeros, every use folds away
@@ -760,12 +883,17 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // last entry of x[] a block without halo columns may touch: its window is padded to whole chunks and
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
-  if (XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG)          // workgroup-uniform
-    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR, CRUN>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                             xs, halo, dot, lb, sp, ps, farx, far_col);
-  else
-    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false, false>(d, rdesc, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                              xs, halo, dot, lb, sp, ps, farx, far_col);
+  const bool tiled = XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG;   // workgroup-uniform
+  if (ROLL & 1) {
+    if (tiled) merge_block_roll<IPT, XU, NT, C16, C12, WIDE, ALIAS>(d, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, lb);
+    else       merge_block_roll<IPT, 0, NT, false, false, false, false>(d, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, lb);
+  } else if (tiled) {
+    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                                        xs, halo, dot, lb, sp, ps);
+  } else {
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                                            xs, halo, dot, lb, sp, ps);
+  }
   CASK_STAMP(5);
 }
 

@@ -17,7 +17,6 @@ struct MergeLaunch {
   const int *rp, *ci;
   const unsigned *ci16;            // NULL: 32-bit indices; else 16-bit slots per nonzero, or (packed12) 12-byte records
   bool packed12;                   //   of eight 12-bit slots per thread, [block][thread]
-  const int2v *run_desc;           // non-NULL: ci16 holds RUN RECORDS (merge_kernel.hpp, CRUN); per block {first dword, dwords of deltas}
   bool one_window;                 // every tiled block's tile is one contiguous window (paired window loads)
   const int *xchunk;
   const double *val;
@@ -26,15 +25,11 @@ struct MergeLaunch {
   DotEpilogue dot;
   bool solver_pass;                // EXT == 2 launch: `pass` describes the composed operand and the scalars
   SolverPass pass;
-  const double *farx;              // plans with far slots: the x values k_far_gather left for them; else NULL
-  const int *far_col;              // far_columns = 2: block-major list of the far columns, gathered by the product kernel itself
-  bool far;                        // the plan has far slots
+  int roll;                        // lean launches: bit 0 = rolling row sums, bit 1 = products aliased over the x window
 };
 
 template <int IPT>
 void launch_merge_blocks(const MergeLaunch &l, const double *x, double *y, hipStream_t s);
-// two blocks per workgroup, software-pipelined (merge_pair_kernel.hpp): plans of tiled, 12-bit packed blocks only
-void launch_merge_pair(const MergeLaunch &l, const double *x, double *y, hipStream_t s);
 
 extern template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
 extern template void launch_merge_blocks<4>(const MergeLaunch &, const double *, double *, hipStream_t);

@@ -1,6 +1,8 @@
 // Definition of launch_merge_blocks<IPT>: picks the k_spmv_merge instantiation for the plan's window
 // shape, load policy and index width.  Included by merge_ipt<N>.hip only.
 #pragma once
+#include <cstdlib>
+
 #include "merge_kernel.hpp"
 #include "merge_launch.hpp"
 
@@ -9,72 +11,61 @@ namespace caskhip {
 template <int IPT, int XU>
 static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
   const dim3 grid(l.grid), block(l.wg_size);
-#define CASK_LAUNCH_KR(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS, CRUN)                                            \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, FAR, CRUN>), grid, block, l.lds_bytes, s, \
+#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, ROLL, LDS, PASS)                                             \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ROLL>), grid, block, LDS, s,           \
                      l.blocks, l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, \
-                     y, l.partials, l.halo, l.dot, PASS, l.farx, l.far_col, l.run_desc)
-#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS) CASK_LAUNCH_KR(NT, C16, C12, WIDE, SKEW, EXT, FAR, PASS, false)
+                     y, l.partials, l.halo, l.dot, PASS)
   // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one, a solver
   // pass the one that composes its operand
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
   const PassArg<2> pass2{l.pass};
-#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                                              \
-  do {                                                                                       \
-    if (l.solver_pass) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, false, pass2);             \
-    else if (ext)      CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, false, PassArg<1>{});      \
-    else               CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 0, false, PassArg<0>{});      \
+  // lean launches of plans without skewed blocks: rolling row sums (bit 0) and / or the products aliased over the x
+  // window (bit 1: the window's LDS is not allocated) -- merge_kernel.hpp, merge_block_roll
+  constexpr bool CAN_ALIAS = XU > 0 && XU <= IPT;
+  const int roll = (ext || l.solver_pass || l.any_skew) ? 0 : (CAN_ALIAS ? l.roll : (l.roll & 1));
+  const int lds_alias = l.lds_bytes - 8 * XU * l.wg_size;
+  const bool alias_ext = CAN_ALIAS && (l.roll & 2) && !l.any_skew;   // extended kernels: the aliased window alone
+#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                                                            \
+  do {                                                                                                     \
+    if (l.solver_pass && alias_ext && !SKEW) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, (CAN_ALIAS && !SKEW ? 2 : 0), lds_alias, pass2); \
+    else if (l.solver_pass) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, 0, l.lds_bytes, pass2);             \
+    else if (ext && alias_ext && !SKEW) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, (CAN_ALIAS && !SKEW ? 2 : 0), lds_alias, PassArg<1>{}); \
+    else if (ext)      CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, 0, l.lds_bytes, PassArg<1>{});           \
+    else               CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 0, 0, l.lds_bytes, PassArg<0>{});           \
   } while (0)
-  // plans with far slots (chunked tiles, never WIDE; no composed passes, no halo)
-#define CASK_LAUNCH_F(NT, C16, C12, SKEW)                                                    \
-  do {                                                                                       \
-    if (ext) CASK_LAUNCH_K(NT, C16, C12, false, SKEW, 1, true, PassArg<1>{});                \
-    else     CASK_LAUNCH_K(NT, C16, C12, false, SKEW, 0, true, PassArg<0>{});                \
-  } while (0)
-  // run records (r4): streaming loads, no skewed blocks, no far slots (the planner only builds them for such plans)
-#define CASK_LAUNCH_R(WIDE)                                                                             \
-  do {                                                                                                  \
-    if (l.solver_pass) CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 2, false, pass2, CAN12);         \
-    else if (ext)      CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 1, false, PassArg<1>{}, CAN12);  \
-    else               CASK_LAUNCH_KR(true, TILED, false, WIDE, false, 0, false, PassArg<0>{}, CAN12);  \
+  // streaming loads, no skewed blocks: the shapes the lean variants exist for
+#define CASK_LAUNCH_L(C16, C12, WIDE)                                                                      \
+  do {                                                                                                     \
+    if (roll == 1)      CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, 1, l.lds_bytes, PassArg<0>{});       \
+    else if (roll == 2) CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, (CAN_ALIAS ? 2 : 0), lds_alias, PassArg<0>{}); \
+    else if (roll == 3) CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, (CAN_ALIAS ? 3 : 1), lds_alias, PassArg<0>{}); \
+    else                CASK_LAUNCH_M(true, C16, C12, WIDE, false);                                        \
   } while (0)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = l.nontemporal || l.any_skew;
   constexpr bool TILED = XU > 0;
   constexpr bool CAN12 = TILED && IPT == 8;                   // 12-bit packed slots exist for 8 items per thread
   constexpr bool CANWIDE = CAN12 && XU >= 2;                  // paired window loads: packed plans whose tiles are one window
-  if (TILED && l.ci16 && l.run_desc && CAN12) {
-    if (l.one_window && CANWIDE) CASK_LAUNCH_R(CANWIDE);
-    else                         CASK_LAUNCH_R(false);
-  } else if (TILED && l.ci16 && l.far && l.packed12 && CAN12) {
-    if (l.any_skew) CASK_LAUNCH_F(true, TILED, CAN12, true);
-    else if (nt)    CASK_LAUNCH_F(true, TILED, CAN12, false);
-    else            CASK_LAUNCH_F(false, TILED, CAN12, false);
-  } else if (TILED && l.ci16 && l.far) {
-    if (l.any_skew) CASK_LAUNCH_F(true, TILED, false, true);
-    else if (nt)    CASK_LAUNCH_F(true, TILED, false, false);
-    else            CASK_LAUNCH_F(false, TILED, false, false);
-  } else if (TILED && l.ci16 && l.packed12 && CAN12 && l.one_window && CANWIDE) {
+  if (TILED && l.ci16 && l.packed12 && CAN12 && l.one_window && CANWIDE) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, true);
-    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, false);
+    else if (nt)    CASK_LAUNCH_L(TILED, CAN12, CANWIDE);
     else            CASK_LAUNCH_M(false, TILED, CAN12, CANWIDE, false);
   } else if (TILED && l.ci16 && l.packed12 && CAN12) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, false, true);
-    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, false, false);
+    else if (nt)    CASK_LAUNCH_L(TILED, CAN12, false);
     else            CASK_LAUNCH_M(false, TILED, CAN12, false, false);
   } else if (TILED && l.ci16) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, false, false, true);
-    else if (nt)    CASK_LAUNCH_M(true, TILED, false, false, false);
+    else if (nt)    CASK_LAUNCH_L(TILED, false, false);
     else            CASK_LAUNCH_M(false, TILED, false, false, false);
   } else {
     if (l.any_skew) CASK_LAUNCH_M(true, false, false, false, true);
-    else if (nt)    CASK_LAUNCH_M(true, false, false, false, false);
+    else if (nt)    CASK_LAUNCH_L(false, false, false);
     else            CASK_LAUNCH_M(false, false, false, false, false);
   }
 #undef CASK_LAUNCH_K
-#undef CASK_LAUNCH_KR
-#undef CASK_LAUNCH_R
+#undef CASK_LAUNCH_L
 #undef CASK_LAUNCH_M
-#undef CASK_LAUNCH_F
 }
 
 template <int IPT>

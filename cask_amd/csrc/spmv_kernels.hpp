@@ -439,42 +439,6 @@ __global__ void k_spmv_fixup(const SplitRow *__restrict__ rows, int n, const dou
   if (dot.w) dot.dot_part[i] = dot.w[r.row] * s;              // slots behind the blocks' (caller offsets the pointer)
 }
 
-// ------------------------------------------------------------- far columns
-// Pre-gather of the x values of "far" nonzeros (columns outside their block's LDS tile: the scattered part of a
-// power-law matrix).  The reference meets scattered columns with column blocking -- the matrix is cut into column
-// blocks of cache_size and x is loaded block by block into on-chip memory (SparseMatrix.hpp:459-482,
-// Spmv.cpp:42-107).  Here only the scattered part is column-blocked: the far nonzeros are sorted by column PANEL
-// (8 panels, one per XCD), workgroup b works on panel b % 8 -- hardware deals workgroups round-robin over the
-// XCDs, so each XCD's L2 only ever sees one eighth of x and every x line is fetched from memory once instead of
-// once per XCD that happens to need it -- and leaves x[col] at farx[dst], block-major, where the product kernel's
-// workgroups pick their far values up with one coalesced load.  Placement is for speed only; any mapping of
-// workgroups to XCDs gives the same result.
-constexpr int FAR_PANELS = 8;
-constexpr int FAR_CHUNK = 1024;        // far nonzeros per workgroup (4 per lane in flight)
-struct FarPanels {
-  int start[FAR_PANELS + 1];           // panel p owns far entries [start[p], start[p+1])
-};
-__global__ void k_far_gather(FarPanels panels, const int *__restrict__ fcol, const int *__restrict__ fdst,
-                             const double *__restrict__ x, double *__restrict__ farx) {
-  const int panel = blockIdx.x & (FAR_PANELS - 1), idx = blockIdx.x >> 3;
-  const int k0 = panels.start[panel] + idx * FAR_CHUNK, k1 = min(k0 + FAR_CHUNK, panels.start[panel + 1]);
-  if (k0 >= k1) return;
-  constexpr int U = FAR_CHUNK / 256;
-  int c[U], dd[U];
-  double v[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int k = min(k0 + u * 256 + (int)threadIdx.x, k1 - 1);
-    c[u] = __builtin_nontemporal_load(fcol + k);
-    dd[u] = __builtin_nontemporal_load(fdst + k);
-  }
-#pragma unroll
-  for (int u = 0; u < U; u++) v[u] = x[c[u]];
-#pragma unroll
-  for (int u = 0; u < U; u++)
-    if (k0 + u * 256 + (int)threadIdx.x < k1) farx[dd[u]] = v[u];
-}
-
 // ------------------------------------------------------------ plan helpers
 // Column span [min,max] of a run of nonzeros, one workgroup per run; fills the
 // x-window fields used by the LDSX paths.

@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 5   /* 5: cask_hip_spmv_windows_device, run records (index16 = 3 / 4); 4: variants SCAN / MERGE_PAIR, CASK_HIP_PRECOND_ILU0_MC, solver stride with an exchange callback */
+#define CASK_HIP_ABI_VERSION 6   /* 6: measured losers removed -- variant MERGE_PAIR (5, xcd_remap = 2), index16 = 3 / 4 (run records),
+                                  * far_columns = 1 / 2 for MERGE: each is rejected with CASK_HIP_ERR_INVALID and a message naming
+                                  * the replacement; 5: cask_hip_spmv_windows_device; 4: variant SCAN, CASK_HIP_PRECOND_ILU0_MC,
+                                  * solver stride with an exchange callback */
 
 /* status codes */
 #define CASK_HIP_OK               0
@@ -38,10 +41,8 @@ extern "C" {
 #define CASK_HIP_VARIANT_VECTOR   1   /* lanes_per_row lanes of a wavefront per row (1 = thread per row) */
 #define CASK_HIP_VARIANT_MERGE    2   /* merge-based: equal (rows+nnz) items per workgroup, products and x tile in LDS */
 #define CASK_HIP_VARIANT_MERGE_WAVE 3 /* merge-based, persistent software-pipelined waves (no workgroup barrier, x from L2) */
-#define CASK_HIP_VARIANT_MERGE_PAIR 5 /* MERGE with two blocks per workgroup, the second one's loads in flight while the first
-                                       * one's rows are reduced (half the grid, one round).  A spelling of MERGE with
-                                       * xcd_remap = 2: the handle reports variant MERGE; plans that are not all tiled,
-                                       * 12-bit packed blocks run the ordinary MERGE kernel */
+#define CASK_HIP_VARIANT_MERGE_PAIR_REMOVED 5 /* ABI 4-5: MERGE with two blocks per workgroup.  Removed in ABI 6 (it won on
+                                       * one BASELINE family, by 2 %); the value is rejected, never reused */
 #define CASK_HIP_VARIANT_SCAN     4   /* nonzero-mapped: equal nonzeros per workgroup, thread-owned runs of products and a
                                        * segmented scan of the carries; no row_ptr stream.  tile_width = x window staged in
                                        * LDS (per block: the densest column range of that width); far_columns = 1 / 2:
@@ -61,23 +62,18 @@ typedef struct cask_hip_params {
   int32_t tile_width;       /* doubles of x staged in LDS per workgroup; -1 = no tile */
   int32_t wg_size;          /* threads per workgroup: 64,128,256,512,1024            */
   int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
-  int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off, 2 = 1 + MERGE_PAIR */
+  int32_t xcd_remap;        /* 1 = contiguous row blocks per XCD (8 XCDs), -1 = off */
   int32_t nontemporal;      /* 1 = stream values/col_ind with nontemporal loads, -1 = off           */
   int32_t index16;          /* MERGE with an x tile: 1 = stream tile-relative slot indices instead of 32-bit columns
                              * (12 bits each, packed per thread, where the kernel has that layout; else 16 bits),
-                             * 2 = 16-bit slots only, -1 = off; r4: 3 = 12-bit and never run records, 4 = RUN RECORDS where
-                             * they can be built (per 128 elements a run-start mask + an int16 delta per run of consecutive
-                             * slots: FEM matrices with several unknowns per node; opt-in, a measured loss -- DESIGN.md 13).
-                             * cask_hip_csr_get_params reports what the plan streams: 1 = 12-bit, 2 = 16-bit, 4 = runs.
+                             * 2 = 16-bit slots only, -1 = off (3 / 4, ABI 5's run records, are rejected).
+                             * cask_hip_csr_get_params reports what the plan streams: 1 = 12-bit, 2 = 16-bit.
                              * The reference's own stream compaction is the RLE of empty-row runs,
                              * src/runtime/Spmv.hpp:213-250 */
-  int32_t far_columns;      /* MERGE with slot indices: nonzeros whose columns lie outside a block's tile ("far") are
-                             * served from a side buffer that a pre-gather launch fills column panel by column panel
-                             * (one panel of x per XCD's L2) -- the reference's column blocking (SparseMatrix.hpp:459-482)
-                             * applied to the scattered part only.  1 = on, 0 / -1 = off (measured: the extra launch
-                             * costs more than the saved line fills on every BASELINE family);
-                             * 2 = far slots without the pre-gather: the product kernel gathers them from x itself,
-                             * through a per-block list of far columns */
+  int32_t far_columns;      /* SCAN only (see CASK_HIP_VARIANT_SCAN): 1 / 2 = far nonzeros through a column-panel
+                             * pre-gather -- the reference's column blocking (SparseMatrix.hpp:459-482) applied to the
+                             * scattered part only; 0 / -1 = off.  Opt-in: it cuts fabric traffic, not time.  MERGE's
+                             * far slots (ABI <= 5) were removed: 1 / 2 with another variant is rejected */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {
@@ -128,6 +124,10 @@ int cask_hip_abi_version(void);
  * (src/runtime/Model.hpp:93-136) with what the HIP runtime reports. */
 int cask_hip_device_count(int32_t *count);
 int cask_hip_device_props_get(int32_t device, cask_hip_device_props *out);
+/* PCI bus id of a device ("0000:c1:00.0"): what tells two ranks apart that both call their GPU "device 0" -- a multi-GPU
+ * run lists one per rank so that its output proves N ranks sat on N distinct devices.  (The reference has one device per
+ * process: max_open / device name in src/runtime/Spmv.cpp:236-262.) */
+int cask_hip_device_pci_bus_id(int32_t device, char *out, int32_t len);
 
 /* Upload a 0-based CSR matrix (host pointers, borrowed for the call) to the
  * current HIP device and build the launch plan.  Replaces

@@ -41,6 +41,12 @@ int cask_hip_rccl_comm_destroy(cask_hip_comm *comm);
  * block's column indices are remapped to the layout by the caller at plan time.  0 restores the contiguous layout. */
 int cask_hip_rccl_comm_set_stride(cask_hip_comm *comm, int64_t stride);
 
+/* What RCCL itself says about the communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice and that device's
+ * PCI bus id (so that a multi-GPU run can prove "N ranks on N distinct devices" from its own output; -1 / "" where the
+ * library lacks the query).  Any pointer may be NULL. */
+int cask_hip_rccl_comm_info(const cask_hip_comm *comm, int32_t *nranks, int32_t *rank, int32_t *device,
+                            char *pci_bus_id, int32_t pci_len);
+
 /* cask_hip_allreduce_fn / cask_hip_exchange_fn with user = the communicator: in-place sum of `count` doubles over
  * the ranks; gather of every rank's slice (uneven: one broadcast per rank inside a group) into d_full.  Both are
  * enqueued on `stream` and return without waiting. */

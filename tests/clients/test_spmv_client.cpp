@@ -4,8 +4,15 @@
 // almost_equal(got, exp, 1E-8, 1E-11).  The reference takes its golden from
 // Eigen; this test client takes it from the CPU oracle (oracle/cask_oracle.c),
 // which test infrastructure is allowed to link.
-//   test_spmv_hip <matrix.mtx> [implId]
+//   test_spmv_hip <matrix.mtx> [implId]                     the reference's form: one matrix per process (ctest -R hw,
+//                                                           CMakeLists.txt:135-139)
+//   test_spmv_hip --all <m1.mtx> <m2.mtx> ...               the same test over a list of matrices in ONE process (the
+//                                                           suite's form: one HIP initialisation instead of 43)
+//   test_spmv_hip --variants v1,v2,... <matrix.mtx>         the test once per value of CASK_HIP_VARIANT, one process; a value
+//                                                           written !v must be REJECTED (std::invalid_argument)
+#include <cstdlib>
 #include <iostream>
+#include <sstream>
 #include <string>
 
 #include "cask/GeneratedImplSupport.hpp"
@@ -53,9 +60,63 @@ static int test(std::string path, int implId) {
   return 1;
 }
 
+static int test_all(int argc, char **argv) {
+  int failed = 0;
+  for (int i = 2; i < argc; i++) {
+    int status = 2;
+    try {
+      status = test(argv[i], -1);
+    } catch (std::exception &e) {
+      std::cout << "Exception: " << e.what() << std::endl;
+    }
+    std::cout << "Matrix " << argv[i] << (status == 0 ? " ok" : " FAILED") << std::endl;
+    failed += status != 0;
+  }
+  std::cout << (argc - 2 - failed) << " of " << (argc - 2) << " matrices passed" << std::endl;
+  return failed ? 1 : 0;
+}
+
+static int test_variants(const std::string &list, const std::string &path) {
+  std::stringstream ss(list);
+  std::string v;
+  int failed = 0, n = 0;
+  while (std::getline(ss, v, ',')) {
+    const bool must_reject = !v.empty() && v[0] == '!';
+    if (must_reject) v = v.substr(1);
+    setenv("CASK_HIP_VARIANT", v.c_str(), 1);
+    int status = 2;
+    bool rejected = false;
+    try {
+      status = test(path, -1);
+    } catch (std::invalid_argument &e) {
+      rejected = true;
+      std::cout << "Rejected: " << e.what() << std::endl;
+    } catch (std::exception &e) {
+      std::cout << "Exception: " << e.what() << std::endl;
+    }
+    const bool ok = must_reject ? rejected : status == 0;
+    std::cout << "Variant " << v << (ok ? (must_reject ? " rejected as it must be" : " ok") : " FAILED") << std::endl;
+    failed += !ok;
+    n++;
+  }
+  unsetenv("CASK_HIP_VARIANT");
+  std::cout << (n - failed) << " of " << n << " variants behaved" << std::endl;
+  return failed ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
   std::cout << "Program arguments:" << std::endl;
   for (int i = 0; i < argc; i++) std::cout << "   " << argv[i] << std::endl;
+  if (argc > 2 && std::string(argv[1]) == "--all") {
+    const int status = test_all(argc, argv);
+    std::cout << (status == 0 ? "All tests passed!" : "Tests failed!") << std::endl;
+    return status;
+  }
+  if (argc == 4 && std::string(argv[1]) == "--variants") {
+    const int status = test_variants(argv[2], argv[3]);
+    std::cout << (status == 0 ? "All tests passed!" : "Tests failed!") << std::endl;
+    return status;
+  }
   if (argc > 1) {
     int status = -1;
     try {

@@ -156,3 +156,62 @@ def test_transpose_csr_matches_oracle():
     x = np.random.default_rng(1).standard_normal(n)
     assert np.array_equal(oracle.csr_spmv(trp, tci, tva, x), oracle.csr_spmv_t(n, rp, ci, va, x))
     assert all(np.all(np.diff(tci[trp[r]:trp[r + 1]]) > 0) for r in range(0, n, max(1, n // 50)))
+
+
+def _selfcheck_worker(rank, world, port, out):
+    """check_fused_halo over gloo with stand-in products: every rank's "fused product" reads the OTHER rank's shared
+    slice (a file-free stand-in: the slices are all-gathered in the fence), so a fault injected on ONE rank fails its
+    READER only."""
+    import torch
+    import torch.distributed as dist
+    from cask_amd import selfcheck as sc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nl = 16
+        n = world * nl
+        idx_own = torch.arange(rank * nl, (rank + 1) * nl)
+        mine = torch.zeros(nl, dtype=torch.float64)
+        seen = [torch.zeros(nl, dtype=torch.float64) for _ in range(world)]
+        fences = [0]
+
+        def fence():                                          # a collective: barrier + what the peers' slices hold now
+            fences[0] += 1
+            dist.all_gather(seen, mine)
+
+        def plain_ref(e):                                     # y = sum of the peers' operands, from the formula
+            return sum(sc.operand(e, torch.arange(g * nl, (g + 1) * nl), n) for g in range(world) if g != rank)
+
+        def fused(y):                                         # ... from what the peers' slices really hold
+            y.copy_(sum(seen[g] for g in range(world) if g != rank))
+
+        ok, why = sc.check_fused_halo(torch, fused, plain_ref, mine, idx_own, fence, n, n=12, rank=rank)
+        t = torch.tensor([1.0 if ok else 0.0])
+        agreed, reason = sc.agree(ok, why, lambda v: (dist.all_reduce(t.fill_(v), op=dist.ReduceOp.MIN), float(t[0]))[1],
+                                  lambda o: (lambda l: (dist.all_gather_object(l, o), l)[1])([None] * world))
+        out[rank] = {"ok": ok, "why": why, "fences": fences[0], "agreed": agreed, "reason": reason}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_selfcheck_with_a_fault_on_one_rank_only_completes_its_collectives(monkeypatch):
+    """a halo fault is seen by the readers of ONE slice; the rank that sees it must finish all
+    2 n fences like its peers before the verdict's collectives, or they would be mismatched (a hang where the fallback
+    should engage).  Fault on rank 1 only: rank 0 (its reader) fails, rank 1 passes, both ran 2 n fences, both agree."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("CASK_FAULT_STALE_HALO", "halo")
+    monkeypatch.setenv("CASK_FAULT_RANK", "1")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_selfcheck_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert not r0["ok"] and "exchange 1" in r0["why"]         # the first odd exchange, and the loop went on
+    assert r1["ok"] and r1["why"] is None
+    assert r0["fences"] == r1["fences"] == 24
+    assert not r0["agreed"] and not r1["agreed"] and r0["reason"] == r1["reason"] and r0["reason"].startswith("rank 0:")
+    monkeypatch.delenv("CASK_FAULT_STALE_HALO")
+    out2 = mgr.dict()
+    mp.spawn(_selfcheck_worker, args=(2, free_port(), out2), nprocs=2, join=True)
+    assert out2[0]["agreed"] and out2[1]["agreed"] and out2[0]["fences"] == 24

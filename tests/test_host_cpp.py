@@ -72,14 +72,21 @@ def test_gen_impl_dfe_compat_binds_the_reference_triple(tmp_path):
 
 @pytest.mark.gpu
 def test_integration_client_over_reference_fixtures(plain_mtx_dir):
-    """ctest -R hw of the reference (CMakeLists.txt:135-139): test_spmv_<target> <matrix> for every fixture."""
+    """ctest -R hw of the reference (CMakeLists.txt:135-139): test_spmv_<target> <matrix> for every fixture.  The
+    reference starts one process per matrix; here the client takes the whole list in ONE process (--all: one HIP
+    initialisation instead of 43 -- 16 s instead of 222 s on a slow box), and the one-matrix form
+    the reference's ctest uses is run once."""
     make("clients")
     exe = REPO / "build" / "test_spmv_hip"
-    for key, _ in golden_matrix_files():
-        path = plain_mtx_dir / (key + ".mtx")
-        out = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
-        assert out.returncode == 0 and "Test passed!" in out.stdout, (key, out.stdout[-600:], out.stderr[-300:])
-        assert "Result  Gflops (actual)=" in out.stdout
+    paths = [str(plain_mtx_dir / (key + ".mtx")) for key, _ in golden_matrix_files()]
+    out = subprocess.run([str(exe), "--all", *paths], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("Test passed!") == len(paths), (out.stdout[-1200:], out.stderr[-300:])
+    assert f"{len(paths)} of {len(paths)} matrices passed" in out.stdout
+    assert out.stdout.count("Result  Gflops (actual)=") == len(paths)
+    for p in paths:
+        assert f"Matrix {p} ok" in out.stdout, p
+    one = subprocess.run([str(exe), paths[0]], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and "Test passed!" in one.stdout and "All tests passed!" in one.stdout, one.stdout[-600:]
 
 
 @pytest.mark.gpu
@@ -92,16 +99,18 @@ def test_preconditioning_client_known_answers(plain_mtx_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["vector", "merge_wave", "scan"])
-def test_env_override_selects_the_variant(plain_mtx_dir, variant):
-    """CASK_HIP_VARIANT reaches the engine through the unchanged client (the reference picks designs by implId)."""
+def test_env_override_selects_the_variant(plain_mtx_dir):
+    """CASK_HIP_VARIANT reaches the engine through the unchanged client (the reference picks designs by implId): every
+    family, one process (--variants sets the variable before each run; `!fpga` must be rejected), and once the way a
+    user would -- the variable set in the environment of the one-matrix form, a bad value a non-zero exit."""
     make("clients")
     exe = REPO / "build" / "test_spmv_hip"
-    env = dict(os.environ, CASK_HIP_VARIANT=variant)
-    out = subprocess.run([str(exe), str(plain_mtx_dir / "matrices" / "test_cage6.mtx")], capture_output=True, text=True, env=env)
-    assert out.returncode == 0 and "Test passed!" in out.stdout, (out.stdout[-600:], out.stderr[-300:])
-    bad = subprocess.run([str(exe), str(plain_mtx_dir / "matrices" / "test_cage6.mtx")], capture_output=True, text=True,
-                         env=dict(os.environ, CASK_HIP_VARIANT="fpga"))
+    mtx = str(plain_mtx_dir / "matrices" / "test_cage6.mtx")
+    out = subprocess.run([str(exe), "--variants", "vector,merge,merge_wave,scan,auto,!fpga", mtx], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "6 of 6 variants behaved" in out.stdout, (out.stdout[-900:], out.stderr[-300:])
+    assert out.stdout.count("Test passed!") == 5 and "Variant fpga rejected as it must be" in out.stdout
+    bad = subprocess.run([str(exe), mtx], capture_output=True, text=True, env=dict(os.environ, CASK_HIP_VARIANT="fpga"), timeout=300)
     assert bad.returncode != 0
 
 
@@ -134,7 +143,7 @@ def test_dse_executable_writes_dse_out(plain_mtx_dir, tmp_path):
     assert len(doc["best_architectures"]) == 3
     for arch in doc["best_architectures"]:
         assert arch["measured_gflops"] > 0 and arch["points_evaluated"] > 10
-        assert arch["architecture_params"]["variant"] in (1, 2, 3, 4, 5)      # any family may win on a small matrix
+        assert arch["architecture_params"]["variant"] in (1, 2, 3, 4)         # any family may win on a small matrix
         assert arch["measured_usec"] > 0 and arch["measured_usec_warm"] > 0 and arch["matrix_copies_rotated"] >= 1
     # and the generator accepts what the DSE wrote
     subprocess.run(["python3", str(REPO / "tools" / "gen_impl.py"), "--dse", str(tmp_path / "dse_out.json"),

@@ -42,7 +42,7 @@ def random_design_point(rng):
     variant = rng.choice(["merge", "merge", "merge", "vector", "merge_wave", "scan", "scan"])
     if variant == "merge":
         return dict(variant="merge", items_per_thread=int(rng.choice([2, 4, 8, 8, 16])), wg_size=int(rng.choice([64, 128, 256, 512])),
-                    tile_width=int(rng.choice([-1, 64, 512, 1024, 4096])), index16=int(rng.choice([-1, 1, 1, 2, 4])),
+                    tile_width=int(rng.choice([-1, 64, 512, 1024, 4096])), index16=int(rng.choice([-1, 1, 1, 2, 0])),
                     xcd_remap=int(rng.choice([-1, 1])), nontemporal=int(rng.choice([-1, 1])))
     if variant == "vector":
         return dict(variant="vector", lanes_per_row=int(rng.choice([1, 2, 4, 8, 16, 32, 64])), wg_size=int(rng.choice([64, 256])),

@@ -204,14 +204,14 @@ def test_solvers_with_a_nonzero_initial_guess():
         np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(want).max()))
 
 
-def test_solvers_on_scan_and_paired_plans():
-    """CG / BiCG on handles planned with the round-3 variants: a SCAN plan has no fused dot epilogue (the solver falls
-    back to its own dot kernels), a MERGE_PAIR plan is a MERGE plan whose solver launches run the ordinary kernels."""
+def test_solvers_on_scan_plans():
+    """CG / BiCG on handles planned with the SCAN variant: such a plan has no fused dot epilogue (the solver falls back to
+    its own dot kernels)."""
     for name, solver in (("G3_circuit", "cg"), ("atmosmodd", "bicg")):
         n, rp, ci, va = synth.small(name, factor=16)
         b = np.random.default_rng(3).standard_normal(n)
         want, want_it, want_conv = (oracle.cg_full if solver == "cg" else oracle.bicg)(rp, ci, va, b, tol=1e-8)
-        for dp in (dict(variant="scan", tile_width=1024), dict(variant="scan", tile_width=-1), dict(variant="merge_pair", tile_width=2048)):
+        for dp in (dict(variant="scan", tile_width=1024), dict(variant="scan", tile_width=-1)):
             m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
             got, it, conv, _ = (m.cg if solver == "cg" else m.bicg)(b, tol=1e-8)
             m.close()

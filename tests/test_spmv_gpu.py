@@ -29,11 +29,9 @@ DESIGN_POINTS = [
     dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, index16=-1),
     dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=4096, index16=2),       # 16-bit slots, not packed
     dict(variant="merge", items_per_thread=8, wg_size=128, tile_width=1024, index16=1, nontemporal=-1),   # 12-bit packed
-    dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096, far_columns=1),    # far slots, 16-bit indices
-    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=2048, far_columns=1),    # far slots, 12-bit packed
-    dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=128, far_columns=1, nontemporal=-1),
-    dict(variant="merge", items_per_thread=4, wg_size=256, tile_width=2048, far_columns=2),    # far slots gathered in-kernel
-    dict(variant="merge", items_per_thread=8, wg_size=128, tile_width=1024, far_columns=2, nontemporal=-1),
+    dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096),                   # 16-bit slots (4 items per thread)
+    dict(variant="merge", items_per_thread=8, wg_size=256, tile_width=2048),                   # 12-bit packed, the headline's shape
+    dict(variant="merge", items_per_thread=2, wg_size=64, tile_width=128, nontemporal=-1),
     dict(variant="merge_wave", items_per_thread=2, wg_size=64),
     dict(variant="merge_wave", items_per_thread=4, wg_size=256, xcd_remap=-1),
     dict(variant="merge_wave", items_per_thread=8, wg_size=512, nontemporal=-1),
@@ -48,12 +46,32 @@ DESIGN_POINTS = [
     dict(variant="scan", items_per_thread=16, wg_size=128, tile_width=300, far_columns=1, xcd_remap=-1),
     dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=-1, far_columns=2),       # far panels by producer workgroups
     dict(variant="scan", items_per_thread=2, wg_size=64, tile_width=128, far_columns=2, nontemporal=-1),
-    dict(variant="merge_pair", tile_width=1024),                                               # two blocks per workgroup
-    dict(variant="merge_pair", tile_width=4096, wg_size=512),
-    dict(variant="merge_pair", tile_width=2048, wg_size=128, xcd_remap=2),
     dict(),   # AUTO / all defaults
 ]
 DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
+
+
+def _covering_subset(points):
+    """A subset of `points` that still holds every kernel family and, within a family, every value of every axis the
+    full list holds (greedy set cover, deterministic).  The 43 reference fixtures are swept over this subset -- the axes
+    select tile widths, load flavours, block mappings and index widths, and which COMBINATION of them meets a fixture's
+    shape adds nothing once each has met it -- while the full list stays on the five synthetic families and on the
+    random profiles (suite time)."""
+    keys = ("variant", "lanes_per_row", "tile_width", "wg_size", "items_per_thread", "xcd_remap", "nontemporal", "index16", "far_columns")
+
+    def cells(dp):
+        return {(dp.get("variant", "auto"), k, dp.get(k, 0)) for k in keys}
+    need = set().union(*(cells(dp) for dp in points))
+    chosen = []
+    while need:
+        best = max(range(len(points)), key=lambda i: (len(cells(points[i]) & need), -i))
+        chosen.append(best)
+        need -= cells(points[best])
+    return [points[i] for i in sorted(chosen)]
+
+
+FIXTURE_POINTS = _covering_subset(DESIGN_POINTS)
+FIXTURE_IDS = [DP_IDS[DESIGN_POINTS.index(dp)] for dp in FIXTURE_POINTS]
 
 
 def run_host(n_rows, n_cols, rp, ci, va, x, dp):
@@ -72,9 +90,10 @@ def fixtures_loaded():
     return out
 
 
-@pytest.mark.parametrize("dp", DESIGN_POINTS, ids=DP_IDS)
+@pytest.mark.parametrize("dp", FIXTURE_POINTS, ids=FIXTURE_IDS)
 def test_reference_fixtures_every_design_point(dp, fixtures_loaded, expected_y):
-    """test/test_spmv.cpp protocol over all 43 fixture matrices (incl. the two 'failing' ones)."""
+    """test/test_spmv.cpp protocol over all 43 fixture matrices (incl. the two 'failing' ones), for a covering subset of
+    the design points (every kernel family; within a family every value of every axis)."""
     for key, m in fixtures_loaded.items():
         x = mmio.test_vector(m.m)
         got = run_host(m.n, m.m, m.row_ptr, m.col_ind, m.values, x, dp)
@@ -120,66 +139,22 @@ def _cant3_small():
     return synth.cant3_like(nx=9, ny=9, nz=33)                  # 8 019 rows, the full matrix's 3 x 3 node blocks
 
 
-@pytest.mark.parametrize("shape", [dict(wg_size=256, tile_width=1024), dict(wg_size=512, tile_width=4096),
-                                   dict(wg_size=128, tile_width=2048)], ids=["w256", "w512", "w128"])
-def test_run_records_give_the_bits_of_the_packed_slots(shape):
-    """the column stream as RUNS of consecutive LDS slots (index16 = 4; merge_kernel.hpp CRUN,
-    cask_hip.hip pack_runs) must gather exactly what the 12-bit packed slots gather (index16 = 3): same products in the
-    same order, bit-identical rows; both against the oracle.  Full-size cant3 (runs of 9) and a small instance whose
-    last block ends in clamped duplicates."""
-    for gen in (synth.cant3_like, _cant3_small):
-        n, rp, ci, va = gen()
-        x = np.random.default_rng(21).uniform(-1, 1, n)
-        want = oracle.csr_spmv(rp, ci, va, x)
-        ys = {}
-        for i16 in (4, 3):
-            m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=i16, **shape))
-            ys[i16] = m.spmv(x)
-            assert m.params.as_dict()["index16"] == (4 if i16 == 4 else 1), m.params.as_dict()
-            assert np.array_equal(ys[i16], m.spmv(x))
-            m.close()
-        oracle.assert_almost_equal(ys[4], want, what=f"run records {shape}")
-        assert np.array_equal(ys[4], ys[3])
-
-
-def test_run_records_are_not_taken_where_columns_scatter():
-    """Rows of scattered columns (the cant-like band: 1.09 columns per run) have ~118 runs per 128 elements -- more
-    bytes than 12-bit slots: asking for run records falls back to the packed records (and AUTO never takes run
-    records: they are a measured loss, profiles/r04_run_records.txt)."""
-    n, rp, ci, va = synth.small("cant", factor=4)
+def test_removed_design_points_are_rejected_with_a_reason():
+    """ABI 6: the measured losers are gone from the shipped engine -- variant MERGE_PAIR (5,
+    xcd_remap = 2), run records (index16 = 3 / 4), far slots for MERGE (far_columns = 1 / 2) -- and asking for one is an
+    error that names the replacement, at create and at set_params."""
+    n, rp, ci, va = synth.small("cant", factor=16)
+    assert capi.load().cask_hip_abi_version() >= 6
+    for bad, word in ((dict(variant=capi.VARIANT_MERGE_PAIR_REMOVED), "MERGE_PAIR"), (dict(variant="merge", xcd_remap=2), "MERGE_PAIR"),
+                      (dict(variant="merge", index16=4), "run records"), (dict(variant="merge", index16=3), "run records"),
+                      (dict(variant="merge", far_columns=1), "SCAN only"), (dict(variant="vector", far_columns=2), "SCAN only")):
+        with pytest.raises(ValueError, match=word):
+            capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**bad))
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+    with pytest.raises(ValueError, match="run records"):
+        m.set_params(capi.make_params(variant="merge", index16=4))
     x = mmio.test_vector(n)
-    want = oracle.csr_spmv(rp, ci, va, x)
-    for i16 in (0, 4):
-        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=i16))
-        assert m.params.as_dict()["index16"] == 1
-        oracle.assert_almost_equal(m.spmv(x), want, what=f"cant-like index16={i16}")
-        m.close()
-
-
-def test_run_records_with_a_dot_epilogue_and_in_a_solver_pass():
-    """The extended instantiations (EXT = 1: dot epilogue; EXT = 2: composed solver pass) decode the same records."""
-    import torch
-    n, rp, ci, va = _cant3_small()
-    rng = np.random.default_rng(4)
-    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", items_per_thread=8, index16=4))
-    assert m.params.as_dict()["index16"] == 4
-    xt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
-    yt = torch.empty(n, dtype=torch.float64, device="cuda")
-    dt = torch.zeros(1, dtype=torch.float64, device="cuda")
-    m.spmv_dot_device(xt, yt, wt, dt)
-    torch.cuda.synchronize()
-    want = oracle.csr_spmv(rp, ci, va, x)
-    oracle.assert_almost_equal(yt.cpu().numpy(), want, what="run records + dot epilogue")
-    assert abs(float(dt[0]) - float(w @ want)) <= 1e-9 * max(1.0, abs(float(w @ want)))
-    b = torch.from_numpy(oracle.csr_spmv(rp, ci, va, np.ones(n))).cuda()
-    sols = []
-    for mode in (capi.SOLVER_CLASSIC, capi.SOLVER_COMPOSED):
-        xs = torch.zeros(n, dtype=torch.float64, device="cuda")
-        it, conv, _ = m.solve_device(b, xs, kind="cg", mode=mode, maxiters=2000, tol=1e-9)
-        torch.cuda.synchronize()
-        sols.append(xs.cpu().numpy())
-        assert conv and np.abs(sols[-1] - 1.0).max() < 1e-6, (mode, it)
+    oracle.assert_almost_equal(m.spmv(x), oracle.csr_spmv(rp, ci, va, x), what="the handle keeps its plan after a rejected set_params")
     m.close()
 
 
@@ -492,25 +467,6 @@ def test_create_device_rejects_out_of_range_columns():
                 capi.CsrMatrix.from_device(2, 3, rp, ci, va, capi.make_params(**dp))
 
 
-def test_far_columns_path_is_taken_and_exact():
-    """The far-column path (pre-gather by column panel + far slots behind the tile) on the power-law family:
-    bit-identical to the same design point without it (same products, same summation order), and reproducible."""
-    n, rp, ci, va = synth.webbase_like()
-    x = np.random.default_rng(21).uniform(-1, 1, n)
-    want = oracle.csr_spmv(rp, ci, va, x)
-    base = dict(variant="merge", items_per_thread=4, wg_size=512, tile_width=4096)
-    ys = {}
-    for far in (-1, 0, 1, 2):
-        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(far_columns=far, **base))
-        got = m.params.as_dict()["far_columns"]
-        ys[far] = (m.spmv(x), m.spmv(x), got)
-        m.close()
-        oracle.assert_almost_equal(ys[far][0], want, what=f"far={far}")
-        assert np.array_equal(ys[far][0], ys[far][1])
-    assert ys[-1][2] == -1 and ys[1][2] == 1 and ys[2][2] == 2
-    assert np.array_equal(ys[1][0], ys[-1][0]) and np.array_equal(ys[0][0], ys[-1][0]) and np.array_equal(ys[2][0], ys[-1][0])
-
-
 def test_cant3_fem_blocks_wide_band():
     """the second cant look-alike -- 3x3 dense node blocks on a 9 x 9 x 257 beam mesh numbered so
     that the band is wide and non-uniform (three bands 7.7 K columns apart): parity under the design points of the
@@ -683,28 +639,3 @@ def test_scan_fused_far_handoff_with_a_changing_operand():
     oracle.assert_almost_equal(y0.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xs[5].cpu().numpy()), what="scan fused")
     m2.close()
     m0.close()
-
-
-def test_paired_block_kernel_is_taken_and_bit_identical_to_merge():
-    """two merge blocks per workgroup (merge_pair_kernel.hpp) on the plans it exists for -- the
-    cant-like and cant3-like matrices at full size: the handle reports MERGE with xcd_remap = 2, and the product has the
-    bits of the ordinary MERGE kernel on the same plan (same arithmetic, same order).  A plan that does not qualify
-    (power-law rows: untiled and long-row blocks) falls back to the ordinary kernel and says so (xcd_remap = 1)."""
-    for gen in (synth.cant_like, synth.cant3_like):
-        n, rp, ci, va = gen()
-        x = np.random.default_rng(41).uniform(-1, 1, n)
-        want = oracle.csr_spmv(rp, ci, va, x)
-        ys = {}
-        for variant in ("merge", "merge_pair"):
-            m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant=variant, tile_width=1024 if gen is synth.cant_like else 4096))
-            prm = m.params.as_dict()
-            assert prm["variant"] == "merge" and prm["xcd_remap"] == (2 if variant == "merge_pair" else 1), prm
-            ys[variant] = m.spmv(x)
-            assert np.array_equal(ys[variant], m.spmv(x))
-            m.close()
-        oracle.assert_almost_equal(ys["merge_pair"], want, what=gen.__name__)
-        assert np.array_equal(ys["merge"], ys["merge_pair"])
-    n, rp, ci, va = synth.small("webbase-1M", factor=16)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge_pair", tile_width=2048))
-    assert m.params.as_dict()["xcd_remap"] == 1
-    m.close()
