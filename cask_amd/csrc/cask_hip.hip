@@ -98,7 +98,6 @@ struct Plan {
   DevBuf<double> scan_farx;
   DevBuf<int> scan_sync, scan_needs;   // fused far pre-gather: producer flags + block epochs; producers each block waits for
   ScanFar scan_far{};
-  bool scan_alias = false;         // SCAN: the x window shares the product area's LDS
 };
 
 // Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
@@ -524,9 +523,13 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   int want_w = prm.tile_width > 0 ? prm.tile_width : 0;
   int xp = 0;
   if (want_w > 0 && m.nnz > 0 && m.n_cols < SCAN_LDS_BIT) {
+    // r5: the window SHARES the product area's LDS (scan_kernel.hpp: dead once every thread holds its x values), so it
+    // is at most ipt * wg entries wide (xp <= ipt / 2) and costs no LDS -- with 16 KB of its own a 2 048-entry window took
+    // a 256 x 8 block from 8 to 4 workgroups per CU, which is what made windows lose on short rows (webbase2: 15.9 us
+    // with its own LDS, 15.2 shared, 16.2 without a window; profiles/r05_merge_forms.txt)
     xp = 2;
     while (xp < 8 && 2 * xp * wg < want_w) xp *= 2;
-    while (xp >= 2 && (base_lds + 16 * xp * wg > MAX_LDS_BYTES || 2 * xp * wg > 65536)) xp /= 2;
+    while (xp >= 2 && (2 * xp > ipt + 1 || 2 * xp * wg > 65536)) xp /= 2;
     if (xp < 2) xp = 0;
   }
   const int W = 2 * xp * wg;
@@ -670,10 +673,7 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
     }
   }
   HIP_TRY(pl.blocks.upload(blocks));
-  // r5: a window that fits the product area shares its LDS (scan_kernel.hpp, XA) -- A/B hook CASK_HIP_SCAN_ALIAS=0
-  static const bool alias_on = [] { const char *e = std::getenv("CASK_HIP_SCAN_ALIAS"); return !e || std::atoi(e) != 0; }();
-  pl.scan_alias = alias_on && pl.xu > 0 && 2 * pl.xu <= ipt + 1;
-  pl.lds_bytes = base_lds + (pl.scan_alias ? 0 : 16 * pl.xu * wg);
+  pl.lds_bytes = base_lds;                                    // (the window lives in the product area)
   pl.ldsx = pl.xu > 0;
   return CASK_HIP_OK;
 }
@@ -770,8 +770,10 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       // tile = set of column ranges in 64-column chunks, 16-bit slot indices (host planner)
       int rc2 = ensure_host_col_ind(m);
       if (rc2) return rc2;
+      // (a window that shares the product area -- merge_window_aliased, spmv_common.hpp -- costs no LDS of its own)
+      auto window_lds = [&](int xu) { return merge_window_aliased(xu, prm.items_per_thread) ? 0 : 8 * xu * prm.wg_size; };
       int xu_cap = 8;
-      while (xu_cap > 0 && base_lds + 8 * xu_cap * prm.wg_size > MAX_LDS_BYTES) xu_cap /= 2;
+      while (xu_cap > 0 && base_lds + window_lds(xu_cap) > MAX_LDS_BYTES) xu_cap /= 2;
       const int max_slots = std::min(tile, xu_cap * prm.wg_size);
       std::vector<std::vector<int>> chunk_starts;
       std::vector<unsigned short> ci16;
@@ -822,7 +824,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       if (max_width > 0) {
         xu = 1;
         while (xu < 8 && xu * prm.wg_size < max_width) xu *= 2;
-        while (xu > 0 && base_lds + 8 * xu * prm.wg_size > MAX_LDS_BYTES) xu /= 2;
+        while (xu > 0 && base_lds + (merge_window_aliased(xu, prm.items_per_thread) ? 0 : 8 * xu * prm.wg_size) > MAX_LDS_BYTES) xu /= 2;
       }
       pl.xu = xu;
       if (xu > 0) pl.prm.tile_width = xu * prm.wg_size;
@@ -845,7 +847,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     // never allocates -- it may be running under stream capture
     HIP_TRY(pl.dot_part.alloc((size_t)pl.grid + (size_t)pl.n_split_rows));
     pl.ldsx = pl.xu > 0;
-    pl.lds_bytes = base_lds + 8 * pl.xu * prm.wg_size;
+    pl.lds_bytes = base_lds + (merge_window_aliased(pl.xu, prm.items_per_thread) ? 0 : 8 * pl.xu * prm.wg_size);
   } else {
     // L >= 4: the pair-load kernel, VEC_RG row groups per wave (spmv_kernels.hpp)
     const int rows_per_wg = prm.wg_size / prm.lanes_per_row * (prm.lanes_per_row >= 4 ? VEC_RG : 1);
@@ -889,7 +891,7 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
   d.slot_bytes_per_nnz = s.slot_bytes_per_nnz;
   d.maxch = s.maxch; d.any_skew = s.any_skew; d.n_long_rows = s.n_long_rows;
   d.n_split_rows = s.n_split_rows; d.n_far = s.n_far;
-  d.scan_far = s.scan_far; d.scan_alias = s.scan_alias;
+  d.scan_far = s.scan_far;
   HIP_TRY(d.blocks.copy_from(s.blocks)); HIP_TRY(d.long_blocks.copy_from(s.long_blocks));
   HIP_TRY(d.split_rows.copy_from(s.split_rows)); HIP_TRY(d.partials.copy_from(s.partials));
   HIP_TRY(d.ci16.copy_from(s.ci16)); HIP_TRY(d.xchunk.copy_from(s.xchunk)); HIP_TRY(d.dot_part.copy_from(s.dot_part));
@@ -929,16 +931,6 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
 // (16 doubles) in dynamic LDS behind the x tile
 int dot_lds_bytes(int wg_size) { return 16 * wg_size + 128; }
 
-// r5 A/B hook: CASK_HIP_MERGE_ROLL = 0 (plain), 1 (rolling row sums), 2 (products aliased over the x window),
-// 3 (both) for the lean MERGE launches; read once.
-int merge_roll_mode() {
-  static const int mode = [] {
-    const char *e = std::getenv("CASK_HIP_MERGE_ROLL");
-    return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
-  }();
-  return mode;
-}
-
 template <int IPT>
 int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot,
                    const SolverPass *pass) {
@@ -950,7 +942,6 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.lds_bytes = pl.lds_bytes + ((dot.w || pass) ? dot_lds_bytes(pl.prm.wg_size) : 0);
   l.solver_pass = pass != nullptr;
   if (pass) l.pass = *pass;
-  l.roll = merge_roll_mode();
   l.xu = pl.xu;
   l.remap = pl.prm.xcd_remap > 0;
   l.n_cols = m.n_cols;
@@ -1046,7 +1037,6 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
     l.n_cols = m.n_cols;
     l.xp = pl.xu;
     l.nontemporal = pl.prm.nontemporal > 0;
-    l.alias = pl.scan_alias;
     l.blocks = pl.blocks.p;
     l.rp = m.d_rp;
     l.ci = pl.scan_ci.p ? pl.scan_ci.p : m.d_ci;

@@ -441,7 +441,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
       xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
       xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
     }
-    if (ALIAS) __syncthreads();                               // aliased plans: the window's LDS becomes the products' (merge_block_roll)
+    if (ALIAS) __syncthreads();                               // aliased window: its LDS becomes the products' (k_spmv_merge)
   } else if (SEAM) {                                          // gathers, some of them from peers
     uint64_t ex[IPT / 2], ey[IPT / 2];
 #pragma unroll
@@ -554,210 +554,6 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   }
 }
 
-// ------------------------------------------------------------------------------------------ rolling row sums (r5)
-// The lean product (EXT = 0, no skewed blocks) with the row sums ROLLED INTO the stream wait.  The stream of a block
-// arrives in IPT/2 steps (step u = the 16-byte pairs [u*WG, (u+1)*WG) of the block, returned in issue order), spread
-// over the microseconds the memory system needs for everybody's bytes; in k_spmv_merge's plain form the products of
-// every step are parked as they arrive but the row sums wait for the last one, so the whole row-sum phase (barrier,
-// row offsets, a lane's dependent run of LDS reads, DPP butterfly, y stores: ~1 us of the launch, profiles/
-// r04_run_records.txt "no tail") sits exposed behind the block's last bytes.  Here a barrier follows EVERY step and a
-// row is summed in the step that completes it: lane group g = tid / G owns row g (the planner's G makes that one
-// row per group; G = 1 blocks may hold up to 2*WG rows: a second row per thread), sums it with exactly the additions
-// of reduce_rows_plain (same order => the same bits), keeps the sum in a register and stores it once the wave has no
-// load left to wait for (a store issued between the waits would count in vmcnt behind the younger loads and turn the
-// next counted wait into a wait for them too).  After the last step only the rows that END in it are left: a quarter
-// of the phase (IPT = 8), run by the one or two waves that own those rows.
-// ALIAS: the products are parked OVER the x window (dead once every wave has gathered its x values: one more barrier,
-// in the shadow of the stream): 18.4 instead of 26.6 KB of LDS per 256 x 8 block -> 8 instead of 6 workgroups per CU,
-// the whole 2 021-block grid of the cant-like matrix resident in ONE round (r3 stamps: a quarter of the workgroups
-// started after 7.5 us, a second, thin round that pays head and tail again).
-template <int G>
-__device__ __forceinline__ double roll_row_sum(const double *prod, int s, int e, int j) {
-  double acc = 0.0;
-#pragma unroll 4
-  for (int k = s + j; k < e; k += G) acc += prod[k];
-  return group_sum<G>(acc);                                   // all lanes of the group take this path together
-}
-__device__ __forceinline__ double roll_row_sum_g(int G, const double *prod, int s, int e, int j) {   // G: workgroup-uniform
-  switch (G) {
-    case 1:  return roll_row_sum<1>(prod, s, e, j);
-    case 2:  return roll_row_sum<2>(prod, s, e, j);
-    case 4:  return roll_row_sum<4>(prod, s, e, j);
-    case 8:  return roll_row_sum<8>(prod, s, e, j);
-    case 16: return roll_row_sum<16>(prod, s, e, j);
-    case 32: return roll_row_sum<32>(prod, s, e, j);
-    default: return roll_row_sum<64>(prod, s, e, j);
-  }
-}
-
-template <int IPT>
-__device__ __forceinline__ void roll_steps(const BlockDesc &d, const dbl2 (&v)[IPT / 2], const dbl2 (&xv)[IPT / 2],
-                                           double *prod, const int *roff, double *__restrict__ y) {
-  const int WG = blockDim.x, tid = threadIdx.x;
-  const int G = d.kind_g & 0xff, lg = __builtin_ctz(G);        // lanes per row (a power of two), workgroup-uniform
-  const int rows_per_pass = WG >> lg, j = tid & (G - 1), g = tid >> lg;
-  // this group's row(s): offsets read once, in the shadow of the stream (roff is parked behind the first barrier)
-  const int r0 = g, r1 = g + rows_per_pass;
-  bool pend0 = r0 < d.n_rows, pend1 = G == 1 && r1 < d.n_rows; // row exists and is not summed yet
-  const bool have0 = pend0, have1 = pend1;
-  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-  if (pend0) { s0 = roff[r0]; e0 = roff[r0 + 1]; }
-  if (pend1) { s1 = roff[r1]; e1 = roff[r1 + 1]; }
-  double acc0 = 0.0, acc1 = 0.0;
-  dbl2 *prod2 = reinterpret_cast<dbl2 *>(prod);
-#pragma unroll
-  for (int u = 0; u < IPT / 2; u++) {
-    // the products of step u are formed HERE, behind step u - 1's barrier: without the pin the compiler forms all of
-    // them up front (they are pure register arithmetic) and with them waits for the whole stream before the first
-    // barrier -- the first build of this kernel did exactly that: four barriers and no overlap, 8.3 -> 11.0 us
-    double va = v[u].x, vb = v[u].y;
-    asm volatile("" : "+v"(va), "+v"(vb));                    // (waits for stream step u only: vmcnt retires in order)
-    dbl2 pr;
-    pr.x = va * xv[u].x;
-    pr.y = vb * xv[u].y;
-    prod2[u * WG + tid] = pr;
-    const bool last = u == IPT / 2 - 1;
-    if (last) {                                               // no load left to wait for: the sums this wave already holds
-      if (have0 && !pend0 && j == 0) y[d.row_start + r0] = acc0;
-      if (have1 && !pend1 && j == 0) y[d.row_start + r1] = acc1;
-    }
-    __syncthreads();
-    const int bound = 2 * (u + 1) * WG;                       // products [0, bound) are parked
-    if (pend0 && (last || e0 <= bound)) {                     // group-uniform
-      acc0 = roll_row_sum_g(G, prod, s0, e0, j);
-      pend0 = false;
-      if (last && j == 0) y[d.row_start + r0] = acc0;
-    }
-    if (pend1 && (last || e1 <= bound)) {                     // (G == 1 blocks with more rows than threads only)
-      acc1 = roll_row_sum<1>(prod, s1, e1, j);
-      pend1 = false;
-      if (last) y[d.row_start + r1] = acc1;
-    }
-  }
-  // (a plan whose block holds more rows than two passes cover does not exist -- build_merge_blocks picks G <= WG /
-  // rows and caps a block at 2*WG - 1 rows -- but a wrong y would be silent: finish any such rows the plain way)
-  for (int r = g + (G == 1 ? 2 : 1) * rows_per_pass; r < d.n_rows; r += rows_per_pass) {
-    const double acc = roll_row_sum_g(G, prod, roff[r], roff[r + 1], j);
-    if (j == 0) y[d.row_start + r] = acc;
-  }
-}
-
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool ALIAS>
-__device__ __forceinline__ void merge_block_roll(const BlockDesc &d, int xlim, int max_gpair,
-                                                 const int *__restrict__ rp, const int *__restrict__ ci,
-                                                 const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
-                                                 const double *__restrict__ val, const double *__restrict__ x,
-                                                 double *__restrict__ y, double *prod, int *roff, double *xs, int lb) {
-  const int WG = blockDim.x, tid = threadIdx.x;
-  const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;   // (see merge_load)
-  const int npairs = (total + 1) >> 1;
-  // issue order as in merge_load: x window, row offsets, slot record, value stream
-  double xw[XU > 0 ? XU : 1];
-  if (XU > 0) {
-    if (WIDE) {
-      const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x);
-      const int plim = xlim >> 1;
-#pragma unroll
-      for (int u = 0; u < XU / 2; u++) {
-        const dbl2 pr = x2[min((d.cmin >> 1) + u * WG + tid, plim)];
-        xw[2 * u] = pr.x;
-        xw[2 * u + 1] = pr.y;
-      }
-    } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
-#pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(xchunk[u * wpw + wave] + lane, xlim)];
-    } else {
-#pragma unroll
-      for (int u = 0; u < XU; u++) xw[u] = x[min(d.cmin + u * WG + tid, xlim)];
-    }
-  }
-  const int ro0 = rp[d.row_start + min(tid, d.n_rows)] - base;
-  const int ro1 = rp[d.row_start + min(tid + WG, d.n_rows)] - base;
-  dbl2 v[IPT / 2];
-  int2v c[IPT / 2];
-  unsigned c16[IPT / 2];
-  unsigned c12[3] = {0u, 0u, 0u};
-  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(val);
-  const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
-  const int first = base >> 1;
-  const int last = min(first + max(npairs - 1, 0), max_gpair);
-  if (C12) {
-    const unsigned *rec = ci16 + ((size_t)lb * WG + tid) * 3;
-    c12[0] = stream_load<NT>(rec);
-    c12[1] = stream_load<NT>(rec + 1);
-    c12[2] = stream_load<NT>(rec + 2);
-  }
-#pragma unroll
-  for (int u = 0; u < IPT / 2; u++) {
-    const int p = min(first + u * WG + tid, last);
-    v[u] = stream_load<NT>(val2 + p);
-    if (C12) continue;
-    if (C16) c16[u] = stream_load<NT>(ci16 + p);
-    else     c[u] = stream_load<NT>(ci2 + p);
-  }
-  if (WIDE) {
-    dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
-#pragma unroll
-    for (int u = 0; u < XU / 2; u++) {
-      dbl2 pr;
-      pr.x = xw[2 * u];
-      pr.y = xw[2 * u + 1];
-      xs2[u * WG + tid] = pr;
-    }
-  } else if (XU > 0) {
-#pragma unroll
-    for (int u = 0; u < XU; u++) xs[u * WG + tid] = xw[u];
-  }
-  roff[tid] = ro0;
-  roff[tid + WG] = ro1;
-  __syncthreads();                                            // (also for XU = 0: the row offsets are read right below)
-  if (C12) {
-    static_assert(!C12 || IPT == 8, "12-bit packed slots are laid out for 8 items per thread");
-    const unsigned q0 = c12[0], q1 = c12[1], q2 = c12[2];
-    c[0].x = (int)(q0 & 0xfffu);
-    c[0].y = (int)((q0 >> 12) & 0xfffu);
-    c[1].x = (int)((q0 >> 24) | ((q1 & 0xfu) << 8));
-    c[1].y = (int)((q1 >> 4) & 0xfffu);
-    if (IPT / 2 > 2) {
-      c[IPT / 2 > 2 ? 2 : 0].x = (int)((q1 >> 16) & 0xfffu);
-      c[IPT / 2 > 2 ? 2 : 0].y = (int)((q1 >> 28) | ((q2 & 0xffu) << 4));
-      c[IPT / 2 > 3 ? 3 : 0].x = (int)((q2 >> 8) & 0xfffu);
-      c[IPT / 2 > 3 ? 3 : 0].y = (int)(q2 >> 20);
-    }
-  } else if (C16) {
-#pragma unroll
-    for (int u = 0; u < IPT / 2; u++) {
-      c[u].x = (int)(c16[u] & 0xffffu);
-      c[u].y = (int)(c16[u] >> 16);
-    }
-  }
-  if (!C12) {                                                 // foreign elements: a column this block owns (see merge_load)
-    if (lead && tid == 0) c[0].x = c[0].y;
-    if (total & 1) {
-#pragma unroll
-      for (int u = 0; u < IPT / 2; u++)
-        if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
-    }
-  }
-  dbl2 xv[IPT / 2];
-  if (XU > 0) {
-#pragma unroll
-    for (int u = 0; u < IPT / 2; u++) {
-      xv[u].x = xs[C16 ? c[u].x : c[u].x - d.cmin];
-      xv[u].y = xs[C16 ? c[u].y : c[u].y - d.cmin];
-    }
-    if (ALIAS) __syncthreads();                               // every wave has its x values: the window's LDS is the products' now
-  } else {
-#pragma unroll
-    for (int u = 0; u < IPT / 2; u++) {
-      xv[u].x = x[c[u].x];
-      xv[u].y = x[c[u].y];
-    }
-  }
-  roll_steps<IPT>(d, v, xv, prod, roff, y);
-}
-
 // SKEW: the plan holds blocks flagged KIND_SKEW (matrices without any run the instantiation that
 // carries no second-pass code at all: 0.13 us per launch on cant).
 // EXT: 0 = the lean kernel of ordinary products; 1 = the launch may carry halo sources and/or a dot epilogue;
@@ -765,9 +561,13 @@ __device__ __forceinline__ void merge_block_roll(const BlockDesc &d, int xlim, i
 // halo sources.  Ordinary products run EXT = 0, which contains none of that code: a kernel this close to the
 // memory system's limits pays for every extra branch, register and byte of LDS (measured while adding them:
 // +1 to +6 %).
-// ROLL (EXT = 0, no SKEW): 0 = plain; 1 = rolling row sums; 2 = plain with the products aliased over the x window;
-// 3 = rolling + aliased (merge_block_roll above).
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, int ROLL = 0>
+// Aliased window (r5, merge_window_aliased(): the widest window of the >= 8-items kernels): the products are parked OVER
+// the x window -- dead once every wave has gathered its x values; one more barrier, in the shadow of the stream -- so a
+// 256 x 8 block with a 2 048-entry window needs 18.4 instead of 34.8 KB of LDS: 8 instead of 4 workgroups per CU.
+// Measured (profiles/r05_merge_forms.txt): G3_circuit-like 21.5 -> 20.6 us, atmosmodd-like 21.2 -> 19.6; on the
+// 1 024-entry window of the cant-like plan (6 -> 8 workgroups per CU) it is 1 % SLOWER, which is why narrower windows
+// keep their own LDS.
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
 __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int n_cols, int nnz,
                              const int *__restrict__ rp, const int *__restrict__ ci,
                              const unsigned *__restrict__ ci16, const int *__restrict__ xchunk, int maxch,
@@ -775,10 +575,9 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              double *__restrict__ y, double *__restrict__ partials, XHalo halo, DotEpilogue dot,
                              PassArg<EXT> pass_arg) {
   static_assert(IPT % 2 == 0, "items per thread must be even (16-byte loads)");
-  static_assert((ROLL & 1) == 0 || (EXT == 0 && !SKEW), "rolling row sums: the lean kernel only");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
-  constexpr bool ALIAS = (ROLL & 2) != 0;
+  constexpr bool ALIAS = merge_window_aliased(XU, IPT);
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
   double *xs = ALIAS ? prod : reinterpret_cast<double *>(roff + 2 * WG);   // XU*WG doubles (ALIAS: XU <= IPT)
@@ -884,10 +683,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   // may reach past its largest column, but never past the caller's n_own entries
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   const bool tiled = XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG;   // workgroup-uniform
-  if (ROLL & 1) {
-    if (tiled) merge_block_roll<IPT, XU, NT, C16, C12, WIDE, ALIAS>(d, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, lb);
-    else       merge_block_roll<IPT, 0, NT, false, false, false, false>(d, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff, xs, lb);
-  } else if (tiled) {
+  if (tiled) {
     merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
                                                         xs, halo, dot, lb, sp, ps);
   } else {

@@ -9,7 +9,8 @@
 namespace caskhip {
 
 struct MergeLaunch {
-  int grid, wg_size, lds_bytes;    // lds_bytes already includes the dot epilogue's slice of w when dot.w is set
+  int grid, wg_size, lds_bytes;    // lds_bytes already includes the dot epilogue's slice of w when dot.w is set; a window
+                                   //   that shares the product area (merge_window_aliased) has no share of its own in it
   int xu;                          // 8-byte window loads per lane: 0 (no tile), 1, 2, 4 or 8
   int remap, n_cols, nnz, maxch;
   bool nontemporal, any_skew;
@@ -25,7 +26,6 @@ struct MergeLaunch {
   DotEpilogue dot;
   bool solver_pass;                // EXT == 2 launch: `pass` describes the composed operand and the scalars
   SolverPass pass;
-  int roll;                        // lean launches: bit 0 = rolling row sums, bit 1 = products aliased over the x window
 };
 
 template <int IPT>

@@ -1,8 +1,6 @@
 // Definition of launch_merge_blocks<IPT>: picks the k_spmv_merge instantiation for the plan's window
 // shape, load policy and index width.  Included by merge_ipt<N>.hip only.
 #pragma once
-#include <cstdlib>
-
 #include "merge_kernel.hpp"
 #include "merge_launch.hpp"
 
@@ -11,35 +9,19 @@ namespace caskhip {
 template <int IPT, int XU>
 static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hipStream_t s) {
   const dim3 grid(l.grid), block(l.wg_size);
-#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, ROLL, LDS, PASS)                                             \
-  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ROLL>), grid, block, LDS, s,           \
+#define CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, EXT, PASS)                                                        \
+  hipLaunchKernelGGL((k_spmv_merge<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>), grid, block, l.lds_bytes, s,         \
                      l.blocks, l.grid, l.remap, l.n_cols, l.nnz, l.rp, l.ci, l.ci16, l.xchunk, l.maxch, l.val, x, \
                      y, l.partials, l.halo, l.dot, PASS)
   // ordinary products run the lean kernel; halo sources or a dot epilogue select the extended one, a solver
   // pass the one that composes its operand
   const bool ext = l.halo.haddr != nullptr || l.dot.w != nullptr;
   const PassArg<2> pass2{l.pass};
-  // lean launches of plans without skewed blocks: rolling row sums (bit 0) and / or the products aliased over the x
-  // window (bit 1: the window's LDS is not allocated) -- merge_kernel.hpp, merge_block_roll
-  constexpr bool CAN_ALIAS = XU > 0 && XU <= IPT;
-  const int roll = (ext || l.solver_pass || l.any_skew) ? 0 : (CAN_ALIAS ? l.roll : (l.roll & 1));
-  const int lds_alias = l.lds_bytes - 8 * XU * l.wg_size;
-  const bool alias_ext = CAN_ALIAS && (l.roll & 2) && !l.any_skew;   // extended kernels: the aliased window alone
-#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                                                            \
-  do {                                                                                                     \
-    if (l.solver_pass && alias_ext && !SKEW) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, (CAN_ALIAS && !SKEW ? 2 : 0), lds_alias, pass2); \
-    else if (l.solver_pass) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, 0, l.lds_bytes, pass2);             \
-    else if (ext && alias_ext && !SKEW) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, (CAN_ALIAS && !SKEW ? 2 : 0), lds_alias, PassArg<1>{}); \
-    else if (ext)      CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, 0, l.lds_bytes, PassArg<1>{});           \
-    else               CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 0, 0, l.lds_bytes, PassArg<0>{});           \
-  } while (0)
-  // streaming loads, no skewed blocks: the shapes the lean variants exist for
-#define CASK_LAUNCH_L(C16, C12, WIDE)                                                                      \
-  do {                                                                                                     \
-    if (roll == 1)      CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, 1, l.lds_bytes, PassArg<0>{});       \
-    else if (roll == 2) CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, (CAN_ALIAS ? 2 : 0), lds_alias, PassArg<0>{}); \
-    else if (roll == 3) CASK_LAUNCH_K(true, C16, C12, WIDE, false, 0, (CAN_ALIAS ? 3 : 1), lds_alias, PassArg<0>{}); \
-    else                CASK_LAUNCH_M(true, C16, C12, WIDE, false);                                        \
+#define CASK_LAUNCH_M(NT, C16, C12, WIDE, SKEW)                                              \
+  do {                                                                                       \
+    if (l.solver_pass) CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 2, pass2);                    \
+    else if (ext)      CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 1, PassArg<1>{});             \
+    else               CASK_LAUNCH_K(NT, C16, C12, WIDE, SKEW, 0, PassArg<0>{});             \
   } while (0)
   // plans with skewed blocks exist only with streaming loads (one instantiation less per shape)
   const bool nt = l.nontemporal || l.any_skew;
@@ -48,23 +30,22 @@ static void launch_merge_ix(const MergeLaunch &l, const double *x, double *y, hi
   constexpr bool CANWIDE = CAN12 && XU >= 2;                  // paired window loads: packed plans whose tiles are one window
   if (TILED && l.ci16 && l.packed12 && CAN12 && l.one_window && CANWIDE) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, true);
-    else if (nt)    CASK_LAUNCH_L(TILED, CAN12, CANWIDE);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, CANWIDE, false);
     else            CASK_LAUNCH_M(false, TILED, CAN12, CANWIDE, false);
   } else if (TILED && l.ci16 && l.packed12 && CAN12) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, CAN12, false, true);
-    else if (nt)    CASK_LAUNCH_L(TILED, CAN12, false);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, CAN12, false, false);
     else            CASK_LAUNCH_M(false, TILED, CAN12, false, false);
   } else if (TILED && l.ci16) {
     if (l.any_skew) CASK_LAUNCH_M(true, TILED, false, false, true);
-    else if (nt)    CASK_LAUNCH_L(TILED, false, false);
+    else if (nt)    CASK_LAUNCH_M(true, TILED, false, false, false);
     else            CASK_LAUNCH_M(false, TILED, false, false, false);
   } else {
     if (l.any_skew) CASK_LAUNCH_M(true, false, false, false, true);
-    else if (nt)    CASK_LAUNCH_L(false, false, false);
+    else if (nt)    CASK_LAUNCH_M(true, false, false, false, false);
     else            CASK_LAUNCH_M(false, false, false, false, false);
   }
 #undef CASK_LAUNCH_K
-#undef CASK_LAUNCH_L
 #undef CASK_LAUNCH_M
 }
 

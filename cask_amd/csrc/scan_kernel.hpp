@@ -151,10 +151,10 @@ __device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *_
 // Column references of the plan's own column stream (plans with an x window and/or far nonzeros; otherwise the
 // caller's col_ind is streamed as it is):  c >= 0 without SCAN_LDS_BIT: x[c];  with it: slot c & 0xffff of the block's
 // x window in LDS;  c < 0: farx[~c].
-// XA (r5): the x window shares the product area's LDS (the window is dead once every thread holds its x values: one
-// more barrier) -- a 2 048-entry window then costs no LDS at all at 256 x 8 and the grid stays at 8 workgroups per CU;
-// with its own 16 KB the same window took the kernel to 4 per CU, which is what made windows lose on short rows.
-template <int IPT, bool NT, int FARX, int XP, bool XA>
+// r5: the x window SHARES the product area's LDS (it is dead once every thread holds its x values: one more barrier) --
+// a 2 048-entry window costs no LDS at 256 x 8 and the grid stays at 8 workgroups per CU; with 16 KB of its own the same
+// window took the kernel to 4 per CU, which is what made windows lose on short rows (profiles/r05_merge_forms.txt).
+template <int IPT, bool NT, int FARX, int XP>
 __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__restrict__ blocks, int n_blocks, int remap,
                                            int nnz, int n_cols, const int *__restrict__ rp, const int *__restrict__ ci,
                                            const double *__restrict__ val, const unsigned *__restrict__ meta,
@@ -168,8 +168,8 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
   double *prod = reinterpret_cast<double *>(smem);            // CAP + WG + 4 doubles (padded runs, see below)
   double *wval = prod + CAP + WG + 4;                              // 16 wave aggregates: value ...
   int *wflag = reinterpret_cast<int *>(wval + 16);            // ... and "holds a row end"
-  static_assert(!XA || (XP > 0 && 2 * XP <= IPT + 1), "aliased window: it must fit the product area");
-  double *xs = XA ? prod : wval + 24;                         // XP > 0: the block's x window, 2 * XP * WG doubles
+  static_assert(XP == 0 || 2 * XP <= IPT + 1, "the window must fit the product area");
+  double *xs = prod;                                          // XP > 0: the block's x window, 2 * XP * WG doubles, in the product area
 
   CASK_STAMP(0);
   const int lb = logical_block(hw_block, n_blocks, remap);
@@ -255,7 +255,7 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
         if (cx >= 0 && (cx & SCAN_LDS_BIT)) xv[u].x = xs[cx & 0xffff];
         if (cy >= 0 && (cy & SCAN_LDS_BIT)) xv[u].y = xs[cy & 0xffff];
       }
-      if (XA) __syncthreads();                                // every thread has its x values: the window's LDS is the products' now
+      __syncthreads();                                        // every thread has its x values: the window's LDS is the products' now
     }
   } else {
 #pragma unroll
@@ -387,7 +387,7 @@ __device__ __forceinline__ void far_chunk(int chunk, const ScanPanels &panels, c
 
 constexpr int SCAN_FAR_U = 4;           // far entries per lane of a producer workgroup
 
-template <int IPT, bool NT, int FARX, int XP, bool XA = false>
+template <int IPT, bool NT, int FARX, int XP>
 __global__ void k_spmv_scan(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int nnz, int n_cols,
                             const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
                             const unsigned *__restrict__ meta, const int *__restrict__ rowmap,
@@ -402,10 +402,10 @@ __global__ void k_spmv_scan(const BlockDesc *__restrict__ blocks, int n_blocks, 
       if (threadIdx.x == 0) __hip_atomic_store(sy.flag + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    scan_block<IPT, NT, FARX, XP, XA>(blockIdx.x - far.grid, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x,
+    scan_block<IPT, NT, FARX, XP>(blockIdx.x - far.grid, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x,
                                   farx, y, partials, far.fcol, sy);
   } else {
-    scan_block<IPT, NT, FARX, XP, XA>(blockIdx.x, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x, farx, y,
+    scan_block<IPT, NT, FARX, XP>(blockIdx.x, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x, farx, y,
                                   partials, nullptr, sy);
   }
 }

@@ -9,20 +9,18 @@ template <int IPT, int XP>
 static void launch_scan_ix(const ScanLaunch &l, const ScanFar &far, const double *x, double *y, hipStream_t s) {
   const bool fused = l.farx && l.sync;
   const dim3 grid(l.grid + (fused ? far.grid : 0)), block(l.wg_size);
-  constexpr bool CAN_XA = XP > 0 && 2 * XP <= IPT + 1;       // the window fits the product area (scan_kernel.hpp, XA)
-#define CASK_LAUNCH_SA(NT, FARX, XA)                                                                                 \
-  hipLaunchKernelGGL((k_spmv_scan<IPT, NT, FARX, XP, XA>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, \
+  if constexpr (XP > 0 && 2 * XP > IPT + 1) {                // the planner never builds a window the product area cannot hold
+    (void)grid; (void)block; (void)x; (void)y; (void)s; (void)far;
+    return;
+  } else {
+#define CASK_LAUNCH_S(NT, FARX)                                                                                      \
+  hipLaunchKernelGGL((k_spmv_scan<IPT, NT, FARX, XP>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, \
                      l.n_cols, l.rp, l.ci, l.val, l.meta, l.rowmap, x, l.farx, y, l.partials, far, ScanSync{l.sync, l.sync ? l.sync + far.grid : nullptr, l.needs})
-#define CASK_LAUNCH_S(NT, FARX)                                                       \
-  do {                                                                                \
-    if (CAN_XA && l.alias) CASK_LAUNCH_SA(NT, FARX, CAN_XA);                          \
-    else                   CASK_LAUNCH_SA(NT, FARX, false);                           \
-  } while (0)
-  if (fused)       { if (l.nontemporal) CASK_LAUNCH_S(true, 2); else CASK_LAUNCH_S(false, 2); }
-  else if (l.farx) { if (l.nontemporal) CASK_LAUNCH_S(true, 1); else CASK_LAUNCH_S(false, 1); }
-  else             { if (l.nontemporal) CASK_LAUNCH_S(true, 0); else CASK_LAUNCH_S(false, 0); }
+    if (fused)       { if (l.nontemporal) CASK_LAUNCH_S(true, 2); else CASK_LAUNCH_S(false, 2); }
+    else if (l.farx) { if (l.nontemporal) CASK_LAUNCH_S(true, 1); else CASK_LAUNCH_S(false, 1); }
+    else             { if (l.nontemporal) CASK_LAUNCH_S(true, 0); else CASK_LAUNCH_S(false, 0); }
 #undef CASK_LAUNCH_S
-#undef CASK_LAUNCH_SA
+  }
 }
 
 template <int IPT>

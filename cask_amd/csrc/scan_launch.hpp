@@ -14,8 +14,8 @@ constexpr int SCAN_LDS_BIT = 0x40000000;   // plan-owned column stream: this ref
 struct ScanLaunch {
   int grid, wg_size, lds_bytes, remap, nnz, n_cols;
   int xp;                          // 16-byte x window loads per thread: 0 (no window), 2, 4 or 8; window = 2 * xp * wg_size
+                                   //   entries, parked in the product area (xp <= items_per_thread / 2)
   bool nontemporal;
-  bool alias;                      // the window shares the product area's LDS (lds_bytes then has no window share)
   const BlockDesc *blocks;
   const int *rp, *ci;              // ci: the caller's columns, or the plan's own stream (window slots / far references);
                                    //   rp is read by KIND_HOLES blocks only (which of their rows are empty)

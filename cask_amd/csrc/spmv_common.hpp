@@ -199,6 +199,10 @@ __device__ __forceinline__ T stream_load(const T *p) {
   return *p;
 }
 
+// MERGE: does the x window of this kernel shape share the product area's LDS?  (k_spmv_merge; the host plans the
+// launch's dynamic LDS with the same rule)
+__host__ __device__ constexpr bool merge_window_aliased(int xu, int ipt) { return xu == 8 && ipt >= 8; }
+
 // Rows longer than SKEW_FACTOR * (lanes per row) products get a whole wave each in a second pass.
 constexpr int SKEW_FACTOR = 32;
 // MERGE blocks with 1 or 2 lanes per row (hundreds of short rows per block): rows beyond SKEW_SHORT * G products

@@ -17,6 +17,10 @@ from pathlib import Path
 
 import numpy as np
 
+import hashlib as _hashlib
+
+_SOURCE_HASH = _hashlib.sha1(Path(__file__).read_bytes()).hexdigest()   # part of every cache key (see _disk_cached)
+
 SPECS = {
     # name: (n, nnz of the real SuiteSparse matrix)
     "cant": (62_451, 4_007_383),
@@ -25,6 +29,45 @@ SPECS = {
     "webbase2": (1_000_005, 3_105_536),       # the same SuiteSparse matrix, second look-alike (webbase2_like)
     "atmosmodd": (1_270_432, 8_814_880),
 }
+
+
+def _disk_cached(fn):
+    """Generated matrices are deterministic functions of their arguments and take 2-5 s each at full size; a test suite
+    or a multi-rank run generates the same one in a dozen processes.  Full-size results are kept as .npy files under
+    $CASK_SYNTH_CACHE (default: <tmp>/cask_synth_cache; "0" = off), keyed by generator, arguments and a hash of this
+    file (an edited generator never meets a stale matrix); written under a temporary name and renamed, so concurrent
+    ranks see whole files or none.  Small instances (< 200 K nonzeros) are not worth a file."""
+    import functools
+    import hashlib
+    import tempfile
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        root = os.environ.get("CASK_SYNTH_CACHE", "")
+        if root == "0":
+            return fn(*args, **kwargs)
+        key = hashlib.sha1((fn.__name__ + repr(args) + repr(sorted(kwargs.items())) + _SOURCE_HASH).encode()).hexdigest()[:20]
+        d = Path(root or os.path.join(tempfile.gettempdir(), "cask_synth_cache"))
+        stem = d / f"{fn.__name__}_{key}"
+        try:
+            if (d / f"{stem.name}.done").exists():
+                n = int(np.load(f"{stem}_n.npy"))
+                return n, np.load(f"{stem}_rp.npy"), np.load(f"{stem}_ci.npy"), np.load(f"{stem}_va.npy")
+        except Exception:  # noqa: BLE001 - a damaged cache entry: regenerate
+            pass
+        n, rp, ci, va = fn(*args, **kwargs)
+        if ci.size >= 200_000:
+            try:
+                d.mkdir(parents=True, exist_ok=True)
+                for tag, arr in (("n", np.asarray(n)), ("rp", rp), ("ci", ci), ("va", va)):
+                    tmp = f"{stem}_{tag}.{os.getpid()}.tmp.npy"
+                    np.save(tmp, arr)
+                    os.replace(tmp, f"{stem}_{tag}.npy")
+                (d / f"{stem.name}.done").write_text("ok")
+            except OSError:
+                pass
+        return n, rp, ci, va
+    return wrapper
 
 
 def _coo_to_csr(n, rows, cols, vals):
@@ -42,6 +85,7 @@ def _coo_to_csr(n, rows, cols, vals):
     return np.cumsum(row_ptr).astype(np.int32), c, vals.astype(np.float64)
 
 
+@_disk_cached
 def cant_like(n=62_451, per_row=33, band=400, seed=0):
     """Symmetric banded FEM-like SPD matrix, ~2*per_row+1 nnz per row (cant: ~64)."""
     rng = np.random.default_rng(seed)
@@ -65,6 +109,7 @@ def cant_like(n=62_451, per_row=33, band=400, seed=0):
     return n, rp, ci, va
 
 
+@_disk_cached
 def g3_like(n=1_585_478, nx=1259, extra_frac=0.01, seed=2):
     """2-D 5-point grid Laplacian + 1% random long-range symmetric edges, shifted SPD (~4.8 nnz/row)."""
     rng = np.random.default_rng(seed)
@@ -91,6 +136,7 @@ def g3_like(n=1_585_478, nx=1259, extra_frac=0.01, seed=2):
     return n, rp, ci, va
 
 
+@_disk_cached
 def webbase_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, seed=3):
     """Power-law row lengths (Zipf alpha, clipped), 70% of columns within +-1000 of the diagonal."""
     rng = np.random.default_rng(seed)
@@ -109,6 +155,7 @@ def webbase_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, see
     return n, rp, ci, va
 
 
+@_disk_cached
 def webbase2_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, seed=7, oversample=1.113):
     """Second webbase-1M look-alike: the same power-law OUT-degrees as ``webbase_like``, but the
     columns of a web graph instead of uniformly random ones --
@@ -171,6 +218,7 @@ def webbase2_like(n=1_000_005, nnz_target=3_105_536, alpha=2.1, max_row=4700, se
     return n, rp, ci, va
 
 
+@_disk_cached
 def atmosmodd_like(n=1_270_432, nx=108, ny=108, seed=4):
     """Nonsymmetric 3-D 7-point advection-diffusion stencil (~6.9 nnz/row), diagonally dominant."""
     del seed
@@ -194,6 +242,7 @@ def atmosmodd_like(n=1_270_432, nx=108, ny=108, seed=4):
     return n, rp, ci, va
 
 
+@_disk_cached
 def cant3_like(nx=9, ny=9, nz=257, order="z_fastest", seed=6):
     """A second cant look-alike, closer to the real FEM matrix: a 9 x 9 x 257 hexahedral mesh of a
     cantilever beam (20 817 nodes x 3 dof = 62 451 rows, the real dimension), 27-point node stencil, every node

@@ -158,6 +158,39 @@ def test_removed_design_points_are_rejected_with_a_reason():
     m.close()
 
 
+def test_widest_window_shares_the_product_area():
+    """r5: the 8-loads-per-lane x window of the >= 8-items merge kernels is parked in the product area's LDS (18.4 instead
+    of 34.8 KB per 256 x 8 block: 8 instead of 4 workgroups per CU), the SCAN kernel's window always is.  Where x comes
+    from does not change a single product or sum: bit-identical to the same plan with a narrower window of its own /
+    without a window, and the handle reports the smaller LDS."""
+    n, rp, ci, va = synth.atmosmodd_like()                      # full size: 7 narrow bands far apart, a chunked tile of ~2 000 slots
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    ys, lds = {}, {}
+    for tile in (2048, -1):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", wg_size=256, items_per_thread=8, tile_width=tile))
+        ys[tile], lds[tile] = m.spmv(x), m.info().lds_bytes
+        assert np.array_equal(ys[tile], m.spmv(x))
+        if tile > 0:
+            assert m.params.as_dict()["tile_width"] == 2048, m.params.as_dict()
+        m.close()
+        oracle.assert_almost_equal(ys[tile], want, what=f"merge tile {tile}")
+    assert np.array_equal(ys[2048], ys[-1])
+    assert lds[2048] == lds[-1] == 8 * (256 * 8 + 2) + 8 * 256  # products + row offsets: the window has no share of its own
+    n, rp, ci, va = synth.small("webbase-1M", factor=8)
+    x = np.random.default_rng(6).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    for ipt, wg in ((8, 256), (4, 512), (16, 128)):
+        out = {}
+        for tile in (4096, -1):
+            m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", wg_size=wg, items_per_thread=ipt, tile_width=tile))
+            out[tile] = (m.spmv(x), m.info().lds_bytes, m.params.as_dict()["tile_width"])
+            m.close()
+            oracle.assert_almost_equal(out[tile][0], want, what=f"scan {ipt} x {wg} tile {tile}")
+        assert np.array_equal(out[4096][0], out[-1][0])
+        assert out[4096][1] == out[-1][1] and 0 < out[4096][2] <= ipt * wg, out
+
+
 def test_edge_shapes():
     # no rows at all
     m = capi.CsrMatrix.from_host(0, 0, [0], [], [])
@@ -252,7 +285,7 @@ def test_transpose_product():
     n, rp, ci, va = synth.small("webbase-1M", factor=8)
     x = np.random.default_rng(9).uniform(-1, 1, n)
     want = oracle.csr_spmv_t(n, rp, ci, va, x)
-    for dp in (dict(), dict(variant="scan", tile_width=2048), dict(variant="merge_pair", tile_width=1024)):
+    for dp in (dict(), dict(variant="scan", tile_width=2048), dict(variant="merge", tile_width=2048, wg_size=256)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         xt = torch.from_numpy(x).cuda()
         yt = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -586,9 +619,10 @@ def test_scan_window_and_far_panels_are_taken_and_exact():
         assert np.array_equal(ys[(tile, far)][0], m.spmv(x))
         m.close()
         oracle.assert_almost_equal(ys[(tile, far)][0], want, what=f"scan tile {tile} far {far}")
-    assert ys[(-1, -1)][1:] == (-1, -1) and ys[(4096, -1)][1:] == (4096, -1) and ys[(-1, 1)][1:] == (-1, 1)
-    assert ys[(4096, 0)][1:] == (4096, -1)                   # far panels are opt-in (measured: they do not pay)
-    assert ys[(-1, 2)][1:] == (-1, 2) and ys[(4096, 2)][1:] == (4096, 2)
+    # (r5: the window lives in the product area's LDS, so it is at most wg_size * items_per_thread = 2 048 entries wide)
+    assert ys[(-1, -1)][1:] == (-1, -1) and ys[(4096, -1)][1:] == (2048, -1) and ys[(-1, 1)][1:] == (-1, 1)
+    assert ys[(4096, 0)][1:] == (2048, -1)                   # far panels are opt-in (measured: they do not pay)
+    assert ys[(-1, 2)][1:] == (-1, 2) and ys[(4096, 2)][1:] == (2048, 2)
     for key in ys:
         assert np.array_equal(ys[key][0], ys[(-1, -1)][0]), key
 

@@ -37,3 +37,9 @@ for w in $workloads; do python3 $root/tools/traffic_summary.py $tag $w; done
 find $out -name "*counter_collection.csv" -delete
 find $out -path "*pmc_*" -name "*kernel_trace.csv" -delete
 find $out -path "*prof_*" -name "*kernel_trace.csv" -delete
+# the README line of the kernel-stats CSV, generated from the CSV itself (copy BOTH into profiles/ together)
+stats=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)
+if [ -n "$stats" ]; then
+  alg=$(python3 -c "import json;print(json.load(open('$out/bench_$tag.json'))['roofline']['algorithmic_bytes_per_launch'])" 2>/dev/null)
+  python3 $root/tools/kernel_stats_line.py $stats $alg | tee $out/prof_${tag}_readme_line.txt
+fi
