@@ -231,7 +231,7 @@ __device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassSc
   }
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool ALIAS = false>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool ALIAS>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
@@ -500,12 +500,12 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   CASK_STAMP(4);
 }
 
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool ALIAS = false>
+template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool ALIAS>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                             const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
-                                            double *__restrict__ y, double *prod, int *roff, double *xs,
+                                            double *__restrict__ y, double *prod, int *roff, double *xs, double *wl,
                                             const XHalo &halo, const DotEpilogue &dot, int lb,
                                             const SolverPass &sp, const PassScalars &ps) {
   const int WG = blockDim.x, tid = threadIdx.x;
@@ -513,16 +513,17 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
   // the per-wave sums.  Deliberately no static LDS: 256 bytes of it made the ordinary product measurably
   // slower (8.75 -> 8.88 us per launch in an interleaved A/B) although the occupancy calculator still
   // reports 6 workgroups per CU for 26 896 bytes (tools/lds_granule.hip); the cause was not established.
-  // (ALIAS: the window shares the products' space, so the slice of w follows the row offsets)
-  double *wl = ALIAS ? reinterpret_cast<double *>(roff + 2 * WG) : xs + XU * WG, *dot_red = wl + 2 * WG;
+  // (wl: behind the window's own LDS, or -- a window that shares the products' space -- right behind the row offsets;
+  // the kernel places it, the same for the tiled and the untiled blocks of a launch)
+  double *dot_red = wl + 2 * WG;
   // the dot operand: EXT == 1 a vector (dot.w); a solver pass composes it (dot.dot_part != NULL asks for the shares)
   const bool want_dot = EXT == 2 ? dot.dot_part != nullptr : (EXT == 1 && dot.w != nullptr);   // launch-uniform
   const double *wsrc = EXT == 2 ? (want_dot ? x : nullptr) : dot.w;
   // a seam block's largest column (d.aux, set by the planner when there is a halo) is a halo column: its
   // load phase is a copy of its own, so the one every other block runs has no halo code in it
   if (EXT && halo.haddr != nullptr && d.aux >= halo.n_own)    // workgroup-uniform
-    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
-                                                       halo, wsrc, wl, lb, sp, ps);
+    merge_load<IPT, XU, NT, C16, C12, WIDE, true, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
+                                                              halo, wsrc, wl, lb, sp, ps);
   else
     merge_load<IPT, XU, NT, C16, C12, WIDE, false, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, xchunk, val, x, prod, roff, xs,
                                                                halo, wsrc, wl, lb, sp, ps);
@@ -581,6 +582,7 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   double *prod = reinterpret_cast<double *>(smem);            // CAP + 2 doubles
   int *roff = reinterpret_cast<int *>(prod + CAP + 2);        // 2*WG ints (a block has < 2*WG rows)
   double *xs = ALIAS ? prod : reinterpret_cast<double *>(roff + 2 * WG);   // XU*WG doubles (ALIAS: XU <= IPT)
+  double *wl = reinterpret_cast<double *>(roff + 2 * WG) + (ALIAS ? 0 : XU * WG);   // EXT: the block's slice of w, 2*WG + 16 doubles
   static_assert(!ALIAS || XU <= IPT, "aliased window: it must fit the products' space");
 
   CASK_STAMP(0);
@@ -685,10 +687,10 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
   const bool tiled = XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG;   // workgroup-uniform
   if (tiled) {
     merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                                        xs, halo, dot, lb, sp, ps);
+                                                               xs, wl, halo, dot, lb, sp, ps);
   } else {
-    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
-                                                            xs, halo, dot, lb, sp, ps);
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+                                                            xs, wl, halo, dot, lb, sp, ps);
   }
   CASK_STAMP(5);
 }

@@ -352,6 +352,10 @@ def load_or_make(name):
             if n != m:
                 raise ValueError(f"{p}: the BASELINE workloads are square, this file is {n} x {m}")
             return n, rp, ci, va, str(p)
+    shrink = int(os.environ.get("CASK_BENCH_SHRINK", "0") or 0)
+    if shrink > 1:                                          # tests of PROTOCOL (fault injection, fallbacks), where size is not the point
+        n, rp, ci, va = small(name, factor=shrink)
+        return n, rp, ci, va, f"synthetic, 1/{shrink} of the rows (CASK_BENCH_SHRINK)"
     n, rp, ci, va = GENERATORS[name]()
     return n, rp, ci, va, "synthetic"
 

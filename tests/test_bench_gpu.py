@@ -88,21 +88,23 @@ def test_stale_halo_fault_sends_every_rank_to_the_fallback():
     take the fallback together, and the run must still be right."""
     # (a) in-kernel halo -> the halo pull
     rec = run_bench(["--steps", "10", "--warmup", "2", "--no-tune", "--copies", "2", "--no-cpu-baseline"],
-                    dict(SHARE, CASK_FAULT_STALE_HALO="halo"), world=2)
+                    dict(SHARE, CASK_FAULT_STALE_HALO="halo", CASK_SELFCHECK_EXCHANGES="12"), world=2)
     assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"].startswith("fell back: rank ") and \
         "in-kernel halo:" in rec["config"]["exchange_selfcheck"]["in_kernel_halo"]          # every failing rank's reason
     assert rec["config"]["exchange"].startswith("per step: pull of"), rec["config"]["exchange"]
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
-    # (b) push all-gather -> the collective
+    # (b) push all-gather -> the collective   ((b) and (c) test the PROTOCOL: an eighth of the rows; the full-size dry runs
+    # of the same two workloads are test_config4_... / test_config5_... below)
     args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
-    rec = run_bench(args, dict(SHARE, CASK_FAULT_STALE_HALO="push"), world=3)
+    rec = run_bench(args, dict(SHARE, CASK_FAULT_STALE_HALO="push", CASK_BENCH_SHRINK="8", CASK_SELFCHECK_EXCHANGES="12"), world=3)
     assert rec["config"]["exchange_selfcheck"]["push_allgather"].startswith("fell back: rank ") and \
         "push all-gather:" in rec["config"]["exchange_selfcheck"]["push_allgather"]
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)")
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     # (c) sharded solver: in-kernel halos -> all-gathered operands, peer-store all-reduce -> the collective
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
-                    dict(SHARE, CASK_FAULT_STALE_HALO="1", CASK_PEER_ALLREDUCE="1"), world=2)
+                    dict(SHARE, CASK_FAULT_STALE_HALO="1", CASK_PEER_ALLREDUCE="1", CASK_BENCH_SHRINK="8", CASK_SELFCHECK_EXCHANGES="12"),
+                    world=2)
     sc = rec["config"]["exchange_selfcheck"]
     assert sc["in_kernel_halo"].startswith("fell back") and sc["peer_store_allreduce"].startswith("fell back"), sc
     assert rec["config"]["exchange"].startswith("per product: RCCL all_gather")
@@ -116,7 +118,8 @@ def test_rccl_collectives_run_at_world_one():
     and all_reduce of scalars on the device -- with the one rank a 1-GPU box allows: the config-4 step (all-gather +
     product) and the config-5 solver pass (operand all-gather + all-reduced dots through the engine's callbacks)."""
     env = {"CASK_BENCH_FORCE_DIST": "1", "CASK_BENCH_EXCHANGE": "all_gather", "CASK_FORCE_COLLECTIVES": "1",
-           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+           "CASK_BENCH_SHRINK": "4"}        # the RCCL calls are the point, not the size (full size: the dry runs below)
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
                      "--no-cpu-baseline"], env)
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)") and "issued by the engine" in rec["config"]["exchange"]
@@ -163,7 +166,8 @@ def test_config5_atmosmodd_bicg_sharded_dry_run():
     halos read in-kernel, dots all-reduced; iteration count and true residual against the oracle."""
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
                     SHARE, world=4)
-    assert rec["n_gpus"] == 4 and rec["config"]["exchange"].startswith("halos read inside the product kernels")
+    assert rec["n_gpus"] == 4 and rec["config"]["exchange"].startswith("halos read inside the product kernels"), \
+        (rec["config"]["exchange"], rec["config"].get("exchange_selfcheck"))
     assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"] == "ok"
     chk = rec["config"]["solve_check"]
     assert chk["converged"] and chk["oracle_converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2

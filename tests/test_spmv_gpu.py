@@ -169,7 +169,7 @@ def test_widest_window_shares_the_product_area():
     ys, lds = {}, {}
     for tile in (2048, -1):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", wg_size=256, items_per_thread=8, tile_width=tile))
-        ys[tile], lds[tile] = m.spmv(x), m.info().lds_bytes
+        ys[tile], lds[tile] = m.spmv(x), m.info.lds_bytes
         assert np.array_equal(ys[tile], m.spmv(x))
         if tile > 0:
             assert m.params.as_dict()["tile_width"] == 2048, m.params.as_dict()
@@ -184,7 +184,7 @@ def test_widest_window_shares_the_product_area():
         out = {}
         for tile in (4096, -1):
             m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", wg_size=wg, items_per_thread=ipt, tile_width=tile))
-            out[tile] = (m.spmv(x), m.info().lds_bytes, m.params.as_dict()["tile_width"])
+            out[tile] = (m.spmv(x), m.info.lds_bytes, m.params.as_dict()["tile_width"])
             m.close()
             oracle.assert_almost_equal(out[tile][0], want, what=f"scan {ipt} x {wg} tile {tile}")
         assert np.array_equal(out[4096][0], out[-1][0])
