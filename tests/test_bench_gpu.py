@@ -80,14 +80,40 @@ def test_two_rank_dry_run_reads_halos_in_kernel():
     assert rec["config"]["rows"] == 2 * 62451
     # the first-contact self-check ran (50 exchanges, the operand changes every time) and passed
     assert rec["config"]["exchange_selfcheck"] == {"in_kernel_halo": "ok"}
+    # the line says what the collectives layer saw and what a step moves over xGMI
+    rccl = rec["config"]["rccl"]
+    assert rccl["backend"] == "gloo" and rccl["world_size_seen"] == 2 and len(rccl["devices"]) == 2
+    assert rccl["distinct_devices"] == 1 and rccl["shared_device_dry_run"] is True       # both ranks on the box's one GPU, declared
+    assert all(":" in d for d in rccl["devices"])                                          # host:PCI bus id per rank
+    xg = rec["config"]["xgmi"]
+    assert xg["bytes_received_per_step_per_gpu"] > 0 and xg["bytes_per_link_max"] > 0 and xg["gbs_per_link_at_step_time"] > 0
+
+
+def test_ranks_that_share_a_device_are_refused_unless_declared():
+    """N ranks on fewer than N devices is not a multi-GPU measurement: without
+    CASK_BENCH_SHARE_DEVICE the run ends with exit status 4 before anything is timed (two ranks started by hand, both
+    on device 0, control plane gloo)."""
+    port = str(free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   CASK_BENCH_BACKEND="gloo")
+        env.pop("CASK_BENCH_SHARE_DEVICE", None)
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                                       "--no-cpu-baseline", "--no-tune", "--no-others"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [4, 4], [(p.returncode, o[1][-500:]) for p, o in zip(procs, outs)]
+    assert "refusing to time" in outs[0][1] and not any(line.startswith("{") for line in outs[0][0].splitlines())
 
 
 def test_stale_halo_fault_sends_every_rank_to_the_fallback():
     """CASK_FAULT_STALE_HALO makes a rank serve the PREVIOUS operand on odd exchanges -- what a
     missed fence or a stale line looks like to its peers.  The self-check must see it on every path, every rank must
     take the fallback together, and the run must still be right."""
-    # (a) in-kernel halo -> the halo pull
-    rec = run_bench(["--steps", "10", "--warmup", "2", "--no-tune", "--copies", "2", "--no-cpu-baseline"],
+    # (a) in-kernel halo -> the halo pull        (--windows 3: these runs test the PROTOCOL; over the gloo control plane
+    # of a shared-device dry run a collective fallback costs ~50 ms a step, and 49 windows of it took 28 s)
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--no-tune", "--copies", "2", "--no-cpu-baseline", "--windows", "3"],
                     dict(SHARE, CASK_FAULT_STALE_HALO="halo", CASK_SELFCHECK_EXCHANGES="12"), world=2)
     assert rec["config"]["exchange_selfcheck"]["in_kernel_halo"].startswith("fell back: rank ") and \
         "in-kernel halo:" in rec["config"]["exchange_selfcheck"]["in_kernel_halo"]          # every failing rank's reason
@@ -95,14 +121,15 @@ def test_stale_halo_fault_sends_every_rank_to_the_fallback():
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     # (b) push all-gather -> the collective   ((b) and (c) test the PROTOCOL: an eighth of the rows; the full-size dry runs
     # of the same two workloads are test_config4_... / test_config5_... below)
-    args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline"]
+    args = ["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2", "--no-cpu-baseline",
+            "--windows", "3"]
     rec = run_bench(args, dict(SHARE, CASK_FAULT_STALE_HALO="push", CASK_BENCH_SHRINK="8", CASK_SELFCHECK_EXCHANGES="12"), world=3)
     assert rec["config"]["exchange_selfcheck"]["push_allgather"].startswith("fell back: rank ") and \
         "push all-gather:" in rec["config"]["exchange_selfcheck"]["push_allgather"]
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)")
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     # (c) sharded solver: in-kernel halos -> all-gathered operands, peer-store all-reduce -> the collective
-    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"],
+    rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline", "--windows", "3"],
                     dict(SHARE, CASK_FAULT_STALE_HALO="1", CASK_PEER_ALLREDUCE="1", CASK_BENCH_SHRINK="8", CASK_SELFCHECK_EXCHANGES="12"),
                     world=2)
     sc = rec["config"]["exchange_selfcheck"]
@@ -123,6 +150,8 @@ def test_rccl_collectives_run_at_world_one():
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "webbase-1M", "--no-tune", "--copies", "2",
                      "--no-cpu-baseline"], env)
     assert rec["config"]["exchange"].startswith("per step: RCCL all_gather(x)") and "issued by the engine" in rec["config"]["exchange"]
+    rccl = rec["config"]["rccl"]                                  # what RCCL itself reports for the engine's communicator
+    assert rccl["backend"].startswith("nccl") and rccl["comm_nranks"] == 1 and rccl["distinct_devices"] == 1 and rccl["errors"] is None
     assert rec["config"]["launch"] == "eager"
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
     env.update(MASTER_PORT=str(free_port()))

@@ -387,6 +387,19 @@ def test_multicolour_ilu_apply_and_pcg():
     x2, it2, _, _ = m.pcg(pc, b, tol=1e-9)                      # reproducible run to run, and the handle is reused
     assert it2 == it_mc and np.array_equal(x, x2)
     m.close()
+    # a LAGGED preconditioner -- the factors of A_old applied to A_new = A_old + 0.5 I, same pattern,
+    # other values.  The colour-ordered fast path multiplies with the preconditioner's cached copy of P A_old P^T; it
+    # must not be taken (content fingerprint), and the solve must be that of A_new: x0 again from b_new = A_new x0.
+    va_new = va.copy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    va_new[ci == rows] += 0.5
+    b_new = oracle.csr_spmv(rp, ci, va_new, x0)
+    m_new = capi.CsrMatrix.from_host(n, n, rp, ci, va_new)
+    x_new, it_new, conv_new, _ = m_new.pcg(pc, b_new, tol=1e-9)
+    assert conv_new
+    np.testing.assert_allclose(x_new, x0, rtol=1e-6, atol=1e-8)          # (with A_old's product it converges to A_old^-1 b_new)
+    assert np.abs(oracle.csr_spmv(rp, ci, va_new, x_new) - b_new).max() <= 1e-7 * np.abs(b_new).max()
+    m_new.close()
     pc.close()
     # a structurally unsymmetric matrix is refused
     with pytest.raises(ValueError, match="symmetric"):
