@@ -100,10 +100,10 @@ build/libcask_hip_stamps.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DCASK_STAMPS -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip cask_amd/csrc/cask_hip_rccl.hip
 
-# ablation builds of the solver pass (development only): build/libcask_hip_abl<N>.so
-build/libcask_hip_abl%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
+# diagnostic builds of the merge kernel (development only; cask_amd/csrc/diag.hpp has the switches): build/libcask_hip_diag<N>.so
+build/libcask_hip_diag%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DCASK_ABL=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip cask_amd/csrc/cask_hip_rccl.hip
+	$(HIPCC) $(HIPFLAGS) -DCASK_DIAG=$* -DCASK_UNITY -shared -o $@ cask_amd/csrc/cask_hip.hip cask_amd/csrc/cask_hip_dfe.hip cask_amd/csrc/cask_hip_p2p.hip cask_amd/csrc/cask_hip_precond.hip cask_amd/csrc/cask_hip_rccl.hip
 
 # row f3: MatrixMarket ingest timing (host only)
 build/ingest_time: tools/ingest_time.cpp $(HOSTHDR)

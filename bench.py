@@ -522,16 +522,19 @@ def rccl_census(cx, dist, capi, local_rank):
     if comm is not None:
         comm.close()
     devices = [f"{e['host']}:{e['pci_bus_id']}" for e in everyone]
+    # ranks that open the SAME device index on the same host share a device for certain; PCI ids that collide while the
+    # indices differ (a virtualised bus) are reported, not refused -- a real node must never be turned away by a naming quirk
+    opened = [f"{e['host']}:index{e['local_rank']}" for e in everyone]
     counts = sorted({e.get("comm_nranks") for e in everyone if e.get("comm_nranks") is not None})
     info = {"backend": cx.backend + (" (RCCL)" if cx.backend == "nccl" else ""), "world_size_seen": dist.get_world_size(),
             "comm_nranks": counts[0] if len(counts) == 1 else (counts or None),
             "comm_devices": [e.get("device") for e in everyone] if counts else None,
-            "devices": devices, "distinct_devices": len(set(devices)),
+            "devices": devices, "distinct_devices": len(set(devices)), "distinct_device_indices": len(set(opened)),
             "shared_device_dry_run": bool(os.environ.get("CASK_BENCH_SHARE_DEVICE")),
             "errors": [f"rank {e['rank']}: {e['engine_comm_error']}" for e in everyone if e.get("engine_comm_error")] or None}
-    if info["distinct_devices"] < world and not info["shared_device_dry_run"]:
+    if info["distinct_device_indices"] < world and not info["shared_device_dry_run"]:
         if rank == 0:
-            print(f"[bench] {world} ranks on {info['distinct_devices']} distinct devices ({devices}): refusing to time a "
+            print(f"[bench] {world} ranks on {info['distinct_device_indices']} distinct devices ({devices}): refusing to time a "
                   "multi-GPU run that is not one (set CASK_BENCH_SHARE_DEVICE=1 for a dry run on a shared device)",
                   file=sys.stderr, flush=True)
         raise SystemExit(EXIT_NOT_DISTINCT)
