@@ -46,8 +46,7 @@ constexpr int KIND_LONG = 0x100;
 constexpr int KIND_PARTIAL = 0x200;
 constexpr int KIND_SKEW = 0x800;      // block holds rows much longer than its lanes-per-row suits: second, wave-per-row pass
 constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutive: chunk c starts at cmin + 64c
-constexpr int KIND_FAR = 0x1000;      // tiled block with far slots: behind its chunks (cwidth - cmin slots) sit cmin x values
-                                      //   that the pre-gather launch left at farx[aux ...] (cmin/aux carry counts here)
+constexpr int KIND_FAR = 0x1000;      // SCAN block with far nonzeros (x values through farx: scan_kernel.hpp)
 
 struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
   int32_t row, first_slot, n_slots, pad;
