@@ -1302,6 +1302,19 @@ def run_solver(cx):
         check = {"iterations": it, "converged": conv, "oracle_iterations": want_it, "oracle_converged": want_conv,
                  "residual_2norm_by_oracle_product": res, "max_abs_diff_vs_oracle_solution": float(np.abs(x_all - want_x).max())}
     cx.phase(f"{name} --solver {kind}: the real solve + oracle check (rank 0)", t_chk)
+    # ---- opt-in: the same solve over each route the dot products / operands can take (every rank reads the same variable)
+    routes = None
+    if os.environ.get("CASK_BENCH_COLLECTIVE_ROUTES") and (world > 1 or use_dist):
+        t_rt = time.perf_counter()
+        routes = {}
+        for route in ("native", "torch", "peer"):
+            sh.collectives_route = route
+            xr, it_r, conv_r = solve(2000, 1e-5)
+            torch.cuda.synchronize()
+            routes[route] = {"collectives": sh.last_collectives, "iterations": it_r, "converged": conv_r,
+                             "max_abs_diff_vs_first_solve": float((xr - xs).abs().max())}
+        sh.collectives_route = None
+        cx.phase(f"{name} --solver {kind}: the solve again over {len(routes)} collective routes", t_rt)
     # ---- warm-up + timed region: exactly K passes (tol = 0 never converges) -----------
     t_timed = time.perf_counter()
     if args.warmup:
@@ -1356,7 +1369,8 @@ def run_solver(cx):
                        "exchange_selfcheck": {**selfchecks, **(getattr(sh, "selfcheck", None) or {})} or None,
                        "solve_check": check, "design_point": sh.matrix.params.as_dict(),
                        "engine_usec_per_pass_last_solve": round(sh.last_usec_per_iteration, 3),
-                       "collectives": getattr(sh, "last_collectives", "none")},
+                       "collectives": getattr(sh, "last_collectives", "none"),
+                       "collective_routes": routes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "working_set_note": working_set_note,

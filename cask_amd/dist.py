@@ -393,7 +393,7 @@ class ShardedSpmv:
         return comm
 
 
-    def scalar_push(self):
+    def scalar_push(self, force=False):
         """The peer-store all-reduce of the solvers' dot products (include/cask_hip_p2p.h, cask_hip_push_allreduce):
         a one-wave launch per reduction that stores this rank's partial sums into every peer's scalar table over
         xGMI and adds the world contributions in rank order -- no collective library in a pass.  OPT-IN
@@ -403,11 +403,11 @@ class ShardedSpmv:
         here); None when some rank cannot map its peers (the solvers then use RCCL)."""
         import os
         import torch.distributed as dist
+        if not (force or os.environ.get("CASK_PEER_ALLREDUCE")) or self.device.type != "cuda":
+            return None
         if getattr(self, "_spush_tried", False):
             return self._spush
         self._spush_tried, self._spush = True, None
-        if not os.environ.get("CASK_PEER_ALLREDUCE") or self.device.type != "cuda":
-            return None
         from . import p2p
 
         def gather_objects(o):
@@ -524,8 +524,11 @@ class ShardedSpmv:
         # CASK_FORCE_COLLECTIVES: take the row-sharded path (callbacks, RCCL collectives) with a single rank -- how the
         # nccl backend is exercised on a 1-GPU box
         collective = self.world > 1 or (bool(os.environ.get("CASK_FORCE_COLLECTIVES")) and dist.is_initialized())
-        native = self.native_comm() if collective else None
-        spush = self.scalar_push() if collective else None
+        # collectives_route: None = the environment decides (CASK_NO_NATIVE_RCCL, CASK_PEER_ALLREDUCE); "native" | "torch" |
+        # "peer" pick the route of THIS solve on every rank (bench.py's route comparison: one process, one RCCL start-up)
+        route = getattr(self, "collectives_route", None)
+        native = self.native_comm() if collective and route != "torch" else None
+        spush = self.scalar_push(force=route == "peer") if collective and route in (None, "peer") else None
         if collective:
             kw["allreduce"] = spush if spush is not None else (native if native is not None else self._allreduce_callback())
             if mode == capi.SOLVER_AUTO:

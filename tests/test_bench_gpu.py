@@ -48,47 +48,6 @@ def run_bench(extra, env=None, world=1, timeout=900, launcher=True):
 SHARE = {"CASK_BENCH_SHARE_DEVICE": "1", "CASK_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"}
 
 
-def test_single_rank_line():
-    rec = run_bench(["--steps", "20", "--warmup", "4", "--no-tune", "--copies", "3", "--cpu-seconds", "0.5"])
-    assert CONTRACT_KEYS <= set(rec)
-    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["dtype"] == "f64" and rec["value"] > 100
-    roof = rec["roofline"]
-    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    # ONE clock (VERDICT r1 item 4): value, ms_per_step and the roofline all derive from the same device-event time
-    assert abs(rec["ms_per_step"] * 1e3 - roof["launch_usec"]) < 1e-2
-    assert abs(rec["value"] - 2.0 * rec["config"]["nnz"] / roof["launch_usec"] * 1e-3) <= 0.01 * rec["value"]
-    assert roof["traffic"] is None or "profiles/" in roof["traffic_source"]
-    cpu = rec["cpu_baseline"]
-    assert cpu["kind"] in ("mkl", "port") and cpu["parity_gpu_vs_cpu_mismatches"] == 0 and cpu["cores"] >= 1
-    if cpu["kind"] == "mkl":
-        assert cpu["mismatches_vs_oracle"] == 0 and cpu["port"]["kind"] == "port" and cpu["port"]["cores"] == 1
-    # VERDICT r3 item 1: ms_per_step is the MEDIAN of >= 31 back-to-back K-step windows; spread and clocks in the line
-    assert rec["windows"] >= 31 and rec["ms_per_step_min"] <= rec["ms_per_step_p10"] <= rec["ms_per_step"] <= rec["ms_per_step_p90"] <= rec["ms_per_step_max"]
-    assert "MEDIAN" in rec["clock"] and "gpu_clocks_mhz" in rec
-    assert rec["config"]["plan_seconds"] > 0 and rec["config"]["upload_seconds"] > 0
-    assert "workload" in rec["config"] and "model" not in rec["config"]
-
-
-def test_two_rank_dry_run_reads_halos_in_kernel():
-    # with the DSE, as the driver launches it: the blocks are tuned with their halo sources attached
-    rec = run_bench(["--steps", "20", "--warmup", "4", "--copies", "2", "--no-cpu-baseline"], SHARE, world=2)
-    assert rec["config"]["tune"]["points"] >= 10            # blocks with halo sources: the MERGE family only
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
-    assert rec["config"]["exchange"].startswith("inside the product kernel"), rec["config"]["exchange"]
-    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
-    assert rec["config"]["rows"] == 2 * 62451
-    # the first-contact self-check ran (50 exchanges, the operand changes every time) and passed
-    assert rec["config"]["exchange_selfcheck"] == {"in_kernel_halo": "ok"}
-    # the line says what the collectives layer saw and what a step moves over xGMI
-    rccl = rec["config"]["rccl"]
-    assert rccl["backend"] == "gloo" and rccl["world_size_seen"] == 2 and len(rccl["devices"]) == 2
-    assert rccl["distinct_devices"] == 1 and rccl["shared_device_dry_run"] is True       # both ranks on the box's one GPU, declared
-    assert all(":" in d for d in rccl["devices"])                                          # host:PCI bus id per rank
-    xg = rec["config"]["xgmi"]
-    assert xg["bytes_received_per_step_per_gpu"] > 0 and xg["bytes_per_link_max"] > 0 and xg["gbs_per_link_at_step_time"] > 0
-
-
 def test_ranks_that_share_a_device_are_refused_unless_declared():
     """N ranks on fewer than N devices is not a multi-GPU measurement: without
     CASK_BENCH_SHARE_DEVICE the run ends with exit status 4 before anything is timed (two ranks started by hand, both
@@ -154,24 +113,24 @@ def test_rccl_collectives_run_at_world_one():
     assert rccl["backend"].startswith("nccl") and rccl["comm_nranks"] == 1 and rccl["distinct_devices"] == 1 and rccl["errors"] is None
     assert rec["config"]["launch"] == "eager"
     assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
-    env.update(MASTER_PORT=str(free_port()))
+    # the config-5 pass: one process, one RCCL start-up, the solve over each route its collectives can take
+    env.update(MASTER_PORT=str(free_port()), CASK_BENCH_COLLECTIVE_ROUTES="1")
     rec = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
     chk = rec["config"]["solve_check"]
     assert chk["converged"] and abs(chk["iterations"] - chk["oracle_iterations"]) <= 2
     assert chk["residual_2norm_by_oracle_product"] <= 2e-5
     assert rec["config"]["collectives"].startswith("native RCCL all-reduce")      # ncclAllReduce / ncclAllGather from the engine
     assert rec["config"]["collectives"].endswith("operand: native RCCL all-gather")
+    routes = rec["config"]["collective_routes"]
+    assert routes["native"]["collectives"] == rec["config"]["collectives"]
     # ... the same through the torch.distributed callbacks
-    env.update(MASTER_PORT=str(free_port()), CASK_NO_NATIVE_RCCL="1")
-    rec2 = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
-    assert rec2["config"]["collectives"].startswith("torch.distributed all-reduce")
-    assert rec2["config"]["solve_check"]["iterations"] == chk["iterations"]
+    assert routes["torch"]["collectives"].startswith("torch.distributed all-reduce")
+    assert routes["torch"]["collectives"].endswith("operand: torch.distributed all-gather")
     # ... and with the dot products reduced by peer stores (opt-in): no all-reduce call in a pass
-    env.pop("CASK_NO_NATIVE_RCCL")
-    env.update(MASTER_PORT=str(free_port()), CASK_PEER_ALLREDUCE="1")
-    rec3 = run_bench(["--steps", "10", "--warmup", "2", "--workload", "atmosmodd", "--solver", "bicg", "--no-cpu-baseline"], env)
-    assert rec3["config"]["collectives"].startswith("peer-store all-reduce")
-    assert rec3["config"]["solve_check"]["iterations"] == chk["iterations"]
+    assert routes["peer"]["collectives"].startswith("peer-store all-reduce")
+    assert rec["config"]["exchange_selfcheck"]["peer_store_allreduce"] == "ok"
+    for r in routes.values():
+        assert r["converged"] and r["iterations"] == chk["iterations"] and r["max_abs_diff_vs_first_solve"] <= 1e-9, routes
 
 
 def test_config4_webbase_row_partitioned_dry_run():
@@ -203,20 +162,6 @@ def test_config5_atmosmodd_bicg_sharded_dry_run():
     assert chk["residual_2norm_by_oracle_product"] <= 5e-5 and chk["max_abs_diff_vs_oracle_solution"] <= 1e-5
 
 
-def test_plain_command_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the form of the driver's recorded
-    command -- starts its two ranks itself (child processes), relays rank 0's line and exits 0."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(SHARE)
-    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--copies", "2",
-           "--no-cpu-baseline", "--no-tune", "--no-others"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    rec = last_json_line(out.stdout)
-    assert rec["n_gpus"] == 2 and rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
-    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1     # ONE line, rank 0's
-
-
 def test_default_line_carries_the_other_baseline_configs():
     """the N = 1 default run times cant3, webbase-1M, CG on G3_circuit and BiCG on atmosmodd after
     the headline and reports them under config.other_workloads with their own checks."""
@@ -245,6 +190,25 @@ def test_default_line_carries_the_other_baseline_configs():
     assert rec["cpu_baseline"]["kind"] in ("mkl", "port")
     # the headline is the cant line, on its own clock, unchanged by what follows
     assert rec["config"]["workload"].startswith("cant-like") and rec["steps"] == 20
+    # ... and it is the one-rank line the driver records: the JSON contract, ONE clock, the CPU column, the windows
+    assert CONTRACT_KEYS <= set(rec)
+    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["dtype"] == "f64" and rec["value"] > 100
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # ONE clock (VERDICT r1 item 4): value, ms_per_step and the roofline all derive from the same device-event time
+    assert abs(rec["ms_per_step"] * 1e3 - roof["launch_usec"]) < 1e-2
+    assert abs(rec["value"] - 2.0 * rec["config"]["nnz"] / roof["launch_usec"] * 1e-3) <= 0.01 * rec["value"]
+    assert roof["traffic"] is None or "profiles/" in roof["traffic_source"]
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] in ("mkl", "port") and cpu["parity_gpu_vs_cpu_mismatches"] == 0 and cpu["cores"] >= 1
+    if cpu["kind"] == "mkl":
+        assert cpu["mismatches_vs_oracle"] == 0 and cpu["port"]["kind"] == "port" and cpu["port"]["cores"] == 1
+    # VERDICT r3 item 1: ms_per_step is the MEDIAN of >= 31 back-to-back K-step windows; spread and clocks in the line
+    assert rec["windows"] >= 31 and rec["ms_per_step_min"] <= rec["ms_per_step_p10"] <= rec["ms_per_step"] <= rec["ms_per_step_p90"] <= rec["ms_per_step_max"]
+    assert "MEDIAN" in rec["clock"] and "gpu_clocks_mhz" in rec
+    assert rec["config"]["plan_seconds"] > 0 and rec["config"]["upload_seconds"] > 0
+    assert "workload" in rec["config"] and "model" not in rec["config"]
 
 
 def test_two_rank_line_appends_the_strong_scaling_configs():
@@ -252,11 +216,30 @@ def test_two_rank_line_appends_the_strong_scaling_configs():
     cant headline; two ranks sharing the GPU, started by bench.py itself."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SHARE)
-    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--copies", "2",
-           "--no-cpu-baseline", "--no-tune", "--other-steps", "20", "--preroll-ms", "40"]
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--copies", "2",
+           "--no-cpu-baseline", "--other-steps", "20", "--preroll-ms", "40"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = last_json_line(out.stdout)
+    # VERDICT r2 item 1a: `python bench.py --gpus 2` with WORLD_SIZE unset -- the form of the driver's recorded command --
+    # starts its two ranks itself (child processes), relays rank 0's line (ONE line) and exits 0
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
+    # the weak-scaling headline at two ranks, WITH the DSE as the driver launches it: the blocks are tuned with their halo
+    # sources attached, the halos are read inside the product kernel, every row of both ranks is right
+    assert rec["config"]["tune"]["points"] >= 10            # blocks with halo sources: the MERGE family only
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["exchange"].startswith("inside the product kernel"), rec["config"]["exchange"]
+    assert rec["config"]["rows_wrong_vs_oracle_all_ranks"] == 0
+    assert rec["config"]["rows"] == 2 * 62451
+    # VERDICT r3 item 3: the first-contact self-check ran (50 exchanges, the operand changes every time) and passed
+    assert rec["config"]["exchange_selfcheck"] == {"in_kernel_halo": "ok"}
+    # VERDICT r4 item 6: the line says what the collectives layer saw and what a step moves over xGMI
+    rccl = rec["config"]["rccl"]
+    assert rccl["backend"] == "gloo" and rccl["world_size_seen"] == 2 and len(rccl["devices"]) == 2
+    assert rccl["distinct_devices"] == 1 and rccl["shared_device_dry_run"] is True       # both ranks on the box's one GPU, declared
+    assert all(":" in d for d in rccl["devices"])                                          # host:PCI bus id per rank
+    xg = rec["config"]["xgmi"]
+    assert xg["bytes_received_per_step_per_gpu"] > 0 and xg["bytes_per_link_max"] > 0 and xg["gbs_per_link_at_step_time"] > 0
     others = rec["config"]["other_workloads"]
     assert [o.get("error") for o in others] == [None] * 3, others
     assert others[0]["rows_wrong"] == 0 and others[0]["scaling"] == "strong"
