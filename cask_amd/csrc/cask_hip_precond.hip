@@ -27,6 +27,7 @@
 #include "cask_hip.h"
 #include "internal.hpp"
 #include "spmv_common.hpp"
+#include "trsv_lanes.hpp"
 
 using caskhip::DevBuf;
 using caskhip::report_failure;
@@ -789,8 +790,8 @@ struct TriFactor {
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
-  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; bool long_rows; int d0 = -1, d1 = -1; };   // levels [l0,l1) = positions [lo,hi) of `order`;
-  std::vector<Step> steps;                                      // chunks [c0,c1) of the packed form (c0 < 0: none)
+  struct Step { int l0, l1, lo, hi; bool wide; int c0, c1; bool long_rows; int d0 = -1, d1 = -1, g0 = -1, g1 = -1, ge = 0; };   // levels [l0,l1) = positions [lo,hi) of `order`;
+  std::vector<Step> steps;                                      // chunks [c0,c1) of the packed form (c0 < 0: none), [d0,d1) of walk2's, [g0,g1) of the lane-group walk's
   // the factor once more in level order for k_trsv_packed (see there)
   DevBuf<int> pk_row, pk_eptr, pk_seg;
   DevBuf<int4> pk_hdr;
@@ -807,6 +808,9 @@ struct TriFactor {
   bool w2_ok = false, walk2 = false;                // walk2: this factor is solved by k_trsv_walk2 (position space)
   DevBuf<int4> w2_hdr;
   mutable DevBuf<unsigned long long> w2_dbg;
+  // ... and the slabs of k_trsv_lanes (trsv_lanes.hpp) for the runs of narrow levels with long rows
+  DevBuf<char> ln_lanes;
+  DevBuf<int> ln_hdr;
 
   int build(int n_, bool lower_, const std::vector<int> &h_rp, const std::vector<int> &h_ci,
             const std::vector<double> &h_val) {
@@ -853,7 +857,7 @@ struct TriFactor {
       any_long = any_long || st.long_rows;
     }
     (void)any_long;
-    walk2 = forced_mode() == 4 || forced_mode() == 0;
+    walk2 = forced_mode() == 4 || forced_mode() == 0 || forced_mode() == 6;
     int rc = walk2 ? build_walk2(h_rp, h_ci, h_val, level, lp, ord) : build_packed(h_rp, h_ci, h_val, level, lp, ord);
     if (rc) return rc;
     PC_TRY(rp.upload(h_rp));
@@ -1109,6 +1113,21 @@ struct TriFactor {
       }
       st.d1 = (int)(hdr.size() / 3);
     }
+    // The lane-group walk (trsv_lanes.hpp) for the runs with long rows -- every run that qualifies under
+    // CASK_HIP_TRSV=lanes, none under CASK_HIP_TRSV=walk2.  Position space as above: the gather / scatter around the solve,
+    // b, x and the diagonals are shared with walk2, which remains the run's fallback.
+    std::vector<char> ln_bytes;
+    std::vector<int> ln_words;
+    if (forced_mode() != 4)
+      for (Step &st : steps) {
+        if (st.wide || !(st.long_rows || forced_mode() == 6)) continue;
+        const size_t g0 = ln_words.size() / caskhip_lanes::LN_HDR_INTS;
+        st.ge = caskhip_lanes::build_lanes_run(st.l0, st.l1, st.lo, lp, peptr, ppos, pval, ln_bytes, ln_words);
+        if (st.ge) {
+          st.g0 = (int)g0;
+          st.g1 = (int)(ln_words.size() / caskhip_lanes::LN_HDR_INTS);
+        }
+      }
     pval.push_back(0.0);                                      // spare elements: the kernels' clamped loads
     ppos.push_back(0);
     early_list.push_back(W2Early{0, 0});
@@ -1145,6 +1164,26 @@ struct TriFactor {
       (void)hipGetLastError();
       for (Step &st : steps) st.d0 = -1;
     }
+    bool ln_ok = !ln_words.empty() && lds_max >= (int)caskhip_lanes::LN_LDS_BYTES;
+    for (const void *fn : {reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 4>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 4>),
+                           reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 8>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 8>),
+                           reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 16>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 16>)})
+      ln_ok = ln_ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)caskhip_lanes::LN_LDS_BYTES) == hipSuccess;
+    if (ln_ok) {
+      PC_TRY(ln_lanes.upload(ln_bytes));
+      PC_TRY(ln_hdr.upload(ln_words));
+    } else {
+      (void)hipGetLastError();
+      for (Step &st : steps) st.g0 = -1;
+    }
+    if (std::getenv("CASK_HIP_TRSV_STATS")) {
+      size_t runs = 0, chunks = 0;
+      int e_max = 0;
+      for (const Step &st : steps)
+        if (st.g0 >= 0) { runs++; chunks += st.g1 - st.g0; e_max = std::max(e_max, st.ge); }
+      std::fprintf(stderr, "lanes %s: %zu runs of narrow levels, %zu chunks (%.1f MB), up to %d entries per lane\n", lower ? "L" : "U", runs,
+                   chunks, ln_bytes.size() / 1e6, e_max);
+    }
     return CASK_HIP_OK;
   }
 
@@ -1158,7 +1197,7 @@ struct TriFactor {
       const char *force = std::getenv("CASK_HIP_TRSV");
       if (!force) return 0;
       const std::string f(force);
-      return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : 0;
+      return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : f == "lanes" ? 6 : 0;
     }();
     return mode;
   }
@@ -1167,6 +1206,7 @@ struct TriFactor {
     const int flags = (lower ? 1 : 0) | (unit ? 2 : 0);
     if (walk2 && n > 0 && w2_bp.p) {                            // the whole solve in position space
       const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_early.p, w2_hdr.p};
+      const caskhip_lanes::LanesTri ln{ln_lanes.p, ln_hdr.p, w2_pdiag.p};
       const int pg = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256), u = unit ? 1 : 0;
       PC_TRY(hipMemsetAsync(w2_progress.p, 0, sizeof(int), s));
       hipLaunchKernelGGL(k_w2_gather, dim3(pg), dim3(256), 0, s, n, order.p, d_b, w2_bp.p);
@@ -1174,6 +1214,15 @@ struct TriFactor {
         if (st.wide)
           hipLaunchKernelGGL(k_trsv_level_p, dim3((st.hi - st.lo + 255) / 256), dim3(256), 0, s, st.lo, st.hi, u, w2_eptr.p,
                              w2_epos.p, w2_eval.p, w2_pdiag.p, w2_bp.p, w2_xp.p);
+        else if (st.g0 >= 0) {
+          using namespace caskhip_lanes;
+          auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(LN_GRID), dim3(LN_T), LN_LDS_BYTES, s, ln, st.g0, st.g1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
+          };
+          if (st.ge == 4) unit ? go(k_trsv_lanes<true, 4>) : go(k_trsv_lanes<false, 4>);
+          else if (st.ge == 8) unit ? go(k_trsv_lanes<true, 8>) : go(k_trsv_lanes<false, 8>);
+          else unit ? go(k_trsv_lanes<true, 16>) : go(k_trsv_lanes<false, 16>);
+        }
         else if (st.d0 < 0)
           hipLaunchKernelGGL(k_trsv_levels_p, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, u, level_ptr.p, w2_eptr.p, w2_epos.p,
                              w2_eval.p, w2_pdiag.p, w2_bp.p, w2_xp.p);
@@ -1194,7 +1243,7 @@ struct TriFactor {
         (void)hipMemcpy(h, w2_dbg.p, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipMemset(w2_dbg.p, 0, sizeof(h));
         if (h[3])
-          std::fprintf(stderr, "walk2 %s: chunks %llu | cycles/chunk: walker at the barrier %.0f, walking %.0f | stagers at the barrier %.0f, working %.0f (load wait %.0f, stage %.0f, issue loads %.0f, write back %.0f)\n",
+          std::fprintf(stderr, "walk %s: chunks %llu | cycles/chunk: walker at the barrier %.0f, walking %.0f | stagers at the barrier %.0f, working %.0f (load wait %.0f, stage %.0f, issue loads %.0f, write back %.0f)\n",
                        lower ? "L" : "U", h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[4] / h[3], (double)h[6] / h[3],
                        (double)h[8] / h[3], (double)h[9] / h[3], (double)h[10] / h[3], (double)h[11] / h[3]);
       }

@@ -1,0 +1,408 @@
+// The lane-group walk (k_trsv_lanes, round 5): runs of narrow levels whose rows are LONG (an FEM factor: the cant-like
+// ILU(0) factors have 32 entries a row in levels of ~7 rows).
+//
+// k_trsv_walk2 gives a row to ONE lane: 7 of the walker's 64 lanes then chain 32 dependent multiply-adds and 32 LDS
+// reads per level -- ~1 us a level, 16.8 ms per ILU(0) application on the cant-like factors, where one CPU core running
+// the reference's mkl_dcsrtrsv needs 2.0 ms (profiles/r05_trsv.txt).  Here a row gets a GROUP of G = 1 .. 64 lanes
+// (a power of two; E = 4, 8 or 16 entries per lane, one E per run of levels), the group's partial sums are added by
+// log2 G DPP steps, and the group's last lane subtracts from the right-hand side, divides and writes the ring:
+//   * SLABS.  The host cuts every level into slabs of consecutive rows that fit 64 lanes at one G (the largest of the
+//     slab) and writes, per slab and lane, a record of E values and E LDS byte addresses (the ring slots of their x
+//     values; an absent entry is value +0.0 at the address of a constant 0.0).  32 / E slabs are a chunk: 24 KB of
+//     records + the right-hand sides and diagonals of its <= 512 positions + a 64-byte header.  The stream is the LDS
+//     image itself.  E is the one of the three that makes the run cheapest (fewest slabs: a level is a dependent step
+//     whatever its width; at E = 8 a cant-like level -- 7 rows of 25-45 entries -- is ONE slab of 7 x 8 lanes).
+//   * STAGERS (waves 1-3) copy chunk k + 1 into the other half of a double buffer while the walker is on chunk k,
+//     request chunk k + 3 behind it (two register sets: a load has two phases to land), and write chunk k - 1's results
+//     from the ring to memory (position space: the gather / scatter kernels of walk2 surround the solve).  One barrier
+//     per chunk; a chunk's header carries its own span of positions and that of the chunk two behind it, so no address
+//     waits for a load of the same phase.
+//   * WALKER (wave 0): per slab E x reads, E multiply-adds in two or four chains, <= 6 DPP additions, the division,
+//     the ring write -- LDS operations of one wave execute in order, so a level's reads go out right behind the
+//     previous level's write, without a barrier.  The records of the slabs ahead are requested in the shadow of that
+//     chain (behind the x reads: the compiler is kept from hoisting them).
+//   * READ-AHEAD (workgroup 8 of 9: the same XCD, the same L2) touches the lines of the chunks ten ahead, as in walk2.
+// A run of levels qualifies if no row has more than 1 024 entries and every source is inside the LDS ring (the producer
+// within LN_RING positions of the consumer's level end, in the same run); anything else stays with walk2.
+//
+// Arithmetic: a row's products are added lane group by lane group, not in stored order -- the result differs from the
+// other schedules' in the last bits (same plan, same bits: reproducible run to run); tests compare it with them and
+// with the oracle under a tolerance.  Reference: the solves of ILUPreconditioner::apply
+// (src/runtime/SparseLinearSolvers.hpp:143-151, MklLayer.hpp:29-85).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace caskhip_lanes {
+
+typedef double ln_dbl2 __attribute__((ext_vector_type(2)));
+typedef int ln_int4 __attribute__((ext_vector_type(4)));
+
+constexpr int LN_ST = 192, LN_T = 64 + LN_ST;            // wave 0 walks, the others stage
+constexpr int LN_GRID = 9;                                // workgroup 0 solves, workgroup 8 (same XCD) reads ahead
+constexpr int LN_RING = 8192;                             // x values of the most recent positions (LDS)
+constexpr int LN_REC_BYTES = 24576;                       // records of a chunk: 2 048 entry slots of 12 bytes
+constexpr int LN_CMAX = 8;                                // slabs per chunk at E = 4 (32 / E in general)
+constexpr int LN_TAB_BYTES = 256;                         // per slab a word per lane: where its result goes | its row << 20
+constexpr int LN_CHUNK_BYTES = LN_REC_BYTES + LN_CMAX * LN_TAB_BYTES;   // a chunk in memory: records, then the slabs' lane words
+constexpr int LN_ROWS = 64 * LN_CMAX;                     // positions a chunk can hold
+constexpr int LN_UNITS = LN_CHUNK_BYTES / 16;             // 16-byte units per chunk (at E > 4 the last ones are unused)
+constexpr int LN_UJ = (LN_UNITS + LN_ST - 1) / LN_ST;     // ... per stager thread
+constexpr int LN_RJ = (LN_ROWS + LN_ST - 1) / LN_ST;      // right-hand sides per stager thread
+constexpr int LN_HDR_INTS = 16;   // per chunk: [8] first position, [9] positions, [10] [11] the same of the chunk two behind, [12] E
+constexpr int LN_ZERO = 8 * LN_RING;                      // LDS byte address of a constant 0.0 ...
+constexpr int LN_DUMP = LN_ZERO + 8;                      // ... and of a slot nobody reads
+constexpr int LN_BUF0 = LN_ZERO + 16;
+constexpr int LN_OFF_B = LN_CHUNK_BYTES, LN_OFF_D = LN_OFF_B + 8 * (LN_ROWS + 64), LN_BUF_BYTES = LN_OFF_D + 8 * (LN_ROWS + 64);
+constexpr size_t LN_LDS_BYTES = LN_BUF0 + 2 * (size_t)LN_BUF_BYTES;
+static_assert(LN_BUF0 % 16 == 0 && LN_BUF_BYTES % 16 == 0 && LN_REC_BYTES % 16 == 0, "16-byte LDS accesses");
+static_assert(LN_DUMP < (1 << 17) && LN_ROWS + 64 < (1 << 10), "lane word: 17 bits of LDS address, 10 of row, 3 of log2 G");
+static_assert(LN_LDS_BYTES <= 160 * 1024, "one workgroup's LDS on gfx950");
+static_assert((LN_RING & (LN_RING - 1)) == 0 && LN_RING >= 4 * LN_ROWS, "ring slots by position mod LN_RING; write-back lags two chunks");
+
+// lane word (one per slab and lane): LDS byte address of its result -- the row's ring slot in the last lane of a group,
+// the dump slot elsewhere -- | row (relative to the chunk's first position) << 17 | log2(lanes per row) << 27
+__host__ __device__ constexpr int ln_lane_word(int dst, int row, int lg) { return dst | (row << 17) | (lg << 27); }
+__host__ __device__ constexpr int ln_slabs_per_chunk(int e) { return 32 / e; }
+
+struct LanesTri {
+  const char *lanes;                   // [chunks][LN_CHUNK_BYTES]
+  const int *hdr;                      // [chunks][LN_HDR_INTS]
+  const double *diag;                  // position space (walk2's)
+};
+
+__device__ __forceinline__ void ln_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);                         // vmcnt 63, expcnt 7, lgkmcnt 0 (the compiler's bookkeeping sees it)
+  __builtin_amdgcn_s_barrier();
+}
+// a + (a as the DPP control moves it; lanes without a source and rows outside ROWMASK add +0.0)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double ln_dpp_add(double a) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, ROWMASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, ROWMASK, 0xf, true);
+  return a + __hiloint2double(hi, lo);
+}
+
+// LDS by byte address.  The kernel has no static LDS, so its dynamic LDS starts at address 0 and the addresses the host
+// wrote into the stream are used as they stand (adding the array's base would be a VALU instruction per access, and the
+// walker is bound by the instructions it issues).
+#define LN_AS3 __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ T ln_ld(int addr) { return *(const LN_AS3 T *)(unsigned)addr; }
+template <typename T>
+__device__ __forceinline__ void ln_st(int addr, T v) { *(LN_AS3 T *)(unsigned)addr = v; }
+
+// One chunk by the walker wave: its slabs back to back, fully unrolled (straight-line code: the compiler counts the LDS
+// operations in flight).  base: the LDS byte address of the chunk's buffer.
+template <bool UNIT, int E>
+__device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
+  constexpr int C = ln_slabs_per_chunk(E), LANE_BYTES = 12 * E, SLAB_BYTES = 64 * LANE_BYTES;
+  constexpr int AHEAD = C >= 8 ? 3 : C >= 4 ? 2 : 1;          // slabs whose records are held ahead of the one being solved
+  constexpr int NCH = E >= 8 ? 4 : 2;                         // independent multiply-add chains per lane
+  ln_dbl2 v[C][E / 2];
+  ln_int4 a[C][E / 4];
+  int tw[C];
+  const int rec0 = base + lane * LANE_BYTES, tab0 = base + LN_REC_BYTES + 4 * lane;
+  auto preload = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < E / 2; q++) v[s][q] = ln_ld<ln_dbl2>(rec0 + s * SLAB_BYTES + 16 * q);
+#pragma unroll
+    for (int q = 0; q < E / 4; q++) a[s][q] = ln_ld<ln_int4>(rec0 + s * SLAB_BYTES + 8 * E + 16 * q);
+    tw[s] = ln_ld<int>(tab0 + s * LN_TAB_BYTES);
+  };
+#pragma unroll
+  for (int s = 0; s < AHEAD; s++) preload(s);
+#pragma unroll
+  for (int s = 0; s < C; s++) {
+    double x[E];
+#pragma unroll
+    for (int t = 0; t < E; t++) x[t] = ln_ld<double>(a[s][t >> 2][t & 3]);
+    const int brow = base + LN_OFF_B + ((tw[s] >> 14) & 0x1ff8);
+    const double rb = ln_ld<double>(brow);
+    double rd = 1.0;
+    if constexpr (!UNIT) rd = ln_ld<double>(brow + (LN_OFF_D - LN_OFF_B));
+    asm volatile("" ::: "memory");                            // the x reads go out first: the chain below waits for them
+    if (s + AHEAD < C) preload(s + AHEAD);
+    double ch[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) ch[c] = v[s][c >> 1][c & 1] * x[c];
+#pragma unroll
+    for (int t = NCH; t < E; t++) ch[t % NCH] = fma(v[s][t >> 1][t & 1], x[t], ch[t % NCH]);
+    double acc = NCH == 4 ? (ch[0] + ch[1]) + (ch[2] + ch[3]) : ch[0] + ch[1];
+    // the group's sum ends up in its LAST lane: an inclusive scan over windows of 2, 4, .. lanes (groups are aligned);
+    // log2(lanes per row) is the slab's, the same in every lane's word: a scalar
+    const int lg = (__builtin_amdgcn_readfirstlane(tw[s]) >> 27) & 7;
+    if (lg >= 1) {
+      acc = ln_dpp_add<0x111, 0xf>(acc);                      // row_shr:1
+      if (lg >= 2) {
+        acc = ln_dpp_add<0x112, 0xf>(acc);                    // row_shr:2
+        if (lg >= 3) {
+          acc = ln_dpp_add<0x114, 0xf>(acc);                  // row_shr:4
+          if (lg >= 4) {
+            acc = ln_dpp_add<0x118, 0xf>(acc);                // row_shr:8
+            if (lg >= 5) {
+              acc = ln_dpp_add<0x142, 0xa>(acc);              // row_bcast15 -> rows 1, 3
+              if (lg >= 6) acc = ln_dpp_add<0x143, 0xc>(acc); // row_bcast31 -> rows 2, 3
+            }
+          }
+        }
+      }
+    }
+    double xn = rb - acc;
+    if constexpr (!UNIT) xn = xn / rd;
+    ln_st<double>(tw[s] & 0x1ffff, xn);
+  }
+}
+
+template <bool UNIT, int E>
+__global__ void __launch_bounds__(LN_T)
+k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *xp, int *progress,
+             unsigned long long *dbg) {
+  constexpr int C = ln_slabs_per_chunk(E), UNITS = (LN_REC_BYTES + C * LN_TAB_BYTES) / 16;   // what a chunk of this E holds
+  if (blockIdx.x != 0) {
+    if (blockIdx.x != 8) return;
+    // read-ahead: one word per 128-byte line of the chunks the stagers will ask for, paced by the progress word.
+    // Nothing depends on it: if it falls behind or lands on another XCD the solve is only slower.
+    constexpr int FETCH_AHEAD = 10;
+    unsigned acc = 0;
+    const int ft = threadIdx.x;
+    for (int f = c0 + 3; f < c1; f++) {
+      for (int polls = 0; polls < (1 << 14); polls++) {       // bounded
+        if (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + FETCH_AHEAD >= f) break;
+        __builtin_amdgcn_s_sleep(20);
+      }
+      const int p0 = t.hdr[LN_HDR_INTS * f + 8], rows = t.hdr[LN_HDR_INTS * f + 9];
+      for (int u = ft; u < UNITS / 8 + 64; u += LN_T) {
+        if (u < UNITS / 8)
+          acc += *reinterpret_cast<const unsigned *>(t.lanes + (size_t)f * LN_CHUNK_BYTES + 128 * u);
+        else {
+          const int q = u - UNITS / 8;                        // 32 lines of b, 32 of the diagonal (LN_ROWS * 8 / 128)
+          const long a = ((8L * p0) & ~127L) + 128L * (q & 31);
+          if (a < 8L * (p0 + rows)) {
+            if (q < 32) acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(bp) + a);
+            else if (!UNIT) acc += *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.diag) + a);
+          }
+        }
+      }
+    }
+    if (acc == 0x9e3779b9u) *progress = -1;                   // (keeps the loads alive)
+    return;
+  }
+  extern __shared__ double ln_lds[];
+  char *lds = reinterpret_cast<char *>(ln_lds);
+  double *ring = ln_lds;
+  const int tid = threadIdx.x, lane = tid & 63, st = tid - 64;
+  auto buf_base = [&](int which) { return LN_BUF0 + which * LN_BUF_BYTES; };
+
+  if (tid < 64) {
+    // ------------------------------------------------------------------------------------------------ the walker
+    unsigned long long d_wait = 0, d_walk = 0;
+    for (int k = c0; k < c1; k++) {
+      const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+      ln_barrier();                                           // chunk k is staged
+      const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+      ln_walk_chunk<UNIT, E>(buf_base((k - c0) & 1), lane);
+      if (dbg) {                                              // CASK_HIP_TRSV_STATS: cycles at the barrier / walking
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        d_wait += q1 - q0;
+        d_walk += __builtin_amdgcn_s_memtime() - q1;
+      }
+    }
+    if (dbg && lane == 0) { atomicAdd(dbg + 0, d_wait); atomicAdd(dbg + 1, d_walk); atomicAdd(dbg + 3, (unsigned long long)(c1 - c0)); }
+    ln_barrier();                                             // the last chunk's x values are in the ring
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- the stagers
+  if (tid == 64) {
+    *reinterpret_cast<double *>(lds + LN_ZERO) = 0.0;
+    *reinterpret_cast<double *>(lds + LN_DUMP) = 0.0;
+  }
+  // Two register sets: chunk j lives in set (j - c0) & 1 from the phase that requests it (j - 3) to the phase that
+  // stages it (j - 1).  hq: unit (st & 3) of the chunk's header -- lane 2 of every wave holds {first position, positions,
+  // first position and positions of the chunk two behind}.
+  struct Set {
+    ln_int4 u[LN_UJ], hq;
+    double lb[LN_RJ], ld[LN_RJ];
+  };
+  Set S0, S1;
+  const ln_int4 *lanes4 = reinterpret_cast<const ln_int4 *>(t.lanes);
+  const ln_int4 *hdr4 = reinterpret_cast<const ln_int4 *>(t.hdr);
+  auto load = [&](Set &X, int k, int p0, int rows) {          // chunk k (clamped: loads past the end repeat the last chunk)
+    const int kk = min(k, c1 - 1);
+#pragma unroll
+    for (int j = 0; j < LN_UJ; j++) X.u[j] = lanes4[(size_t)kk * LN_UNITS + min(st + LN_ST * j, UNITS - 1)];
+#pragma unroll
+    for (int j = 0; j < LN_RJ; j++) {
+      const int p = p0 + min(st + LN_ST * j, max(rows - 1, 0));
+      X.lb[j] = bp[p];
+      if constexpr (!UNIT) X.ld[j] = t.diag[p];
+    }
+    X.hq = hdr4[(size_t)kk * (LN_HDR_INTS / 4) + (st & 3)];
+  };
+  auto stage = [&](const Set &X, int which, int rows) {       // registers -> buffer `which`
+    char *buf = lds + buf_base(which);
+#pragma unroll
+    for (int j = 0; j < LN_UJ; j++)
+      if (st + LN_ST * j < UNITS) *reinterpret_cast<ln_int4 *>(buf + 16 * (st + LN_ST * j)) = X.u[j];
+#pragma unroll
+    for (int j = 0; j < LN_RJ; j++) {
+      const int r = st + LN_ST * j;
+      if (r < rows) {
+        *reinterpret_cast<double *>(buf + LN_OFF_B + 8 * r) = X.lb[j];
+        if constexpr (!UNIT) *reinterpret_cast<double *>(buf + LN_OFF_D + 8 * r) = X.ld[j];
+      }
+    }
+  };
+  auto write_back = [&](int p0, int rows) {                   // ring -> xp
+    if (rows > 0) {
+#pragma unroll
+      for (int j = 0; j < LN_RJ; j++) {
+        const int p = p0 + min(st + LN_ST * j, rows - 1);
+        xp[p] = ring[p & (LN_RING - 1)];
+      }
+    }
+  };
+  auto span_of = [&](int k, int &p0, int &rows) {             // (prologue only: scalar loads)
+    const int kk = min(k, c1 - 1);
+    p0 = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 8]);
+    rows = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 9]);
+  };
+  int pW, rW, pV = 0, rV = 0;                                 // chunk k (being walked) and chunk k - 1 (written back in phase k)
+  {
+    int p1, r1, p2, r2;
+    span_of(c0, pW, rW);
+    span_of(c0 + 1, p1, r1);
+    span_of(c0 + 2, p2, r2);
+    load(S0, c0, pW, rW);
+    load(S1, c0 + 1, p1, r1);
+    stage(S0, 0, rW);                                         // chunk c0 (waits for its loads)
+    load(S0, c0 + 2, p2, r2);
+  }
+  unsigned long long e_wait = 0, e_work = 0;
+  auto phase = [&](Set &X, int k) {                           // X holds chunk k + 1
+    const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    ln_barrier();                                             // phase k: the walker is on chunk k
+    const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (tid == 64) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int pN = __builtin_amdgcn_readlane(X.hq.x, 2), rN = __builtin_amdgcn_readlane(X.hq.y, 2);      // chunk k + 1
+    const int p3 = __builtin_amdgcn_readlane(X.hq.z, 2), r3 = __builtin_amdgcn_readlane(X.hq.w, 2);      // chunk k + 3
+    if (k + 1 < c1) stage(X, (k + 1 - c0) & 1, rN);
+    write_back(pV, rV);                                       // chunk k - 1 (nothing in the first phase)
+    pV = pW; rV = rW; pW = pN; rW = rN;
+    load(X, k + 3, p3, r3);                                   // two phases to land
+    if (dbg) { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long q2 = __builtin_amdgcn_s_memtime(); e_wait += q1 - q0; e_work += q2 - q1; }
+  };
+  for (int k = c0; k < c1; k += 2) {
+    phase(S1, k);
+    if (k + 1 < c1) phase(S0, k + 1);
+  }
+  if (dbg && tid == 64) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
+  ln_barrier();                                               // the last chunk is walked
+  write_back(pV, rV);
+}
+
+// ---- host: the slabs of one run of narrow levels [l0, l1) = positions [lo, ..) -----------------------------------------
+// peptr / ppos / pval: the factor's off-diagonal entries in position space (row = position, source = producer position).
+// Appends whole chunks to `lanes` / `hdr` and returns E (4, 8, 16); 0 (nothing appended) when the run does not qualify.
+inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, const std::vector<int> &peptr,
+                           const std::vector<int> &ppos, const std::vector<double> &pval, std::vector<char> &lanes,
+                           std::vector<int> &hdr) {
+  for (int l = l0; l < l1; l++)
+    for (int i = lp[l]; i < lp[l + 1]; i++) {
+      if (peptr[i + 1] - peptr[i] > 64 * 16) return 0;
+      for (int e = peptr[i]; e < peptr[i + 1]; e++)
+        if (ppos[e] < lo || ppos[e] < lp[l + 1] - LN_RING) return 0;          // a source outside the run or the ring
+    }
+  struct Slab { int p0, nrows, lg; };
+  auto cut = [&](int E, std::vector<Slab> *out) {
+    auto lg_of = [&](int ne) {
+      const int per = (ne + E - 1) / E;
+      int lg = 0;
+      while ((1 << lg) < per) lg++;
+      return lg;
+    };
+    size_t count = 0;
+    for (int l = l0; l < l1; l++)
+      for (int i = lp[l]; i < lp[l + 1];) {
+        int lg = 0, cnt = 0;
+        while (i + cnt < lp[l + 1]) {
+          const int nlg = std::max(lg, lg_of(peptr[i + cnt + 1] - peptr[i + cnt]));
+          if (nlg > 6 || ((cnt + 1) << nlg) > 64) break;
+          lg = nlg;
+          cnt++;
+        }
+        if (cnt == 0) return (size_t)-1;                      // a row too long for this E
+        if (out) out->push_back(Slab{i, cnt, lg});
+        count++;
+        i += cnt;
+      }
+    return count;
+  };
+  // the cheapest E: a slab is a dependent step of ~260 cycles + ~10 per entry of a lane for the walker; a chunk ~1 200
+  // cycles of staging
+  int best_e = 0;
+  double best = 0.0;
+  for (int E : {4, 8, 16}) {
+    const size_t n = cut(E, nullptr);
+    if (n == (size_t)-1) continue;
+    const double walker = (double)n * (260.0 + 10.0 * E), stagers = (double)((n + 32 / E - 1) / (32 / E)) * 1200.0;
+    const double cost = std::max(walker, stagers);
+    if (!best_e || cost < best) { best_e = E; best = cost; }
+  }
+  if (!best_e) return 0;
+  const int E = best_e, C = ln_slabs_per_chunk(E), lane_bytes = 12 * E;
+  std::vector<Slab> slabs;
+  cut(E, &slabs);
+  const size_t n_chunks = (slabs.size() + C - 1) / C;
+  const size_t lanes0 = lanes.size(), hdr0 = hdr.size();
+  lanes.resize(lanes0 + n_chunks * (size_t)LN_CHUNK_BYTES);
+  hdr.resize(hdr0 + n_chunks * (size_t)LN_HDR_INTS, 0);
+  for (size_t k = 0; k < n_chunks; k++) {
+    int *h = hdr.data() + hdr0 + k * LN_HDR_INTS;
+    const int pk = slabs[k * C].p0;
+    int rows = 0;
+    for (int s = 0; s < C; s++) {
+      const size_t si = k * C + s;
+      const Slab sl = si < slabs.size() ? slabs[si] : Slab{pk + rows, 0, 0};   // padding slabs: no rows
+      rows = sl.p0 + sl.nrows - pk;
+      char *rec = lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + (size_t)s * 64 * lane_bytes;
+      int *tab = reinterpret_cast<int *>(lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + LN_REC_BYTES + (size_t)s * LN_TAB_BYTES);
+      for (int lane = 0; lane < 64; lane++, rec += lane_bytes) {
+        double v[16];
+        int a[16];
+        const int row = lane >> sl.lg, g = lane & ((1 << sl.lg) - 1);
+        const bool writer = g == (1 << sl.lg) - 1 && row < sl.nrows;
+        tab[lane] = ln_lane_word(writer ? ((sl.p0 + row) & (LN_RING - 1)) * 8 : LN_DUMP, sl.p0 - pk + row, sl.lg);
+        for (int t = 0; t < E; t++) {
+          v[t] = 0.0;
+          a[t] = LN_ZERO;
+          if (row < sl.nrows) {
+            const int i = sl.p0 + row, e = peptr[i] + g + (t << sl.lg);
+            if (e < peptr[i + 1]) {
+              v[t] = pval[e];
+              a[t] = (ppos[e] & (LN_RING - 1)) * 8;
+            }
+          }
+        }
+        std::memcpy(rec, v, 8 * (size_t)E);
+        std::memcpy(rec + 8 * E, a, 4 * (size_t)E);
+      }
+    }
+    h[8] = pk;
+    h[9] = rows;
+    h[12] = E;
+  }
+  for (size_t k = 0; k < n_chunks; k++) {                     // the span of the chunk two behind (the last ones repeat the last)
+    int *h = hdr.data() + hdr0 + k * LN_HDR_INTS;
+    const int *h2 = hdr.data() + hdr0 + std::min(k + 2, n_chunks - 1) * LN_HDR_INTS;
+    h[10] = h2[8];
+    h[11] = h2[9];
+  }
+  return E;
+}
+
+}  // namespace caskhip_lanes

@@ -247,8 +247,8 @@ def test_packed_walk_random_dependency_graphs(seed):
 
 
 def test_triangular_solve_schedules_agree_bit_for_bit():
-    """Three schedules of the same triangular solve (cask_hip_precond.hip): walker + stagers in position space (walk2, the
-    default), the four-wave packed walk of narrow-level runs (packed, r2) and the row-indexed walk of round 1
+    """Schedules of the same triangular solve (cask_hip_precond.hip): walker + stagers in position space (walk2), the
+    four-wave packed walk of narrow-level runs (packed, r2) and the row-indexed walk of round 1
     (CASK_HIP_TRSV=levels).  (The one-walker-wave kernel and the one-launch synchronisation-free solve, measured losses,
     left the engine in round 5.)  All walk every row in stored order: identical bits -- on a grid factor with thousands
     of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
@@ -305,17 +305,37 @@ for case_no, (n, rp, ci, va) in enumerate(cases):
 np.save(sys.argv[1], np.concatenate(out))
 print(max(levels))
 '''
-    outs = {}
-    for mode in ("levels", "packed", "walk2"):   # packed = the four-wave walk (r2); walk2 = r3, the default
-        path = f"/tmp/cask_trsv_{mode}.npy"
-        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600,
-                             env=dict(os.environ, CASK_HIP_TRSV=mode), cwd=str(REPO))
+    outs, stderr = {}, {}
+    # packed = the four-wave walk (r2); walk2 = r3; lanes = the lane-group walk for every run of levels that qualifies (r5);
+    # "" = the default: lanes where the rows are long (the FEM-like factor), walk2 elsewhere
+    for mode in ("levels", "packed", "walk2", "lanes", ""):
+        path = f"/tmp/cask_trsv_{mode or 'default'}.npy"
+        env = dict(os.environ, CASK_HIP_TRSV=mode, CASK_HIP_TRSV_STATS="1" if mode in ("lanes", "") else "")
+        if not mode:
+            env.pop("CASK_HIP_TRSV")
+        if not env["CASK_HIP_TRSV_STATS"]:
+            env.pop("CASK_HIP_TRSV_STATS")
+        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
         assert res.returncode == 0, res.stderr[-1500:]
         assert int(res.stdout.strip().splitlines()[-1]) > 500
-        outs[mode] = np.load(path)
+        outs[mode], stderr[mode] = np.load(path), res.stderr
     assert np.all(np.isfinite(outs["levels"]))
     assert np.array_equal(outs["levels"], outs["packed"])
     assert np.array_equal(outs["levels"], outs["walk2"])
+    # The lane-group walk adds a row's products group by group, not in stored order: the same solution to rounding.  It
+    # must really have run: everywhere it can under `lanes` (wherever every source is inside the ring and no row exceeds 256 entries), on the FEM-like
+    # factor alone by default.
+    import re
+    def lanes_chunks(text):
+        return [int(m) for m in re.findall(r"lanes [LU]: \d+ runs of narrow levels, (\d+) chunks", text)]
+    n_forced, n_default = (sum(c > 0 for c in lanes_chunks(stderr[m])) for m in ("lanes", ""))
+    print("factors with lane-group runs: forced", n_forced, "default", n_default)
+    assert n_forced >= 6 and 0 < n_default <= n_forced, (n_forced, n_default, stderr["lanes"][-800:])
+    scale = np.abs(outs["levels"]).max()
+    for mode in ("lanes", ""):
+        assert np.all(np.isfinite(outs[mode]))
+        assert np.abs(outs[mode] - outs["levels"]).max() <= 1e-11 * scale, (mode, np.abs(outs[mode] - outs["levels"]).max(), scale)
+    assert not np.array_equal(outs["lanes"], outs["levels"])            # (a different order of additions)
 
 
 def _multicolour_reference(n, rp, ci, va):

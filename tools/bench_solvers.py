@@ -105,7 +105,7 @@ def run_trsv_compare(name, gpu_pcg_passes=24):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
     z_gpu = zt.cpu().numpy()
-    out["gpu"] = {"ms_per_application": round(min(times), 3), "schedule": os.environ.get("CASK_HIP_TRSV", "walk2"),
+    out["gpu"] = {"ms_per_application": round(min(times), 3), "schedule": os.environ.get("CASK_HIP_TRSV", "default: lanes for runs of long rows, walk2 otherwise"),
                   "gbs_algorithmic": round(alg_bytes / (min(times) * 1e-3) / 1e9, 2)}
     # ---- CPU: mkl_dcsrtrsv as the reference calls it
     mkl = bench.load_mkl()
