@@ -7,20 +7,25 @@
 // (a power of two; E = 4, 8 or 16 entries per lane, one E per run of levels), the group's partial sums are added by
 // log2 G DPP steps, and the group's last lane subtracts from the right-hand side, divides and writes the ring:
 //   * SLABS.  The host cuts every level into slabs of consecutive rows that fit 64 lanes at one G (the largest of the
-//     slab) and writes, per slab and lane, a record of E values and E LDS byte addresses (the ring slots of their x
-//     values; an absent entry is value +0.0 at the address of a constant 0.0).  32 / E slabs are a chunk: 24 KB of
-//     records + the right-hand sides and diagonals of its <= 512 positions + a 64-byte header.  The stream is the LDS
-//     image itself.  E is the one of the three that makes the run cheapest (fewest slabs: a level is a dependent step
-//     whatever its width; at E = 8 a cant-like level -- 7 rows of 25-45 entries -- is ONE slab of 7 x 8 lanes).
-//   * STAGERS (waves 1-3) copy chunk k + 1 into the other half of a double buffer while the walker is on chunk k,
-//     request chunk k + 3 behind it (two register sets: a load has two phases to land), and write chunk k - 1's results
-//     from the ring to memory (position space: the gather / scatter kernels of walk2 surround the solve).  One barrier
-//     per chunk; a chunk's header carries its own span of positions and that of the chunk two behind it, so no address
-//     waits for a load of the same phase.
+//     slab) and writes, per slab and lane, E values and E LDS byte addresses (the ring slots of their x values; an
+//     absent entry is value +0.0 at the address of a constant 0.0) -- stored 16-byte unit by unit across the lanes, so
+//     that the wave's 16-byte reads are consecutive -- and a word: where the lane's result goes (the row's ring slot in
+//     a group's last lane, a dump slot elsewhere), its row, log2 G.  32 / E slabs are a chunk: 24 KB of records, the
+//     lane words, and the right-hand sides and diagonals of its <= 512 positions.  The stream is the LDS image itself.
+//     E is the one of the three that makes the run cheapest (fewest slabs: a level is a dependent step whatever its
+//     width; at E = 8 a cant-like level -- 7 rows of 25-45 entries -- is ONE slab of 7 x 8 lanes).
+//   * STAGERS (waves 1-9): three groups of three waves take turns.  A group copies chunk k + 1 into the other half of
+//     a double buffer while the walker is on chunk k, requests chunk k + 4 behind it -- three chunks are in flight, each
+//     with three phases to land: ONE chunk in flight streamed 26 GB/s, a load's latency, and was the limit -- and
+//     writes the results of the chunk of its last turn from the ring to memory (position space: the gather / scatter
+//     kernels of walk2 surround the solve).  One barrier per chunk; a chunk's header carries its own span of positions
+//     and that of the chunk three behind it, so no address waits for a load of the same phase.
 //   * WALKER (wave 0): per slab E x reads, E multiply-adds in two or four chains, <= 6 DPP additions, the division,
 //     the ring write -- LDS operations of one wave execute in order, so a level's reads go out right behind the
 //     previous level's write, without a barrier.  The records of the slabs ahead are requested in the shadow of that
-//     chain (behind the x reads: the compiler is kept from hoisting them).
+//     chain (behind the x reads: the compiler is kept from hoisting them).  It issues no scalar or vector memory
+//     operation and computes no address: ~60 instructions a slab, ~450 cycles (LDS round trip ~130, three DPP steps
+//     ~120, bank conflicts of the x reads ~90: profiles/r05_trsv.txt).
 //   * READ-AHEAD (workgroup 8 of 9: the same XCD, the same L2) touches the lines of the chunks ten ahead, as in walk2.
 // A run of levels qualifies if no row has more than 1 024 entries and every source is inside the LDS ring (the producer
 // within LN_RING positions of the consumer's level end, in the same run); anything else stays with walk2.
@@ -41,7 +46,7 @@ namespace caskhip_lanes {
 typedef double ln_dbl2 __attribute__((ext_vector_type(2)));
 typedef int ln_int4 __attribute__((ext_vector_type(4)));
 
-constexpr int LN_ST = 192, LN_T = 64 + LN_ST;            // wave 0 walks, the others stage
+constexpr int LN_NG = 3, LN_ST = 192, LN_T = 64 + LN_NG * LN_ST;   // wave 0 walks; LN_NG groups of three waves stage, taking turns
 constexpr int LN_GRID = 9;                                // workgroup 0 solves, workgroup 8 (same XCD) reads ahead
 constexpr int LN_RING = 8192;                             // x values of the most recent positions (LDS)
 constexpr int LN_REC_BYTES = 24576;                       // records of a chunk: 2 048 entry slots of 12 bytes
@@ -52,7 +57,7 @@ constexpr int LN_ROWS = 64 * LN_CMAX;                     // positions a chunk c
 constexpr int LN_UNITS = LN_CHUNK_BYTES / 16;             // 16-byte units per chunk (at E > 4 the last ones are unused)
 constexpr int LN_UJ = (LN_UNITS + LN_ST - 1) / LN_ST;     // ... per stager thread
 constexpr int LN_RJ = (LN_ROWS + LN_ST - 1) / LN_ST;      // right-hand sides per stager thread
-constexpr int LN_HDR_INTS = 16;   // per chunk: [8] first position, [9] positions, [10] [11] the same of the chunk two behind, [12] E
+constexpr int LN_HDR_INTS = 16;   // per chunk: [8] first position, [9] positions, [10] [11] the same of the chunk LN_NG behind, [12] E
 constexpr int LN_ZERO = 8 * LN_RING;                      // LDS byte address of a constant 0.0 ...
 constexpr int LN_DUMP = LN_ZERO + 8;                      // ... and of a slot nobody reads
 constexpr int LN_BUF0 = LN_ZERO + 16;
@@ -61,7 +66,7 @@ constexpr size_t LN_LDS_BYTES = LN_BUF0 + 2 * (size_t)LN_BUF_BYTES;
 static_assert(LN_BUF0 % 16 == 0 && LN_BUF_BYTES % 16 == 0 && LN_REC_BYTES % 16 == 0, "16-byte LDS accesses");
 static_assert(LN_DUMP < (1 << 17) && LN_ROWS + 64 < (1 << 10), "lane word: 17 bits of LDS address, 10 of row, 3 of log2 G");
 static_assert(LN_LDS_BYTES <= 160 * 1024, "one workgroup's LDS on gfx950");
-static_assert((LN_RING & (LN_RING - 1)) == 0 && LN_RING >= 4 * LN_ROWS, "ring slots by position mod LN_RING; write-back lags two chunks");
+static_assert((LN_RING & (LN_RING - 1)) == 0 && LN_RING >= (LN_NG + 2) * LN_ROWS, "ring slots by position mod LN_RING; the write-back lags LN_NG chunks");
 
 // lane word (one per slab and lane): LDS byte address of its result -- the row's ring slot in the last lane of a group,
 // the dump slot elsewhere -- | row (relative to the chunk's first position) << 17 | log2(lanes per row) << 27
@@ -91,9 +96,9 @@ __device__ __forceinline__ double ln_dpp_add(double a) {
 // walker is bound by the instructions it issues).
 #define LN_AS3 __attribute__((address_space(3)))
 template <typename T>
-__device__ __forceinline__ T ln_ld(int addr) { return *(const LN_AS3 T *)(unsigned)addr; }
+__device__ __forceinline__ T ln_ld(int addr) { return *(const LN_AS3 T *)(uintptr_t)(unsigned)addr; }
 template <typename T>
-__device__ __forceinline__ void ln_st(int addr, T v) { *(LN_AS3 T *)(unsigned)addr = v; }
+__device__ __forceinline__ void ln_st(int addr, T v) { *(LN_AS3 T *)(uintptr_t)(unsigned)addr = v; }
 
 // One chunk by the walker wave: its slabs back to back, fully unrolled (straight-line code: the compiler counts the LDS
 // operations in flight).  base: the LDS byte address of the chunk's buffer.
@@ -105,12 +110,15 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
   ln_dbl2 v[C][E / 2];
   ln_int4 a[C][E / 4];
   int tw[C];
-  const int rec0 = base + lane * LANE_BYTES, tab0 = base + LN_REC_BYTES + 4 * lane;
+  // a slab's records are stored 16-byte unit by unit (unit q of all 64 lanes, then unit q + 1): a wave's 16-byte reads
+  // are then consecutive (lane by lane at a stride of 12 E bytes they were 4- to 8-way bank conflicts -- six such reads
+  // per slab kept the LDS busy for longer than the whole dependent chain)
+  const int rec0 = base + lane * 16, tab0 = base + LN_REC_BYTES + 4 * lane;
   auto preload = [&](int s) {
 #pragma unroll
-    for (int q = 0; q < E / 2; q++) v[s][q] = ln_ld<ln_dbl2>(rec0 + s * SLAB_BYTES + 16 * q);
+    for (int q = 0; q < E / 2; q++) v[s][q] = ln_ld<ln_dbl2>(rec0 + s * SLAB_BYTES + 1024 * q);
 #pragma unroll
-    for (int q = 0; q < E / 4; q++) a[s][q] = ln_ld<ln_int4>(rec0 + s * SLAB_BYTES + 8 * E + 16 * q);
+    for (int q = 0; q < E / 4; q++) a[s][q] = ln_ld<ln_int4>(rec0 + s * SLAB_BYTES + 1024 * (E / 2 + q));
     tw[s] = ln_ld<int>(tab0 + s * LN_TAB_BYTES);
   };
 #pragma unroll
@@ -194,7 +202,7 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
   extern __shared__ double ln_lds[];
   char *lds = reinterpret_cast<char *>(ln_lds);
   double *ring = ln_lds;
-  const int tid = threadIdx.x, lane = tid & 63, st = tid - 64;
+  const int tid = threadIdx.x, lane = tid & 63, sg = tid - 64;
   auto buf_base = [&](int which) { return LN_BUF0 + which * LN_BUF_BYTES; };
 
   if (tid < 64) {
@@ -217,43 +225,43 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
   }
 
   // -------------------------------------------------------------------------------------------------- the stagers
+  // LN_NG groups of three waves take turns: chunk r (counted from c0) belongs to group r % LN_NG, which requests it
+  // LN_NG phases before it stages it -- LN_NG chunks are in flight, each with LN_NG phases to land (one CU streams
+  // ~26 GB/s with one chunk in flight: a load's latency, not the memory, was the limit) -- and writes its results back
+  // when its turn comes again.  hq: unit (st & 3) of a chunk's header: lane 2 of every wave holds {first position,
+  // positions, first position and positions of the chunk LN_NG behind}.
   if (tid == 64) {
     *reinterpret_cast<double *>(lds + LN_ZERO) = 0.0;
     *reinterpret_cast<double *>(lds + LN_DUMP) = 0.0;
   }
-  // Two register sets: chunk j lives in set (j - c0) & 1 from the phase that requests it (j - 3) to the phase that
-  // stages it (j - 1).  hq: unit (st & 3) of the chunk's header -- lane 2 of every wave holds {first position, positions,
-  // first position and positions of the chunk two behind}.
-  struct Set {
-    ln_int4 u[LN_UJ], hq;
-    double lb[LN_RJ], ld[LN_RJ];
-  };
-  Set S0, S1;
+  const int grp = __builtin_amdgcn_readfirstlane(sg / LN_ST), st = sg % LN_ST;
+  ln_int4 u[LN_UJ], hq;
+  double lb[LN_RJ], ld[LN_RJ];
   const ln_int4 *lanes4 = reinterpret_cast<const ln_int4 *>(t.lanes);
   const ln_int4 *hdr4 = reinterpret_cast<const ln_int4 *>(t.hdr);
-  auto load = [&](Set &X, int k, int p0, int rows) {          // chunk k (clamped: loads past the end repeat the last chunk)
+  auto load = [&](int k, int p0, int rows) {                  // chunk k (clamped: loads past the end repeat the last chunk)
     const int kk = min(k, c1 - 1);
 #pragma unroll
-    for (int j = 0; j < LN_UJ; j++) X.u[j] = lanes4[(size_t)kk * LN_UNITS + min(st + LN_ST * j, UNITS - 1)];
+    for (int j = 0; j < LN_UJ; j++) u[j] = lanes4[(size_t)kk * LN_UNITS + min(st + LN_ST * j, UNITS - 1)];
 #pragma unroll
     for (int j = 0; j < LN_RJ; j++) {
       const int p = p0 + min(st + LN_ST * j, max(rows - 1, 0));
-      X.lb[j] = bp[p];
-      if constexpr (!UNIT) X.ld[j] = t.diag[p];
+      lb[j] = bp[p];
+      if constexpr (!UNIT) ld[j] = t.diag[p];
     }
-    X.hq = hdr4[(size_t)kk * (LN_HDR_INTS / 4) + (st & 3)];
+    hq = hdr4[(size_t)kk * (LN_HDR_INTS / 4) + (st & 3)];
   };
-  auto stage = [&](const Set &X, int which, int rows) {       // registers -> buffer `which`
+  auto stage = [&](int which, int rows) {                     // registers -> buffer `which`
     char *buf = lds + buf_base(which);
 #pragma unroll
     for (int j = 0; j < LN_UJ; j++)
-      if (st + LN_ST * j < UNITS) *reinterpret_cast<ln_int4 *>(buf + 16 * (st + LN_ST * j)) = X.u[j];
+      if (st + LN_ST * j < UNITS) *reinterpret_cast<ln_int4 *>(buf + 16 * (st + LN_ST * j)) = u[j];
 #pragma unroll
     for (int j = 0; j < LN_RJ; j++) {
       const int r = st + LN_ST * j;
       if (r < rows) {
-        *reinterpret_cast<double *>(buf + LN_OFF_B + 8 * r) = X.lb[j];
-        if constexpr (!UNIT) *reinterpret_cast<double *>(buf + LN_OFF_D + 8 * r) = X.ld[j];
+        *reinterpret_cast<double *>(buf + LN_OFF_B + 8 * r) = lb[j];
+        if constexpr (!UNIT) *reinterpret_cast<double *>(buf + LN_OFF_D + 8 * r) = ld[j];
       }
     }
   };
@@ -266,43 +274,44 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
       }
     }
   };
-  auto span_of = [&](int k, int &p0, int &rows) {             // (prologue only: scalar loads)
-    const int kk = min(k, c1 - 1);
-    p0 = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 8]);
-    rows = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 9]);
-  };
-  int pW, rW, pV = 0, rV = 0;                                 // chunk k (being walked) and chunk k - 1 (written back in phase k)
+  int pP = 0, rP = 0;                                         // the chunk this group staged last: written back at its next turn
   {
-    int p1, r1, p2, r2;
-    span_of(c0, pW, rW);
-    span_of(c0 + 1, p1, r1);
-    span_of(c0 + 2, p2, r2);
-    load(S0, c0, pW, rW);
-    load(S1, c0 + 1, p1, r1);
-    stage(S0, 0, rW);                                         // chunk c0 (waits for its loads)
-    load(S0, c0 + 2, p2, r2);
+    const int kk = min(c0 + grp, c1 - 1);                     // the group's first chunk (scalar loads: once)
+    const int p0 = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 8]);
+    const int rows = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 9]);
+    load(c0 + grp, p0, rows);
+    if (grp == 0) {
+      const int pn = __builtin_amdgcn_readlane(hq.z, 2), rn = __builtin_amdgcn_readlane(hq.w, 2);
+      stage(0, rows);                                         // chunk c0 (waits for its loads)
+      pP = p0; rP = rows;
+      load(c0 + LN_NG, pn, rn);
+    }
   }
   unsigned long long e_wait = 0, e_work = 0;
-  auto phase = [&](Set &X, int k) {                           // X holds chunk k + 1
+  for (int k = c0; k < c1; k++) {
     const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     ln_barrier();                                             // phase k: the walker is on chunk k
     const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (tid == 64) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int pN = __builtin_amdgcn_readlane(X.hq.x, 2), rN = __builtin_amdgcn_readlane(X.hq.y, 2);      // chunk k + 1
-    const int p3 = __builtin_amdgcn_readlane(X.hq.z, 2), r3 = __builtin_amdgcn_readlane(X.hq.w, 2);      // chunk k + 3
-    if (k + 1 < c1) stage(X, (k + 1 - c0) & 1, rN);
-    write_back(pV, rV);                                       // chunk k - 1 (nothing in the first phase)
-    pV = pW; rV = rW; pW = pN; rW = rN;
-    load(X, k + 3, p3, r3);                                   // two phases to land
+    if ((k + 1 - c0) % LN_NG == grp) {                        // this group's turn: chunk k + 1 is in its registers
+      const int pN = __builtin_amdgcn_readlane(hq.x, 2), rN = __builtin_amdgcn_readlane(hq.y, 2);      // chunk k + 1
+      const int pn = __builtin_amdgcn_readlane(hq.z, 2), rn = __builtin_amdgcn_readlane(hq.w, 2);      // chunk k + 1 + LN_NG
+      write_back(pP, rP);                                     // the chunk of its last turn: walked since
+      rP = 0;
+      if (k + 1 < c1) {
+        stage((k + 1 - c0) & 1, rN);
+        pP = pN; rP = rN;
+      }
+      load(k + 1 + LN_NG, pn, rn);                            // LN_NG phases to land
+      // the progress word (paces the read-ahead workgroup) LAST: a store is waited for with the loads at the wave's next
+      // vmcnt(0) -- stored at the top of the phase it held the group's first wave, and with it the barrier, for the ~1 us
+      // a write-through store takes, every LN_NG-th phase
+      if (st == 0) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (dbg) { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long q2 = __builtin_amdgcn_s_memtime(); e_wait += q1 - q0; e_work += q2 - q1; }
-  };
-  for (int k = c0; k < c1; k += 2) {
-    phase(S1, k);
-    if (k + 1 < c1) phase(S0, k + 1);
   }
-  if (dbg && tid == 64) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
+  if (dbg && sg == 0) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
   ln_barrier();                                               // the last chunk is walked
-  write_back(pV, rV);
+  write_back(pP, rP);
 }
 
 // ---- host: the slabs of one run of narrow levels [l0, l1) = positions [lo, ..) -----------------------------------------
@@ -371,7 +380,7 @@ inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, c
       rows = sl.p0 + sl.nrows - pk;
       char *rec = lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + (size_t)s * 64 * lane_bytes;
       int *tab = reinterpret_cast<int *>(lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + LN_REC_BYTES + (size_t)s * LN_TAB_BYTES);
-      for (int lane = 0; lane < 64; lane++, rec += lane_bytes) {
+      for (int lane = 0; lane < 64; lane++) {
         double v[16];
         int a[16];
         const int row = lane >> sl.lg, g = lane & ((1 << sl.lg) - 1);
@@ -388,17 +397,17 @@ inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, c
             }
           }
         }
-        std::memcpy(rec, v, 8 * (size_t)E);
-        std::memcpy(rec + 8 * E, a, 4 * (size_t)E);
+        for (int q = 0; q < E / 2; q++) std::memcpy(rec + 1024 * q + 16 * lane, v + 2 * q, 16);           // unit-major (see ln_walk_chunk)
+        for (int q = 0; q < E / 4; q++) std::memcpy(rec + 1024 * (E / 2 + q) + 16 * lane, a + 4 * q, 16);
       }
     }
     h[8] = pk;
     h[9] = rows;
     h[12] = E;
   }
-  for (size_t k = 0; k < n_chunks; k++) {                     // the span of the chunk two behind (the last ones repeat the last)
+  for (size_t k = 0; k < n_chunks; k++) {                     // the span of the chunk LN_NG behind (the last ones repeat the last)
     int *h = hdr.data() + hdr0 + k * LN_HDR_INTS;
-    const int *h2 = hdr.data() + hdr0 + std::min(k + 2, n_chunks - 1) * LN_HDR_INTS;
+    const int *h2 = hdr.data() + hdr0 + std::min(k + LN_NG, n_chunks - 1) * LN_HDR_INTS;
     h[10] = h2[8];
     h[11] = h2[9];
   }
