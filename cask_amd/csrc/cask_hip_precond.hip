@@ -787,6 +787,7 @@ __global__ void k_scale(int64_t n, const double *__restrict__ dinv, const double
 struct TriFactor {
   int n = 0;
   bool lower = true, unit = false;
+  int mode = 0;                                                 // CASK_HIP_TRSV when the factor was built (forced_mode)
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
@@ -836,7 +837,8 @@ struct TriFactor {
     std::vector<int> fill(lp.begin(), lp.end() - 1);
     for (int r = 0; r < n; r++) ord[fill[level[r]]++] = r;
     steps.clear();
-    const int wide_from = forced_mode() == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
+    mode = forced_mode();                                       // (read when the factor is built: a process may build factors under several)
+    const int wide_from = mode == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
     for (int l = 0; l < n_levels;) {
       if (lp[l + 1] - lp[l] >= wide_from) {
         steps.push_back(Step{l, l + 1, lp[l], lp[l + 1], true, -1, -1, false});
@@ -857,7 +859,7 @@ struct TriFactor {
       any_long = any_long || st.long_rows;
     }
     (void)any_long;
-    walk2 = forced_mode() == 4 || forced_mode() == 0 || forced_mode() == 6;
+    walk2 = mode == 4 || mode == 0 || mode == 6;
     int rc = walk2 ? build_walk2(h_rp, h_ci, h_val, level, lp, ord) : build_packed(h_rp, h_ci, h_val, level, lp, ord);
     if (rc) return rc;
     PC_TRY(rp.upload(h_rp));
@@ -1118,9 +1120,9 @@ struct TriFactor {
     // b, x and the diagonals are shared with walk2, which remains the run's fallback.
     std::vector<char> ln_bytes;
     std::vector<int> ln_words;
-    if (forced_mode() != 4)
+    if (mode != 4)
       for (Step &st : steps) {
-        if (st.wide || !(st.long_rows || forced_mode() == 6)) continue;
+        if (st.wide || !(st.long_rows || mode == 6)) continue;
         const size_t g0 = ln_words.size() / caskhip_lanes::LN_HDR_INTS;
         st.ge = caskhip_lanes::build_lanes_run(st.l0, st.l1, st.lo, lp, peptr, ppos, pval, ln_bytes, ln_words);
         if (st.ge) {
@@ -1193,13 +1195,10 @@ struct TriFactor {
   // application against 225 for `levels`) and the single-walker-wave walk (r3: 36.5 against 32.2 ms) were removed in
   // round 5: measured losses, docs/experiments.md.
   static int forced_mode() {
-    static const int mode = [] {
-      const char *force = std::getenv("CASK_HIP_TRSV");
-      if (!force) return 0;
-      const std::string f(force);
-      return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : f == "lanes" ? 6 : 0;
-    }();
-    return mode;
+    const char *force = std::getenv("CASK_HIP_TRSV");
+    if (!force) return 0;
+    const std::string f(force);
+    return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : f == "lanes" ? 6 : 0;
   }
 
   int solve(const double *d_b, double *d_x, hipStream_t s) const {
@@ -1250,7 +1249,7 @@ struct TriFactor {
       return CASK_HIP_OK;
     }
     // the packed walk reads b a chunk ahead of the x it writes: not for an in-place solve
-    const bool packed_ok = forced_mode() != 2 && d_b != d_x;
+    const bool packed_ok = mode != 2 && d_b != d_x;
     const PackedTri pk{pk_row.p, pk_eptr.p, pk_seg.p, pk_hdr.p, pk_code.p, pk_diag.p, pk_val.p};
     for (const Step &st : steps) {
       if (st.wide)

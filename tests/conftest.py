@@ -64,3 +64,24 @@ def have_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def spawn_collect(fn, args, world):
+    """Start `world` rank processes running ``fn(rank, *args, out)`` and return what each put on ``out`` as
+    ``(rank, result)``, by rank.  The results are read BEFORE the join (a child blocks in ``put`` until its data is
+    read: vectors are larger than a pipe's buffer), without a manager process (one process and ~0.4 s less per launch)."""
+    import queue
+    import torch.multiprocessing as mp
+    out = mp.get_context("spawn").Queue()
+    ctx = mp.spawn(fn, args=(*args, out), nprocs=world, join=False)
+    by_rank = {}
+    while len(by_rank) < world:
+        try:
+            rank, result = out.get(timeout=2.0)
+            by_rank[rank] = result
+        except queue.Empty:
+            if ctx.join(timeout=0):            # (raises what a failed rank raised)
+                raise RuntimeError(f"ranks exited without a result: got {sorted(by_rank)} of {world}")
+    while not ctx.join():
+        pass
+    return [by_rank[r] for r in range(world)]

@@ -13,7 +13,7 @@ import pytest
 
 import oracle
 from cask_amd import synth
-from conftest import have_gpu
+from conftest import have_gpu, spawn_collect
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a GPU")]
 
@@ -33,106 +33,175 @@ def _matrix(spec):
     raise KeyError(kind)
 
 
-def _worker(rank, world, port, case, out):
+def _worker(rank, world, port, cases, out):
+    """One launch, a LIST of cases: the ranks start (torch import, HIP context, gloo rendezvous: 2-3 s) once per world size
+    and run the module's cases of that size one after the other, each on operators of its own."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    from cask_amd import capi
-    from cask_amd import dist as cdist
     torch.cuda.set_device(0)
-    if case.get("peer_allreduce"):                 # dot products reduced by peer stores (cask_hip_push_allreduce), opt-in
-        os.environ["CASK_PEER_ALLREDUCE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n, rp, ci, va = _matrix(case["matrix"])
-
-        def fence():                               # host-side fence: gloo does not order device streams
-            torch.cuda.synchronize()
-            dist.barrier()
-
-        res = {}
-        bicg = case.get("solver") == "bicg"
-        kw = dict(balance=case.get("balance", "nnz"))
-        if case["exchange"] == "p2p":
-            kw.update(exchange="p2p", fence=fence, fused_halo=True, solver_slots=6 if bicg else 3)
-        sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, **kw)
-        b0, b1 = sh.bounds[rank], sh.bounds[rank + 1]
-        res["bounds"] = (b0, b1)
-        sht = None
-        if bicg:
-            trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
-            if case["exchange"] == "p2p":
-                sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, exchange="p2p", fence=fence,
-                                                    fused_halo=True, share_with=sh)
-            else:
-                sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, bounds=sh.bounds)
-        if case.get("b") is not None:
-            b = np.asarray(case["b"]) if not isinstance(case["b"], str) else None
-            if b is None:                          # "A*x0": the right-hand side of the reference's harness
-                x0 = np.random.default_rng(5).uniform(-1, 1, n)
-                b = oracle.csr_spmv(rp, ci, va, x0)
-            bl = torch.from_numpy(b[b0:b1].copy()).cuda()
-            x_init = None
-            if case.get("x_init") is not None:                 # a non-zero initial guess: the set-up product reads it
-                x_init = torch.from_numpy(np.asarray(case["x_init"])[b0:b1].copy()).cuda()   # through the halo too
-            for mode in case.get("modes", (0,)):
-                if bicg:
-                    xs, it, conv = sh.bicg(sht, bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
-                else:
-                    xs, it, conv = sh.cg(bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
-                torch.cuda.synchronize()
-                res[f"x{mode}"], res[f"it{mode}"], res[f"conv{mode}"] = xs.cpu().numpy(), it, conv
-                res[f"us{mode}"] = sh.last_usec_per_iteration
-                res["collectives"] = sh.last_collectives
-                fence()
-        if case.get("chain"):
-            # a product whose operand changes every time: x_{k+1} = y_k / 4 + x_k, every rank rewriting its shared
-            # slice between products (a stale halo entry -- one product late -- changes every later iterate)
-            x = torch.from_numpy(case["chain_x0"][b0:b1].copy()).cuda()
-            for _ in range(case["chain"]):
-                y = sh.spmv(x)
-                x = y * 0.25 + x
-            torch.cuda.synchronize()
-            res["chain"] = x.cpu().numpy()
-            fence()
-        if case.get("spmv_x") is not None:
-            xl = torch.from_numpy(np.asarray(case["spmv_x"])[b0:b1].copy()).cuda()
-            y = sh.spmv(xl)
-            torch.cuda.synchronize()
-            # checked here, against this rank's rows of the oracle product (the full-size cases)
-            want = oracle.csr_spmv(*cdist.slice_rows(rp, ci, va, b0, b1), np.asarray(case["spmv_x"]))
-            bad, first = oracle.mismatches(y.cpu().numpy(), want)
-            res["rows_wrong"] = bad
-            res["exchange"] = "p2p_fused" if sh.exchange is not None else "all_gather"
-            fence()
-        if sht is not None and case["exchange"] == "p2p":
-            sht.exchange = None                    # the vectors belong to sh
-        sh.close()
-        out[rank] = res
+        results = []
+        for case in cases:
+            # dot products reduced by peer stores (cask_hip_push_allreduce): opt-in, read when an operator first solves
+            os.environ.pop("CASK_PEER_ALLREDUCE", None)
+            if case.get("peer_allreduce"):
+                os.environ["CASK_PEER_ALLREDUCE"] = "1"
+            results.append(_run_case(rank, world, case))
+        out.put((rank, results))
     finally:
         dist.destroy_process_group()
 
 
+def _run_case(rank, world, case):
+    import torch
+    import torch.distributed as dist
+    from cask_amd import dist as cdist
+    n, rp, ci, va = _matrix(case["matrix"])
+
+    def fence():                               # host-side fence: gloo does not order device streams
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    res = {}
+    bicg = case.get("solver") == "bicg"
+    kw = dict(balance=case.get("balance", "nnz"))
+    if case["exchange"] == "p2p":
+        kw.update(exchange="p2p", fence=fence, fused_halo=True, solver_slots=6 if bicg else 3)
+    sh = cdist.ShardedSpmv.from_global(rp, ci, va, n, rank, world, **kw)
+    b0, b1 = sh.bounds[rank], sh.bounds[rank + 1]
+    res["bounds"] = (b0, b1)
+    sht = None
+    if bicg:
+        trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)
+        if case["exchange"] == "p2p":
+            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, exchange="p2p", fence=fence,
+                                                fused_halo=True, share_with=sh)
+        else:
+            sht = cdist.ShardedSpmv.from_global(trp, tci, tva, n, rank, world, bounds=sh.bounds)
+    if case.get("b") is not None:
+        b = np.asarray(case["b"]) if not isinstance(case["b"], str) else None
+        if b is None:                          # "A*x0": the right-hand side of the reference's harness
+            x0 = np.random.default_rng(5).uniform(-1, 1, n)
+            b = oracle.csr_spmv(rp, ci, va, x0)
+        bl = torch.from_numpy(b[b0:b1].copy()).cuda()
+        x_init = None
+        if case.get("x_init") is not None:                 # a non-zero initial guess: the set-up product reads it
+            x_init = torch.from_numpy(np.asarray(case["x_init"])[b0:b1].copy()).cuda()   # through the halo too
+        for mode in case.get("modes", (0,)):
+            if bicg:
+                xs, it, conv = sh.bicg(sht, bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
+            else:
+                xs, it, conv = sh.cg(bl, x_init, tol=case.get("tol", 1e-5), mode=mode, maxiters=case.get("maxiters", 2000))
+            torch.cuda.synchronize()
+            res[f"x{mode}"], res[f"it{mode}"], res[f"conv{mode}"] = xs.cpu().numpy(), it, conv
+            res[f"us{mode}"] = sh.last_usec_per_iteration
+            res["collectives"] = sh.last_collectives
+            fence()
+    if case.get("chain"):
+        # a product whose operand changes every time: x_{k+1} = y_k / 4 + x_k, every rank rewriting its shared
+        # slice between products (a stale halo entry -- one product late -- changes every later iterate)
+        x = torch.from_numpy(case["chain_x0"][b0:b1].copy()).cuda()
+        for _ in range(case["chain"]):
+            y = sh.spmv(x)
+            x = y * 0.25 + x
+        torch.cuda.synchronize()
+        res["chain"] = x.cpu().numpy()
+        fence()
+    if case.get("spmv_x") is not None:
+        xl = torch.from_numpy(np.asarray(case["spmv_x"])[b0:b1].copy()).cuda()
+        y = sh.spmv(xl)
+        torch.cuda.synchronize()
+        # checked here, against this rank's rows of the oracle product (the full-size cases)
+        want = oracle.csr_spmv(*cdist.slice_rows(rp, ci, va, b0, b1), np.asarray(case["spmv_x"]))
+        bad, first = oracle.mismatches(y.cpu().numpy(), want)
+        res["rows_wrong"] = bad
+        res["exchange"] = "p2p_fused" if sh.exchange is not None else "all_gather"
+        fence()
+    if sht is not None and case["exchange"] == "p2p":
+        sht.exchange = None                    # the vectors belong to sh
+    sh.close()
+    return res
+
+
+def run_world_batch(world, cases):
+    """-> [case][rank] results."""
+    by_rank = spawn_collect(_worker, (world, free_port(), list(cases)), world)
+    return [[by_rank[r][c] for r in range(world)] for c in range(len(cases))]
+
+
 def run_world(world, case):
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, free_port(), case, out), nprocs=world, join=True)
-    return [out[r] for r in range(world)]
+    return run_world_batch(world, [case])[0]
+
+
+# ---- the module's cases by world size: ONE launch per size, results handed to the tests below -----------------------
+G3, AT = ("small", "G3_circuit", 64), ("small", "atmosmodd", 64)
+
+
+def _initial_guess_inputs():
+    """(b, x_init) for CG on the G3-like system and for BiCG on the stencil (one generator, in this order)."""
+    rng = np.random.default_rng(17)
+    n_g3, n_at = _matrix(G3)[0], _matrix(AT)[0]
+    cg = (rng.standard_normal(n_g3), rng.uniform(-1, 1, n_g3))
+    bicg = (rng.standard_normal(n_at), rng.uniform(-1, 1, n_at))
+    return cg, bicg
+
+
+def _not_converged_rhs():
+    return np.random.default_rng(7).standard_normal(_matrix(G3)[0])
+
+
+def _chain_x0():
+    return np.random.default_rng(11).uniform(-1, 1, _matrix(AT)[0])
+
+
+def _cases(world):
+    (b_cg, x_cg), (b_bi, x_bi) = _initial_guess_inputs()
+    cases = {}
+    if world in (2, 3):
+        cases["cg_p2p"] = {"matrix": G3, "exchange": "p2p", "b": "A*x0", "modes": (0, 1, 2)}
+        cases["cg_all_gather"] = {"matrix": G3, "exchange": "all_gather", "b": "A*x0", "modes": (0,)}
+    if world == 2:
+        for ex in ("p2p", "all_gather"):
+            cases[f"not_converged_{ex}"] = {"matrix": G3, "exchange": ex, "b": _not_converged_rhs(), "maxiters": 5}
+            cases[f"guess_bicg_{ex}"] = {"matrix": AT, "exchange": ex, "solver": "bicg", "b": b_bi, "x_init": x_bi, "tol": 1e-9}
+    if world == 3:
+        for ex in ("p2p", "all_gather"):
+            cases[f"bicg_{ex}"] = {"matrix": AT, "exchange": ex, "solver": "bicg", "b": "A*x0", "tol": 1e-9}
+            cases[f"guess_cg_{ex}"] = {"matrix": G3, "exchange": ex, "b": b_cg, "x_init": x_cg,
+                                       "modes": (1, 2) if ex == "p2p" else (0,)}
+        cases["peer_cg"] = {"matrix": G3, "exchange": "p2p", "b": "A*x0", "peer_allreduce": True, "modes": (0,)}
+        cases["peer_bicg"] = {"matrix": AT, "exchange": "p2p", "b": "A*x0", "peer_allreduce": True, "solver": "bicg", "tol": 1e-9}
+        cases["chain"] = {"matrix": AT, "exchange": "p2p", "chain": 6, "chain_x0": _chain_x0()}
+    if world == 5:
+        for name, ex in (("webbase-1M", "all_gather"), ("atmosmodd", "p2p")):
+            n = synth.SPECS[name][0]
+            cases[name] = {"matrix": ("full", name), "exchange": ex, "spmv_x": np.arange(n, dtype=np.float64) * 0.25 / n}
+    return cases
+
+
+_RESULTS = {}
+
+
+def world_results(world, key):
+    if world not in _RESULTS:
+        cases = _cases(world)
+        _RESULTS[world] = dict(zip(cases, run_world_batch(world, list(cases.values()))))
+    return _RESULTS[world][key]
 
 
 @pytest.mark.parametrize("world,exchange", [(2, "p2p"), (3, "p2p"), (2, "all_gather"), (3, "all_gather")])
 def test_sharded_cg_matches_oracle(world, exchange):
     """Config 3 in small, row-sharded: composed passes over in-kernel halos (p2p; also forced classic, which spends a
     third collective per pass as a fence) and classic passes with the operand all-gathered (uneven slices)."""
-    spec = ("small", "G3_circuit", 64)
-    n, rp, ci, va = _matrix(spec)
+    n, rp, ci, va = _matrix(G3)
     x0 = np.random.default_rng(5).uniform(-1, 1, n)
     b = oracle.csr_spmv(rp, ci, va, x0)
     want, want_it, want_conv = oracle.cg_full(rp, ci, va, b)
     modes = (0, 1, 2) if exchange == "p2p" else (0,)
-    res = run_world(world, {"matrix": spec, "exchange": exchange, "b": "A*x0", "modes": modes})
+    res = world_results(world, f"cg_{exchange}")
     assert want_conv
     for mode in modes:
         got = np.concatenate([r[f"x{mode}"] for r in res])
@@ -146,12 +215,11 @@ def test_sharded_cg_matches_oracle(world, exchange):
 @pytest.mark.parametrize("exchange", ["p2p", "all_gather"])
 def test_sharded_bicg_matches_oracle_three_ranks(exchange):
     """Config 5 in small on three ranks (nnz-balanced, uneven slices): A and A^T blocks over the same vectors."""
-    spec = ("small", "atmosmodd", 64)
-    n, rp, ci, va = _matrix(spec)
+    n, rp, ci, va = _matrix(AT)
     x0 = np.random.default_rng(5).uniform(-1, 1, n)
     b = oracle.csr_spmv(rp, ci, va, x0)
     want, want_it, want_conv = oracle.bicg(rp, ci, va, b, tol=1e-9)
-    res = run_world(3, {"matrix": spec, "exchange": exchange, "solver": "bicg", "b": "A*x0", "tol": 1e-9})
+    res = world_results(3, f"bicg_{exchange}")
     got = np.concatenate([r["x0"] for r in res])
     assert want_conv and all(r["conv0"] for r in res)
     assert all(abs(r["it0"] - want_it) <= 1 for r in res), ([r["it0"] for r in res], want_it)
@@ -160,12 +228,11 @@ def test_sharded_bicg_matches_oracle_three_ranks(exchange):
 
 
 def test_sharded_cg_not_converged_reports_last_iteration():
-    spec = ("small", "G3_circuit", 64)
-    n, rp, ci, va = _matrix(spec)
-    b = np.random.default_rng(7).standard_normal(n)
+    n, rp, ci, va = _matrix(G3)
+    b = _not_converged_rhs()
     want, want_it, want_conv = oracle.cg_full(rp, ci, va, b, maxiters=5)
     for exchange in ("p2p", "all_gather"):
-        res = run_world(2, {"matrix": spec, "exchange": exchange, "b": b, "maxiters": 5})
+        res = world_results(2, f"not_converged_{exchange}")
         assert not want_conv and not any(r["conv0"] for r in res)
         assert all(r["it0"] == want_it == 4 for r in res)        # iterations = i of the last pass (:231)
         np.testing.assert_allclose(np.concatenate([r["x0"] for r in res]), want, rtol=1e-9, atol=1e-12)
@@ -174,10 +241,9 @@ def test_sharded_cg_not_converged_reports_last_iteration():
 def test_operand_that_changes_every_product_in_kernel_halo():
     """x_{k+1} = A x_k / 4 + x_k over 6 products on three ranks, halos read inside the product kernel from slices
     the owners rewrite between products: any halo entry served one product late shows in the final iterate."""
-    spec = ("small", "atmosmodd", 64)
-    n, rp, ci, va = _matrix(spec)
-    x = np.random.default_rng(11).uniform(-1, 1, n)
-    res = run_world(3, {"matrix": spec, "exchange": "p2p", "chain": 6, "chain_x0": x})
+    n, rp, ci, va = _matrix(AT)
+    x = _chain_x0()
+    res = world_results(3, "chain")
     want = x.copy()
     for _ in range(6):
         want = oracle.csr_spmv(rp, ci, va, want) * 0.25 + want
@@ -210,8 +276,8 @@ def test_full_size_configs_in_five_blocks(name, exchange):
     the exchange each workload gets from bench.py -- RCCL-style all-gather of x for the power-law matrix whose
     halo is nearly all of x, the in-kernel halo for the stencil -- every rank's rows against the oracle."""
     n = synth.SPECS[name][0]
-    x = np.arange(n, dtype=np.float64) * 0.25 / n
-    res = run_world(5, {"matrix": ("full", name), "exchange": exchange, "spmv_x": x})
+    res = world_results(5, name)
+    assert all(r["exchange"] == ("p2p_fused" if exchange == "p2p" else "all_gather") for r in res)
     assert sum(r["rows_wrong"] for r in res) == 0
     assert res[0]["bounds"][0] == 0 and res[-1]["bounds"][1] == n
     assert all(res[g]["bounds"][1] == res[g + 1]["bounds"][0] for g in range(4))
@@ -272,7 +338,7 @@ def _tiny_worker(rank, world, port, out):
         xs, it, conv = sh.cg(bl, tol=1e-12)
         torch.cuda.synchronize()
         res.update(x=xs.cpu().numpy(), it=it, conv=conv)
-        out[rank] = res
+        out.put((rank, res))
     finally:
         dist.destroy_process_group()
 
@@ -294,11 +360,7 @@ def test_a_rank_without_a_merge_plan_does_not_strand_the_others():
     VECTOR kernel (no dot epilogue, no in-kernel halo): the in-kernel-halo construction is then refused on EVERY rank
     (a refusal on one rank alone would leave the others in a collective), and the all-gather solver agrees on the
     classic pass collectively."""
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_tiny_worker, args=(3, free_port(), out), nprocs=3, join=True)
-    res = [out[r] for r in range(3)]
+    res = spawn_collect(_tiny_worker, (3, free_port()), 3)
     assert all(r["p2p"].startswith("refused") for r in res), [r["p2p"] for r in res]
     assert [r["fuses_dot"] for r in res] == [True, True, False]
     n, rp, ci, va, b = _tiny_system()
@@ -312,24 +374,20 @@ def test_a_rank_without_a_merge_plan_does_not_strand_the_others():
 def test_sharded_solvers_with_a_nonzero_initial_guess(exchange):
     """r = b - A x0 with x0 != 0: the set-up product reads the initial guess of every rank (through the halo table
     with the slot offset, or the all-gather) before the first pass."""
-    spec = ("small", "G3_circuit", 64)
-    n, rp, ci, va = _matrix(spec)
-    rng = np.random.default_rng(17)
-    b, x_init = rng.standard_normal(n), rng.uniform(-1, 1, n)
+    (b, x_init), (b_bi, x_bi) = _initial_guess_inputs()
+    n, rp, ci, va = _matrix(G3)
     want, want_it, want_conv = oracle.cg_full(rp, ci, va, b, x0=x_init)
     modes = (1, 2) if exchange == "p2p" else (0,)
-    res = run_world(3, {"matrix": spec, "exchange": exchange, "b": b, "x_init": x_init, "modes": modes})
+    res = world_results(3, f"guess_cg_{exchange}")
     for mode in modes:
         got = np.concatenate([r[f"x{mode}"] for r in res])
         assert all(r[f"conv{mode}"] == want_conv for r in res)
         assert all(abs(r[f"it{mode}"] - want_it) <= 2 for r in res), ([r[f"it{mode}"] for r in res], want_it)
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
     # BiCG, nonsymmetric, same thing
-    spec = ("small", "atmosmodd", 64)
-    n, rp, ci, va = _matrix(spec)
-    b, x_init = rng.standard_normal(n), rng.uniform(-1, 1, n)
-    want, want_it, want_conv = oracle.bicg(rp, ci, va, b, x0=x_init, tol=1e-9)
-    res = run_world(2, {"matrix": spec, "exchange": exchange, "solver": "bicg", "b": b, "x_init": x_init, "tol": 1e-9})
+    n, rp, ci, va = _matrix(AT)
+    want, want_it, want_conv = oracle.bicg(rp, ci, va, b_bi, x0=x_bi, tol=1e-9)
+    res = world_results(2, f"guess_bicg_{exchange}")
     got = np.concatenate([r["x0"] for r in res])
     assert want_conv and all(r["conv0"] for r in res) and all(abs(r["it0"] - want_it) <= 1 for r in res)
     np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
@@ -347,12 +405,7 @@ def test_sharded_solvers_with_peer_store_allreduce(solver):
     b = oracle.csr_spmv(rp, ci, va, x0)
     tol = 1e-5 if solver == "cg" else 1e-9
     want, want_it, want_conv = (oracle.cg_full(rp, ci, va, b) if solver == "cg" else oracle.bicg(rp, ci, va, b, tol=tol))
-    case = {"matrix": spec, "exchange": "p2p", "b": "A*x0", "peer_allreduce": True}
-    if solver == "bicg":
-        case.update(solver="bicg", tol=tol)
-    else:
-        case["modes"] = (0,)
-    res = run_world(3, case)
+    res = world_results(3, f"peer_{solver}")
     got = np.concatenate([r["x0"] for r in res])
     assert want_conv and all(r["conv0"] for r in res)
     assert all(abs(r["it0"] - want_it) <= 2 for r in res) and len({r["it0"] for r in res}) == 1

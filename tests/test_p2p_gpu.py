@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from cask_amd import synth
-from conftest import have_gpu
+from conftest import have_gpu, spawn_collect
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a GPU")]
 
@@ -86,17 +86,13 @@ def _worker(rank, world, port, case, out):
                 fence()
             sht.exchange = None                    # the vectors belong to sh
         sh.close()
-        out[rank] = res
+        out.put((rank, res))
     finally:
         dist.destroy_process_group()
 
 
 def run_world(world, case):
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, free_port(), case, out), nprocs=world, join=True)
-    return [out[r] for r in range(world)]
+    return spawn_collect(_worker, (world, free_port(), case), world)
 
 
 def check(world, matrix, balance="nnz", fused=False):

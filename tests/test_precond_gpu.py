@@ -259,7 +259,7 @@ def test_triangular_solve_schedules_agree_bit_for_bit():
     import subprocess
     import sys
     code = r'''
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, ".")
 from cask_amd import capi, synth
 out, levels = [], []
@@ -291,39 +291,46 @@ def ragged(n):
     return n, rp, ci, va
 cases = [synth.small("G3_circuit", factor=16), synth.small("atmosmodd", factor=32),
          synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000), ragged(30000)]
-for case_no, (n, rp, ci, va) in enumerate(cases):
-    r = rng.standard_normal(n)
-    if case_no == 4:                                       # a triangular matrix as it stands: no factorisation
+rhs = [rng.standard_normal(c[0]) for c in cases]
+# the schedule is a property of a factor, read from CASK_HIP_TRSV when it is built: one process, every schedule
+for mode in sys.argv[2:]:
+    os.environ.pop("CASK_HIP_TRSV", None)
+    if mode != "default":
+        os.environ["CASK_HIP_TRSV"] = mode
+    print("MODE", mode, file=sys.stderr, flush=True)
+    out, levels = [], []
+    for case_no, (n, rp, ci, va) in enumerate(cases):
+        r = rhs[case_no]
+        if case_no == 4:                                       # a triangular matrix as it stands: no factorisation
+            out.append(capi.trsolve(n, rp, ci, va, r, lower=True))
+            continue
+        for kind in ("ilu0_unit", "ilu0"):
+            pc = capi.Preconditioner(kind, n, rp, ci, va)
+            out.append(pc.apply(r))
+            levels.append(pc.info()["levels_lower"])
+            pc.close()
         out.append(capi.trsolve(n, rp, ci, va, r, lower=True))
-        continue
-    for kind in ("ilu0_unit", "ilu0"):
-        pc = capi.Preconditioner(kind, n, rp, ci, va)
-        out.append(pc.apply(r))
-        levels.append(pc.info()["levels_lower"])
-    out.append(capi.trsolve(n, rp, ci, va, r, lower=True))
-    out.append(capi.trsolve(n, rp, ci, va, r, lower=False))
-np.save(sys.argv[1], np.concatenate(out))
-print(max(levels))
+        out.append(capi.trsolve(n, rp, ci, va, r, lower=False))
+    np.save(sys.argv[1] + mode + ".npy", np.concatenate(out))
+    print(max(levels))
 '''
-    outs, stderr = {}, {}
     # packed = the four-wave walk (r2); walk2 = r3; lanes = the lane-group walk for every run of levels that qualifies (r5);
-    # "" = the default: lanes where the rows are long (the FEM-like factor), walk2 elsewhere
-    for mode in ("levels", "packed", "walk2", "lanes", ""):
-        path = f"/tmp/cask_trsv_{mode or 'default'}.npy"
-        env = dict(os.environ, CASK_HIP_TRSV=mode, CASK_HIP_TRSV_STATS="1" if mode in ("lanes", "") else "")
-        if not mode:
-            env.pop("CASK_HIP_TRSV")
-        if not env["CASK_HIP_TRSV_STATS"]:
-            env.pop("CASK_HIP_TRSV_STATS")
-        res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
-        assert res.returncode == 0, res.stderr[-1500:]
-        assert int(res.stdout.strip().splitlines()[-1]) > 500
-        outs[mode], stderr[mode] = np.load(path), res.stderr
+    # default = lanes where the rows are long (the FEM-like factor), walk2 elsewhere
+    modes = ("levels", "packed", "walk2", "lanes", "default")
+    res = subprocess.run([sys.executable, "-c", code, "/tmp/cask_trsv_", *modes], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, CASK_HIP_TRSV_STATS="1"), cwd=str(REPO))
+    assert res.returncode == 0, res.stderr[-1500:]
+    assert all(int(line) > 500 for line in res.stdout.strip().splitlines()[-len(modes):])
+    outs = {("" if m == "default" else m): np.load(f"/tmp/cask_trsv_{m}.npy") for m in modes}
+    stderr = {}
+    for part in res.stderr.split("MODE ")[1:]:
+        name, _, text = part.partition("\n")
+        stderr["" if name.strip() == "default" else name.strip()] = text
     assert np.all(np.isfinite(outs["levels"]))
     assert np.array_equal(outs["levels"], outs["packed"])
     assert np.array_equal(outs["levels"], outs["walk2"])
     # The lane-group walk adds a row's products group by group, not in stored order: the same solution to rounding.  It
-    # must really have run: everywhere it can under `lanes` (wherever every source is inside the ring and no row exceeds 256 entries), on the FEM-like
+    # must really have run: everywhere it can under `lanes` (wherever every source is inside the ring and no row exceeds 1 024 entries), on the FEM-like
     # factor alone by default.
     import re
     def lanes_chunks(text):

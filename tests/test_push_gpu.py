@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from cask_amd import synth
-from conftest import have_gpu
+from conftest import have_gpu, spawn_collect
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a GPU")]
 
@@ -60,7 +60,7 @@ def _worker(rank, world, port, case, out):
         torch.cuda.synchronize()
         if case["exchange"].startswith("push"):
             sh.push.check()
-        out[rank] = {"bounds": (b0, b1), "ys": ys, "gathered_ok": gathered_ok, "S": sh.S}
+        out.put((rank, {"bounds": (b0, b1), "ys": ys, "gathered_ok": gathered_ok, "S": sh.S}))
         dist.barrier()
         sh.close()
     finally:
@@ -68,11 +68,7 @@ def _worker(rank, world, port, case, out):
 
 
 def run_world(world, case):
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, free_port(), case, out), nprocs=world, join=True)
-    return [out[r] for r in range(world)]
+    return spawn_collect(_worker, (world, free_port(), case), world)
 
 
 def check(res, matrix, products):
@@ -143,7 +139,7 @@ def _reduce_worker(rank, world, port, out):
             got.append(t.cpu().numpy().copy())
         torch.cuda.synchronize()
         ex.check()
-        out[rank] = got
+        out.put((rank, got))
         dist.barrier()
         for p in ex.peers.values():
             p2p.close_peer(p)
@@ -158,10 +154,7 @@ def _reduce_worker(rank, world, port, out):
 def test_peer_store_allreduce_same_bits_on_every_rank(world):
     """cask_hip_push_allreduce: 40 chained reductions; every rank ends with the SAME bits (rank-order sum), equal to
     the rank-order sum computed on the host."""
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_reduce_worker, args=(world, free_port(), out), nprocs=world, join=True)
+    out = spawn_collect(_reduce_worker, (world, free_port()), world)
     rngs = [np.random.default_rng(100 + r) for r in range(world)]
     for k in range(40):
         cnt = 1 + k % 4
