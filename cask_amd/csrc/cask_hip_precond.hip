@@ -812,6 +812,7 @@ struct TriFactor {
   // ... and the slabs of k_trsv_lanes (trsv_lanes.hpp) for the runs of narrow levels with long rows
   DevBuf<char> ln_lanes;
   DevBuf<int> ln_hdr;
+  DevBuf<double> ln_rdiag;                          // 1 / diagonal, position space
 
   int build(int n_, bool lower_, const std::vector<int> &h_rp, const std::vector<int> &h_ci,
             const std::vector<double> &h_val) {
@@ -1172,8 +1173,11 @@ struct TriFactor {
                            reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 16>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 16>)})
       ln_ok = ln_ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)caskhip_lanes::LN_LDS_BYTES) == hipSuccess;
     if (ln_ok) {
+      std::vector<double> rdiag(pdiag.size());
+      for (size_t i = 0; i < pdiag.size(); i++) rdiag[i] = 1.0 / pdiag[i];
       PC_TRY(ln_lanes.upload(ln_bytes));
       PC_TRY(ln_hdr.upload(ln_words));
+      PC_TRY(ln_rdiag.upload(rdiag));
     } else {
       (void)hipGetLastError();
       for (Step &st : steps) st.g0 = -1;
@@ -1205,7 +1209,7 @@ struct TriFactor {
     const int flags = (lower ? 1 : 0) | (unit ? 2 : 0);
     if (walk2 && n > 0 && w2_bp.p) {                            // the whole solve in position space
       const Walk2Tri w2{w2_pos.p, w2_ent.p, w2_early.p, w2_hdr.p};
-      const caskhip_lanes::LanesTri ln{ln_lanes.p, ln_hdr.p, w2_pdiag.p};
+      const caskhip_lanes::LanesTri ln{ln_lanes.p, ln_hdr.p, ln_rdiag.p};
       const int pg = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256), u = unit ? 1 : 0;
       PC_TRY(hipMemsetAsync(w2_progress.p, 0, sizeof(int), s));
       hipLaunchKernelGGL(k_w2_gather, dim3(pg), dim3(256), 0, s, n, order.p, d_b, w2_bp.p);

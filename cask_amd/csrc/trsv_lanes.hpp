@@ -6,32 +6,36 @@
 // the reference's mkl_dcsrtrsv needs 2.0 ms (profiles/r05_trsv.txt).  Here a row gets a GROUP of G = 1 .. 64 lanes
 // (a power of two; E = 4, 8 or 16 entries per lane, one E per run of levels), the group's partial sums are added by
 // log2 G DPP steps, and the group's last lane subtracts from the right-hand side, divides and writes the ring:
-//   * SLABS.  The host cuts every level into slabs of consecutive rows that fit 64 lanes at one G (the largest of the
-//     slab) and writes, per slab and lane, E values and E LDS byte addresses (the ring slots of their x values; an
+//   * SLABS.  The host cuts every level into slabs of consecutive rows whose lane groups -- 2^lg lanes for a row of up
+//     to E 2^lg entries, a size per row, widest first so that every group starts on a multiple of its size -- fit 64
+//     lanes, and writes, per slab and lane, E values and E LDS byte addresses (the ring slots of their x values; an
 //     absent entry is value +0.0 at the address of a constant 0.0) -- stored 16-byte unit by unit across the lanes, so
 //     that the wave's 16-byte reads are consecutive -- and a word: where the lane's result goes (the row's ring slot in
-//     a group's last lane, a dump slot elsewhere), its row, log2 G.  32 / E slabs are a chunk: 24 KB of records, the
-//     lane words, and the right-hand sides and diagonals of its <= 512 positions.  The stream is the LDS image itself.
-//     E is the one of the three that makes the run cheapest (fewest slabs: a level is a dependent step whatever its
-//     width; at E = 8 a cant-like level -- 7 rows of 25-45 entries -- is ONE slab of 7 x 8 lanes).
-//   * STAGERS (waves 1-9): three groups of three waves take turns.  A group copies chunk k + 1 into the other half of
-//     a double buffer while the walker is on chunk k, requests chunk k + 4 behind it -- three chunks are in flight, each
-//     with three phases to land: ONE chunk in flight streamed 26 GB/s, a load's latency, and was the limit -- and
-//     writes the results of the chunk of its last turn from the ring to memory (position space: the gather / scatter
-//     kernels of walk2 surround the solve).  One barrier per chunk; a chunk's header carries its own span of positions
-//     and that of the chunk three behind it, so no address waits for a load of the same phase.
-//   * WALKER (wave 0): per slab E x reads, E multiply-adds in two or four chains, <= 6 DPP additions, the division,
-//     the ring write -- LDS operations of one wave execute in order, so a level's reads go out right behind the
-//     previous level's write, without a barrier.  The records of the slabs ahead are requested in the shadow of that
-//     chain (behind the x reads: the compiler is kept from hoisting them).  It issues no scalar or vector memory
-//     operation and computes no address: ~60 instructions a slab, ~450 cycles (LDS round trip ~130, three DPP steps
-//     ~120, bank conflicts of the x reads ~90: profiles/r05_trsv.txt).
+//     a group's last lane, a dump slot elsewhere), its row, its group's log2 size.  32 / E slabs are a chunk: 24 KB of
+//     records, the lane words, and the right-hand sides and reciprocal diagonals of its <= 512 positions.  The stream
+//     is the LDS image itself.  E is the one of the three that makes the run cheapest (fewest slabs: a level is a
+//     dependent step whatever its width; at E = 8 a cant-like level -- 7 rows of 25-45 entries -- is ONE slab).
+//   * STAGERS (waves 1-9): three groups of three waves.  A group copies its chunk into the other half of a double
+//     buffer while the walker is on the chunk before it, requests its next chunk (three further on) in the following
+//     phase -- three chunks are in flight, each with two phases to land: ONE chunk in flight streamed 26 GB/s, a
+//     load's latency, and was the limit -- and writes its chunk's results from the ring to memory in the phase after
+//     the walk (position space: the gather / scatter kernels of walk2 surround the solve).  Every phase sees one group
+//     staging, one requesting, one writing back.  One barrier per chunk; a chunk's header carries its own span of
+//     positions and that of the chunk three behind it, so no address waits for a load of the same phase.
+//   * WALKER (wave 0): per slab E x reads, E multiply-adds in two or four chains, <= 6 DPP steps (an inclusive scan
+//     whose total lands in a group's last lane; a lane of a narrower group multiplies what crosses its group's
+//     boundary by 0), a multiplication by the reciprocal diagonal, the ring write -- LDS operations of one wave execute
+//     in order, so a level's reads go out right behind the previous level's write, without a barrier.  The records of
+//     the slabs ahead are requested in the shadow of that chain (behind the x reads: the compiler is kept from hoisting
+//     them).  It issues no scalar or vector memory operation and computes no address: ~65 instructions a slab, ~480
+//     cycles (LDS round trip ~130, three DPP steps ~120, the x reads ~90: profiles/r05_trsv.txt).
 //   * READ-AHEAD (workgroup 8 of 9: the same XCD, the same L2) touches the lines of the chunks ten ahead, as in walk2.
 // A run of levels qualifies if no row has more than 1 024 entries and every source is inside the LDS ring (the producer
 // within LN_RING positions of the consumer's level end, in the same run); anything else stays with walk2.
 //
 // Arithmetic: a row's products are added lane group by lane group, not in stored order -- the result differs from the
-// other schedules' in the last bits (same plan, same bits: reproducible run to run); tests compare it with them and
+// other schedules' in the last bits, and the division is a multiplication by the reciprocal the host rounded (within an
+// ulp of the quotient) -- same plan, same bits: reproducible run to run; tests compare it with the other schedules and
 // with the oracle under a tolerance.  Reference: the solves of ILUPreconditioner::apply
 // (src/runtime/SparseLinearSolvers.hpp:143-151, MklLayer.hpp:29-85).
 #pragma once
@@ -66,7 +70,7 @@ constexpr size_t LN_LDS_BYTES = LN_BUF0 + 2 * (size_t)LN_BUF_BYTES;
 static_assert(LN_BUF0 % 16 == 0 && LN_BUF_BYTES % 16 == 0 && LN_REC_BYTES % 16 == 0, "16-byte LDS accesses");
 static_assert(LN_DUMP < (1 << 17) && LN_ROWS + 64 < (1 << 10), "lane word: 17 bits of LDS address, 10 of row, 3 of log2 G");
 static_assert(LN_LDS_BYTES <= 160 * 1024, "one workgroup's LDS on gfx950");
-static_assert((LN_RING & (LN_RING - 1)) == 0 && LN_RING >= (LN_NG + 2) * LN_ROWS, "ring slots by position mod LN_RING; the write-back lags LN_NG chunks");
+static_assert(LN_NG == 3 && (LN_RING & (LN_RING - 1)) == 0 && LN_RING >= (LN_NG + 2) * LN_ROWS, "ring slots by position mod LN_RING; the write-back lags LN_NG chunks");
 
 // lane word (one per slab and lane): LDS byte address of its result -- the row's ring slot in the last lane of a group,
 // the dump slot elsewhere -- | row (relative to the chunk's first position) << 17 | log2(lanes per row) << 27
@@ -76,19 +80,19 @@ __host__ __device__ constexpr int ln_slabs_per_chunk(int e) { return 32 / e; }
 struct LanesTri {
   const char *lanes;                   // [chunks][LN_CHUNK_BYTES]
   const int *hdr;                      // [chunks][LN_HDR_INTS]
-  const double *diag;                  // position space (walk2's)
+  const double *diag;                  // position space: the RECIPROCALS of the diagonal entries
 };
 
 __device__ __forceinline__ void ln_barrier() {
   __builtin_amdgcn_s_waitcnt(0xC07F);                         // vmcnt 63, expcnt 7, lgkmcnt 0 (the compiler's bookkeeping sees it)
   __builtin_amdgcn_s_barrier();
 }
-// a + (a as the DPP control moves it; lanes without a source and rows outside ROWMASK add +0.0)
+// a as the DPP control moves it (lanes without a source and rows outside ROWMASK: +0.0)
 template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double ln_dpp_add(double a) {
+__device__ __forceinline__ double ln_dpp_moved(double a) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, ROWMASK, 0xf, true);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, ROWMASK, 0xf, true);
-  return a + __hiloint2double(hi, lo);
+  return __hiloint2double(hi, lo);
 }
 
 // LDS by byte address.  The kernel has no static LDS, so its dynamic LDS starts at address 0 and the addresses the host
@@ -132,6 +136,10 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
     const double rb = ln_ld<double>(brow);
     double rd = 1.0;
     if constexpr (!UNIT) rd = ln_ld<double>(brow + (LN_OFF_D - LN_OFF_B));
+    const int lg = (__builtin_amdgcn_readfirstlane(tw[s]) >> 27) & 7, lgl = (tw[s] >> 27) & 7;
+    double f[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) f[k] = lgl > k ? 1.0 : 0.0;
     asm volatile("" ::: "memory");                            // the x reads go out first: the chain below waits for them
     if (s + AHEAD < C) preload(s + AHEAD);
     double ch[NCH];
@@ -140,27 +148,29 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
 #pragma unroll
     for (int t = NCH; t < E; t++) ch[t % NCH] = fma(v[s][t >> 1][t & 1], x[t], ch[t % NCH]);
     double acc = NCH == 4 ? (ch[0] + ch[1]) + (ch[2] + ch[3]) : ch[0] + ch[1];
-    // the group's sum ends up in its LAST lane: an inclusive scan over windows of 2, 4, .. lanes (groups are aligned);
-    // log2(lanes per row) is the slab's, the same in every lane's word: a scalar
-    const int lg = (__builtin_amdgcn_readfirstlane(tw[s]) >> 27) & 7;
+    // A group's sum ends up in its LAST lane: an inclusive scan over windows of 2, 4, .. lanes.  Groups start on multiples
+    // of their sizes, widest first: a step of 2^(k-1) lanes reaches across a group boundary only in lanes whose own group
+    // is narrower than 2^k, and those add 0 x what came across (f[k]: 1.0 or 0.0, from the lane word, computed while the x
+    // values are on their way: a masked step costs the dependent chain what a plain one does; partial sums are finite).
+    // lg: the widest group's log2 (lane 0's), a scalar.
     if (lg >= 1) {
-      acc = ln_dpp_add<0x111, 0xf>(acc);                      // row_shr:1
+      acc = fma(f[0], ln_dpp_moved<0x111, 0xf>(acc), acc);    // row_shr:1
       if (lg >= 2) {
-        acc = ln_dpp_add<0x112, 0xf>(acc);                    // row_shr:2
+        acc = fma(f[1], ln_dpp_moved<0x112, 0xf>(acc), acc);  // row_shr:2
         if (lg >= 3) {
-          acc = ln_dpp_add<0x114, 0xf>(acc);                  // row_shr:4
+          acc = fma(f[2], ln_dpp_moved<0x114, 0xf>(acc), acc);                 // row_shr:4
           if (lg >= 4) {
-            acc = ln_dpp_add<0x118, 0xf>(acc);                // row_shr:8
+            acc = fma(f[3], ln_dpp_moved<0x118, 0xf>(acc), acc);               // row_shr:8
             if (lg >= 5) {
-              acc = ln_dpp_add<0x142, 0xa>(acc);              // row_bcast15 -> rows 1, 3
-              if (lg >= 6) acc = ln_dpp_add<0x143, 0xc>(acc); // row_bcast31 -> rows 2, 3
+              acc = fma(f[4], ln_dpp_moved<0x142, 0xa>(acc), acc);             // row_bcast15 -> rows 1, 3
+              if (lg >= 6) acc += ln_dpp_moved<0x143, 0xc>(acc);               // row_bcast31 -> rows 2, 3 (one group of 64)
             }
           }
         }
       }
     }
     double xn = rb - acc;
-    if constexpr (!UNIT) xn = xn / rd;
+    if constexpr (!UNIT) xn = xn * rd;                        // rd = 1 / diagonal (host): a multiplication instead of ~15 instructions in the chain
     ln_st<double>(tw[s] & 0x1ffff, xn);
   }
 }
@@ -225,11 +235,13 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
   }
 
   // -------------------------------------------------------------------------------------------------- the stagers
-  // LN_NG groups of three waves take turns: chunk r (counted from c0) belongs to group r % LN_NG, which requests it
-  // LN_NG phases before it stages it -- LN_NG chunks are in flight, each with LN_NG phases to land (one CU streams
-  // ~26 GB/s with one chunk in flight: a load's latency, not the memory, was the limit) -- and writes its results back
-  // when its turn comes again.  hq: unit (st & 3) of a chunk's header: lane 2 of every wave holds {first position,
-  // positions, first position and positions of the chunk LN_NG behind}.
+  // LN_NG = 3 groups of three waves: chunk r (counted from c0) belongs to group r % 3, which stages it in phase r - 1,
+  // requests its next chunk (r + 3) in phase r -- two phases to land; three chunks are in flight (one CU streams ~26 GB/s
+  // with one chunk in flight: a load's latency, not the memory, was the limit) -- and writes chunk r's results back in
+  // phase r + 1, when the walker is through with it.  So every phase sees one group staging (~800 cycles), one requesting
+  // (~600) and one writing back (~300) side by side; all three in one group's turn (~1 800) was as long as the walker's
+  // phase.  hq: unit (st & 3) of a chunk's header: lane 2 of every wave holds {first position, positions, first position
+  // and positions of the chunk three behind}.
   if (tid == 64) {
     *reinterpret_cast<double *>(lds + LN_ZERO) = 0.0;
     *reinterpret_cast<double *>(lds + LN_DUMP) = 0.0;
@@ -281,35 +293,43 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
     const int rows = __builtin_amdgcn_readfirstlane(t.hdr[LN_HDR_INTS * kk + 9]);
     load(c0 + grp, p0, rows);
     if (grp == 0) {
-      const int pn = __builtin_amdgcn_readlane(hq.z, 2), rn = __builtin_amdgcn_readlane(hq.w, 2);
-      stage(0, rows);                                         // chunk c0 (waits for its loads)
+      stage(0, rows);                                         // chunk c0 (waits for its loads); chunk c0 + 3 is requested in phase c0
       pP = p0; rP = rows;
-      load(c0 + LN_NG, pn, rn);
     }
   }
-  unsigned long long e_wait = 0, e_work = 0;
+  unsigned long long e_wait = 0, e_work = 0, e_a = 0, e_b = 0, e_c = 0, e_d = 0;   // (per turn: loads awaited, write-back, staging, requests)
   for (int k = c0; k < c1; k++) {
     const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     ln_barrier();                                             // phase k: the walker is on chunk k
     const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-    if ((k + 1 - c0) % LN_NG == grp) {                        // this group's turn: chunk k + 1 is in its registers
-      const int pN = __builtin_amdgcn_readlane(hq.x, 2), rN = __builtin_amdgcn_readlane(hq.y, 2);      // chunk k + 1
-      const int pn = __builtin_amdgcn_readlane(hq.z, 2), rn = __builtin_amdgcn_readlane(hq.w, 2);      // chunk k + 1 + LN_NG
-      write_back(pP, rP);                                     // the chunk of its last turn: walked since
-      rP = 0;
+    // A group's three jobs take three phases, so that a phase sees one group staging, one requesting, one writing back:
+    // what it does in phase k is d = (k + 1 - c0 - its number) mod 3.
+    const int d = (k + 1 - c0 + 2 * grp) % LN_NG;             // (+ 2 grp = - grp mod 3)
+    if (d == 0) {                                             // chunk k + 1 is in its registers: stage it
+      const int rN = __builtin_amdgcn_readlane(hq.y, 2);
+      const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
       if (k + 1 < c1) {
         stage((k + 1 - c0) & 1, rN);
-        pP = pN; rP = rN;
+        pP = __builtin_amdgcn_readlane(hq.x, 2);
+        rP = rN;
       }
-      load(k + 1 + LN_NG, pn, rn);                            // LN_NG phases to land
-      // the progress word (paces the read-ahead workgroup) LAST: a store is waited for with the loads at the wave's next
-      // vmcnt(0) -- stored at the top of the phase it held the group's first wave, and with it the barrier, for the ~1 us
-      // a write-through store takes, every LN_NG-th phase
+      if (dbg) { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long tb = __builtin_amdgcn_s_memtime(); e_a += ta - q1; e_c += tb - ta; }
+    } else if (d == 1) {                                      // request the chunk of its next turn (k + 3): two phases to land
+      const int pn = __builtin_amdgcn_readlane(hq.z, 2), rn = __builtin_amdgcn_readlane(hq.w, 2);   // (the header staged last phase)
+      load(k + LN_NG, pn, rn);
+      // the progress word (paces the read-ahead workgroup) behind the loads: a store is waited for with the loads at the
+      // wave's next vmcnt(0) -- stored at the top of a staging phase it held the wave, and with it the barrier, for the
+      // ~1 us a write-through store takes
       if (st == 0) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg) e_d += __builtin_amdgcn_s_memtime() - q1;
+    } else {                                                  // the chunk it staged two phases ago has been walked: results to memory
+      write_back(pP, rP);
+      rP = 0;
+      if (dbg) { __builtin_amdgcn_s_waitcnt(0xC07F); e_b += __builtin_amdgcn_s_memtime() - q1; }
     }
     if (dbg) { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long q2 = __builtin_amdgcn_s_memtime(); e_wait += q1 - q0; e_work += q2 - q1; }
   }
-  if (dbg && sg == 0) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); }
+  if (dbg && sg == 0) { atomicAdd(dbg + 4, e_wait); atomicAdd(dbg + 6, e_work); atomicAdd(dbg + 8, e_a); atomicAdd(dbg + 11, e_b); atomicAdd(dbg + 9, e_c); atomicAdd(dbg + 10, e_d); }
   ln_barrier();                                               // the last chunk is walked
   write_back(pP, rP);
 }
@@ -326,26 +346,29 @@ inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, c
       for (int e = peptr[i]; e < peptr[i + 1]; e++)
         if (ppos[e] < lo || ppos[e] < lp[l + 1] - LN_RING) return 0;          // a source outside the run or the ring
     }
-  struct Slab { int p0, nrows, lg; };
+  // A slab: consecutive rows of one level whose lane groups -- 2^lg lanes for a row of up to E 2^lg entries, a size per
+  // ROW -- add up to at most 64 lanes (a common size per slab needed 23 % more slabs on the cant-like factors: one row of
+  // 40 entries made every group of its slab 8 lanes wide).
+  struct Slab { int p0, nrows; };
+  auto lg_of = [](int ne, int E) {
+    const int per = (ne + E - 1) / E;
+    int lg = 0;
+    while ((1 << lg) < per) lg++;
+    return lg;
+  };
   auto cut = [&](int E, std::vector<Slab> *out) {
-    auto lg_of = [&](int ne) {
-      const int per = (ne + E - 1) / E;
-      int lg = 0;
-      while ((1 << lg) < per) lg++;
-      return lg;
-    };
     size_t count = 0;
     for (int l = l0; l < l1; l++)
       for (int i = lp[l]; i < lp[l + 1];) {
-        int lg = 0, cnt = 0;
+        int used = 0, cnt = 0;
         while (i + cnt < lp[l + 1]) {
-          const int nlg = std::max(lg, lg_of(peptr[i + cnt + 1] - peptr[i + cnt]));
-          if (nlg > 6 || ((cnt + 1) << nlg) > 64) break;
-          lg = nlg;
+          const int lg = lg_of(peptr[i + cnt + 1] - peptr[i + cnt], E);
+          if (lg > 6 || used + (1 << lg) > 64) break;
+          used += 1 << lg;
           cnt++;
         }
         if (cnt == 0) return (size_t)-1;                      // a row too long for this E
-        if (out) out->push_back(Slab{i, cnt, lg});
+        if (out) out->push_back(Slab{i, cnt});
         count++;
         i += cnt;
       }
@@ -376,21 +399,33 @@ inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, c
     int rows = 0;
     for (int s = 0; s < C; s++) {
       const size_t si = k * C + s;
-      const Slab sl = si < slabs.size() ? slabs[si] : Slab{pk + rows, 0, 0};   // padding slabs: no rows
+      const Slab sl = si < slabs.size() ? slabs[si] : Slab{pk + rows, 0};      // padding slabs: no rows
       rows = sl.p0 + sl.nrows - pk;
       char *rec = lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + (size_t)s * 64 * lane_bytes;
       int *tab = reinterpret_cast<int *>(lanes.data() + lanes0 + k * (size_t)LN_CHUNK_BYTES + LN_REC_BYTES + (size_t)s * LN_TAB_BYTES);
+      // lanes: the widest groups first (sizes are powers of two, so every group starts on a multiple of its size -- what
+      // the DPP steps need -- and lane 0 belongs to the widest group: its word tells the walker how many steps the slab takes)
+      int lane_row[64], lane_g[64], lane_lg[64];
+      for (int lane = 0; lane < 64; lane++) { lane_row[lane] = -1; lane_g[lane] = 0; lane_lg[lane] = 0; }
+      int cursor = 0;
+      for (int want = 6; want >= 0; want--)
+        for (int row = 0; row < sl.nrows; row++) {
+          const int i = sl.p0 + row;
+          if (lg_of(peptr[i + 1] - peptr[i], E) != want) continue;
+          for (int g = 0; g < (1 << want); g++, cursor++) { lane_row[cursor] = row; lane_g[cursor] = g; lane_lg[cursor] = want; }
+        }
       for (int lane = 0; lane < 64; lane++) {
         double v[16];
         int a[16];
-        const int row = lane >> sl.lg, g = lane & ((1 << sl.lg) - 1);
-        const bool writer = g == (1 << sl.lg) - 1 && row < sl.nrows;
-        tab[lane] = ln_lane_word(writer ? ((sl.p0 + row) & (LN_RING - 1)) * 8 : LN_DUMP, sl.p0 - pk + row, sl.lg);
+        const int row = lane_row[lane], g = lane_g[lane], lg = lane_lg[lane];
+        const bool writer = row >= 0 && g == (1 << lg) - 1;
+        // (a lane without a row reads the spare right-hand side behind the slab's rows)
+        tab[lane] = ln_lane_word(writer ? ((sl.p0 + row) & (LN_RING - 1)) * 8 : LN_DUMP, sl.p0 - pk + (row >= 0 ? row : sl.nrows), lg);
         for (int t = 0; t < E; t++) {
           v[t] = 0.0;
           a[t] = LN_ZERO;
-          if (row < sl.nrows) {
-            const int i = sl.p0 + row, e = peptr[i] + g + (t << sl.lg);
+          if (row >= 0) {
+            const int i = sl.p0 + row, e = peptr[i] + g + (t << lg);
             if (e < peptr[i + 1]) {
               v[t] = pval[e];
               a[t] = (ppos[e] & (LN_RING - 1)) * 8;
