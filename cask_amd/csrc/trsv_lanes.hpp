@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -378,7 +379,9 @@ inline int build_lanes_run(int l0, int l1, int lo, const std::vector<int> &lp, c
   // cycles of staging
   int best_e = 0;
   double best = 0.0;
+  const char *only = std::getenv("CASK_HIP_TRSV_LANES_E");   // tests: one E instead of the cheapest
   for (int E : {4, 8, 16}) {
+    if (only && std::atoi(only) != E) continue;
     const size_t n = cut(E, nullptr);
     if (n == (size_t)-1) continue;
     const double walker = (double)n * (260.0 + 10.0 * E), stagers = (double)((n + 32 / E - 1) / (32 / E)) * 1200.0;

@@ -253,8 +253,9 @@ def test_triangular_solve_schedules_agree_bit_for_bit():
     left the engine in round 5.)  All walk every row in stored order: identical bits -- on a grid factor with thousands
     of levels and long-range edges, a 3-D stencil, a banded FEM-like factor with 40 entries per row (several chunks
     per level run, entry-capped chunks), an arrow matrix whose last row is longer than a chunk can hold (that
-    step falls back to the row-indexed walk) and a ragged random triangle (rows of 0-9 entries, sources near, beyond
-    the LDS ring and anywhere)."""
+    step falls back to the row-indexed walk), a ragged random triangle (rows of 0-9 entries, sources near, beyond
+    the LDS ring and anywhere) and a dense band (rows of 1 to ~250 entries).  The lane-group walk (r5: a row on 1-64
+    lanes, 4 / 8 / 16 entries a lane) adds in another order: the same solution to rounding."""
     import os
     import subprocess
     import sys
@@ -290,12 +291,16 @@ def ragged(n):
     va[rp[1:] - 1] = rng.uniform(2.0, 3.0, n) * rng.choice([-1.0, 1.0], n)
     return n, rp, ci, va
 cases = [synth.small("G3_circuit", factor=16), synth.small("atmosmodd", factor=32),
-         synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000), ragged(30000)]
+         synth.cant_like(n=6000, per_row=41, band=300, seed=2), arrow(5000), ragged(30000),
+         synth.cant_like(n=800, per_row=350, band=400, seed=5)]        # rows of 1 .. ~250 entries: lane groups of 1 .. 64
 rhs = [rng.standard_normal(c[0]) for c in cases]
 # the schedule is a property of a factor, read from CASK_HIP_TRSV when it is built: one process, every schedule
 for mode in sys.argv[2:]:
     os.environ.pop("CASK_HIP_TRSV", None)
-    if mode != "default":
+    os.environ.pop("CASK_HIP_TRSV_LANES_E", None)
+    if mode.startswith("lanes") and mode != "lanes":          # lanes4 / lanes16: that many entries per lane, whatever is cheapest
+        os.environ["CASK_HIP_TRSV"], os.environ["CASK_HIP_TRSV_LANES_E"] = "lanes", mode[5:]
+    elif mode != "default":
         os.environ["CASK_HIP_TRSV"] = mode
     print("MODE", mode, file=sys.stderr, flush=True)
     out, levels = [], []
@@ -316,7 +321,7 @@ for mode in sys.argv[2:]:
 '''
     # packed = the four-wave walk (r2); walk2 = r3; lanes = the lane-group walk for every run of levels that qualifies (r5);
     # default = lanes where the rows are long (the FEM-like factor), walk2 elsewhere
-    modes = ("levels", "packed", "walk2", "lanes", "default")
+    modes = ("levels", "packed", "walk2", "lanes", "lanes4", "lanes16", "default")
     res = subprocess.run([sys.executable, "-c", code, "/tmp/cask_trsv_", *modes], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, CASK_HIP_TRSV_STATS="1"), cwd=str(REPO))
     assert res.returncode == 0, res.stderr[-1500:]
@@ -339,7 +344,7 @@ for mode in sys.argv[2:]:
     print("factors with lane-group runs: forced", n_forced, "default", n_default)
     assert n_forced >= 6 and 0 < n_default <= n_forced, (n_forced, n_default, stderr["lanes"][-800:])
     scale = np.abs(outs["levels"]).max()
-    for mode in ("lanes", ""):
+    for mode in ("lanes", "lanes4", "lanes16", ""):
         assert np.all(np.isfinite(outs[mode]))
         assert np.abs(outs[mode] - outs["levels"]).max() <= 1e-11 * scale, (mode, np.abs(outs[mode] - outs["levels"]).max(), scale)
     assert not np.array_equal(outs["lanes"], outs["levels"])            # (a different order of additions)
