@@ -5,7 +5,7 @@ echo "== build() + smoke()"
 python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -3
 echo "== GPU suite (driver form)"
 SECONDS=0
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r05_gputests_9.log 2>&1; echo "pytest rc=$? wall ${SECONDS}s"; tail -3 gpurun_out/r05_gputests_9.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r05_gputests_final.log 2>&1; echo "pytest rc=$? wall ${SECONDS}s"; tail -3 gpurun_out/r05_gputests_final.log
 echo "== driver command"
 SECONDS=0
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r05_final.json 2> gpurun_out/bench_r05_final.err; echo "rc=$? wall ${SECONDS}s"
