@@ -16,8 +16,9 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcask_hip.so"
 
 VARIANT_AUTO, VARIANT_VECTOR, VARIANT_MERGE, VARIANT_MERGE_WAVE, VARIANT_SCAN = 0, 1, 2, 3, 4
 VARIANT_MERGE_PAIR_REMOVED = 5      # ABI 4-5; rejected since ABI 6 (tests/test_capi_cpu.py, test_spmv_gpu.py)
+VARIANT_SLICE = 6                   # ABI 7: short rows row-mapped (lanes_per_row = K), long rows nonzero-mapped, one launch
 VARIANT_NAMES = {VARIANT_AUTO: "auto", VARIANT_VECTOR: "vector", VARIANT_MERGE: "merge",
-                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan"}
+                 VARIANT_MERGE_WAVE: "merge_wave", VARIANT_SCAN: "scan", VARIANT_SLICE: "slice"}
 
 # Every symbol include/cask_hip.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = (

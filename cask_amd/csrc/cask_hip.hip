@@ -18,6 +18,7 @@
 #include "cask_hip.h"
 #include "cask_hip_p2p.h"
 #include "merge_launch.hpp"
+#include "plan_host.hpp"
 #include "scan_launch.hpp"
 #include "spmv_kernels.hpp"
 #ifdef CASK_UNITY   // single-translation-unit build (diagnostic builds: tools/stamps.py)
@@ -56,16 +57,11 @@ namespace {
       return fail(CASK_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-int pow2_floor(int v) {
-  int p = 1;
-  while (p * 2 <= v) p *= 2;
-  return p;
-}
+using plan::is_pow2;
+using plan::pow2_floor;
 
 constexpr int MAX_LDS_BYTES = 64 * 1024;      // per workgroup; keeps >= 2 workgroups per CU (160 KiB LDS)
 constexpr int DEFAULT_TILE = 4096;            // doubles (32 KiB)
-constexpr int LONG_PIECE_FACTOR = 16;         // a long-row piece is at most 16*CAP nonzeros
 
 struct Plan {
   cask_hip_params prm{};          // resolved
@@ -88,16 +84,22 @@ struct Plan {
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
   int n_long_rows = 0, n_split_rows = 0;
   DevBuf<double> dot_part;         // MERGE: per-block (+ per split row) shares of the fused w.y
-  int n_far = 0;                   // SCAN far plans: nonzeros served from scan_farx
   // VECTOR
   DevBuf<int2v> xspan;
-  // SCAN (scan_kernel.hpp): per-thread row-end words, the row map of blocks that span empty rows, and -- far plans --
-  // the plan's own column stream with far references, the far columns panel-major and the buffer they are gathered into
+  int vec_long_rows = 0;           // VECTOR: rows longer than this go to the long-row pieces (long_blocks); 0 = none do
+  // SCAN (scan_kernel.hpp): per-thread row-end words, the row map of blocks that span empty rows, and -- with an x window --
+  // the plan's own column stream (LDS slots)
   DevBuf<unsigned> scan_meta;
-  DevBuf<int> scan_rowmap, scan_ci, scan_fcol;
-  DevBuf<double> scan_farx;
-  DevBuf<int> scan_sync, scan_needs;   // fused far pre-gather: producer flags + block epochs; producers each block waits for
-  ScanFar scan_far{};
+  DevBuf<int> scan_rowmap, scan_ci;
+  // SLICE (slice_kernel.hpp): the row-mapped slices (descriptors, slot map, the plan's copies of the short rows' values
+  // and columns in plane order) and the long rows' sub-matrix (its values; blocks / scan_meta / scan_rowmap / scan_ci above
+  // describe it)
+  DevBuf<SliceDesc> slices;
+  DevBuf<uint16_t> slice_slot;
+  DevBuf<double> slice_val, long_val;
+  DevBuf<int> slice_ci;
+  int n_slice_blocks = 0, slice_k = 0;
+  int64_t long_nnz = 0;
 };
 
 // Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
@@ -161,19 +163,29 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
         out.wg_size == 1024))
     return fail(CASK_HIP_ERR_INVALID, "wg_size must be 64, 128, 256, 512 or 1024");
   if (out.variant != CASK_HIP_VARIANT_VECTOR && out.variant != CASK_HIP_VARIANT_MERGE &&
-      out.variant != CASK_HIP_VARIANT_MERGE_WAVE && out.variant != CASK_HIP_VARIANT_SCAN)
+      out.variant != CASK_HIP_VARIANT_MERGE_WAVE && out.variant != CASK_HIP_VARIANT_SCAN && out.variant != CASK_HIP_VARIANT_SLICE)
     return fail(CASK_HIP_ERR_INVALID, "unknown variant");
   if (m.halo_addr && out.variant != CASK_HIP_VARIANT_MERGE)
     return fail(CASK_HIP_ERR_INVALID, "a matrix with halo sources runs the MERGE variant only");
-  if (out.far_columns >= 1 && out.variant != CASK_HIP_VARIANT_SCAN)
-    return fail(CASK_HIP_ERR_INVALID, "far_columns = 1 / 2 exist for variant SCAN only (the MERGE far slots were removed in "
-                                      "ABI 6: the pre-gather cost more than the line fills it saved, docs/experiments.md)");
+  if (out.far_columns >= 1)
+    return fail(CASK_HIP_ERR_INVALID, "far_columns = 1 / 2 were removed (MERGE's far slots in ABI 6, SCAN's column-panel pre-gather "
+                                      "in ABI 7): the pre-gather cost more time than the line fills it saved, docs/experiments.md; "
+                                      "use 0 / -1");
   if (m.nnz < 2 && !m.halo_addr) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
-  if (out.lanes_per_row == 0) {
+  if (out.variant == CASK_HIP_VARIANT_SLICE) {
+    // K, the longest row a slice thread takes, travels in lanes_per_row; the long rows' blocks are SCAN blocks
+    if (out.lanes_per_row == 0) out.lanes_per_row = 4;
+    if (out.lanes_per_row < 1 || out.lanes_per_row > SLICE_KMAX)
+      return fail(CASK_HIP_ERR_INVALID, "variant SLICE: lanes_per_row carries K, the longest row a slice thread takes: 1..8");
+    if (out.items_per_thread == 0) out.items_per_thread = 8;
+    if (out.items_per_thread != 4 && out.items_per_thread != 8)
+      return fail(CASK_HIP_ERR_INVALID, "variant SLICE: items_per_thread (of the long rows' blocks) must be 4 or 8");
+    if (m.n_cols >= SCAN_LDS_BIT) return fail(CASK_HIP_ERR_INVALID, "variant SLICE: too many columns");
+  } else if (out.lanes_per_row == 0) {
     int l = pow2_floor(std::max(1, (int)std::lround(mean / 4.0)));
     out.lanes_per_row = std::min(64, std::max(out.variant == CASK_HIP_VARIANT_VECTOR ? 2 : 1, l));
   }
-  if (!is_pow2(out.lanes_per_row) || out.lanes_per_row > 64)
+  if (out.variant != CASK_HIP_VARIANT_SLICE && (!is_pow2(out.lanes_per_row) || out.lanes_per_row > 64))
     return fail(CASK_HIP_ERR_INVALID, "lanes_per_row must be a power of two in 1..64");
   if (out.items_per_thread == 0) out.items_per_thread = 8;
   if (!(out.items_per_thread == 2 || out.items_per_thread == 4 || out.items_per_thread == 8 ||
@@ -188,9 +200,9 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     return fail(CASK_HIP_ERR_INVALID, "index16 = 3 / 4 (run records and their A/B twin) were removed in ABI 6: the decode cost "
                                       "more than the bytes bought (docs/experiments.md); use 0 / 1 (12-bit packed slots)");
   if (out.index16 > 2) return fail(CASK_HIP_ERR_INVALID, "index16 must be -1 (off), 0/1 (compressed) or 2 (16-bit only)");
-  if (out.far_columns < -1 || out.far_columns > 2) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1, 0, 1 or 2");
+  if (out.far_columns < -1) return fail(CASK_HIP_ERR_INVALID, "far_columns must be -1 or 0");
   if (out.variant != CASK_HIP_VARIANT_MERGE) out.index16 = -1;
-  if (out.variant == CASK_HIP_VARIANT_MERGE || out.variant == CASK_HIP_VARIANT_SCAN) {
+  if (out.variant == CASK_HIP_VARIANT_MERGE || out.variant == CASK_HIP_VARIANT_SCAN || out.variant == CASK_HIP_VARIANT_SLICE) {
     const long cap = (long)out.wg_size * out.items_per_thread;
     if (8 * (cap + 2) + 8 * out.wg_size > MAX_LDS_BYTES)
       return fail(CASK_HIP_ERR_INVALID, "wg_size*items_per_thread needs more than 64 KiB of LDS");
@@ -198,87 +210,8 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
   return CASK_HIP_OK;
 }
 
-// Cut the merge path of (row ends) against (nonzero indices) into shares of at
-// most `cap` items (and at most `max_rows` rows), snapped to row boundaries;
-// rows longer than cap/2 become long-row pieces of at most `piece` nonzeros.
-// Long pieces go to `longs` when it is given (pipelined plan), else inline.
-// `rows_are_items` = false (SCAN plans): only nonzeros count against `cap`, and a block that spans empty rows is
-// flagged KIND_HOLES.
-void build_merge_blocks(const cask_hip_matrix &m, int cap, int max_rows, long piece, int threads,
-                        std::vector<BlockDesc> &blocks, std::vector<BlockDesc> *longs,
-                        std::vector<SplitRow> &splits, int &n_long, int &n_partial_slots, bool rows_are_items = true) {
-  const int *rp = m.h_rp.data();
-  const int long_t = cap / 2;
-  n_long = 0;
-  n_partial_slots = 0;
-  int cur_start = 0, cur_rows = 0, cur_nnz = 0, cur_max = 0, cur_empty = 0;
-  auto close = [&](int next_row) {
-    if (cur_rows == 0) return;
-    BlockDesc d{};
-    d.row_start = cur_start;
-    d.n_rows = cur_rows;
-    d.nnz_start = rp[cur_start];
-    d.nnz_count = cur_nnz;
-    // lanes per row in the reduce phase: as many as keep the phase to ONE pass over the block's rows
-    // (threads / rows), but no more than the mean row length can feed
-    const int mean = std::max(1, cur_nnz / cur_rows);
-    const int by_rows = pow2_floor(std::max(1, threads / cur_rows));
-    int by_len = 1;
-    while (by_len < mean && by_len < 64) by_len *= 2;
-    d.kind_g = std::min(64, std::max(1, std::min(by_rows, by_len)));
-    if (cur_max > skew_short_max(d.kind_g & 0xff)) d.kind_g |= KIND_SKEW;   // longer rows: 16 lanes or a wave each
-    if (cur_nnz == 0) {
-      // a run of empty rows: nothing to stream.  The stream path would still issue its clamped 16-byte pair
-      // loads, and for a block at the (odd) end of the arrays the pair's second element lies past col_ind --
-      // an uninitialised column fed to an x gather.  Such a block is a zero-fill piece instead (long-row path,
-      // nnz_count == 0, n_rows rows), which touches neither the stream nor x.
-      d.kind_g = KIND_LONG;
-      d.aux = 0;
-      (longs ? *longs : blocks).push_back(d);
-    } else {
-      if (!rows_are_items) d.kind_g = cur_empty ? KIND_HOLES : 0;
-      blocks.push_back(d);
-    }
-    cur_rows = 0;
-    cur_nnz = 0;
-    cur_max = 0;
-    cur_empty = 0;
-    cur_start = next_row;
-  };
-  for (int r = 0; r < m.n_rows; r++) {
-    const int len = rp[r + 1] - rp[r];
-    if (len > long_t) {
-      close(r);
-      n_long++;
-      const int n_pieces = (int)((len + piece - 1) / piece);
-      if (n_pieces > 1) splits.push_back(SplitRow{r, n_partial_slots, n_pieces, 0});
-      for (int pc = 0; pc < n_pieces; pc++) {
-        BlockDesc d{};
-        d.row_start = r;
-        d.n_rows = 1;
-        d.nnz_start = rp[r] + (int)(pc * piece);
-        d.nnz_count = (int)std::min<long>(piece, len - pc * piece);
-        d.kind_g = KIND_LONG | (n_pieces > 1 ? KIND_PARTIAL : 0);
-        d.aux = n_pieces > 1 ? n_partial_slots++ : 0;
-        (longs ? *longs : blocks).push_back(d);
-      }
-      cur_start = r + 1;
-      continue;
-    }
-    if (cur_rows > 0 && ((rows_are_items ? cur_rows + 1 : 0) + cur_nnz + len > cap || cur_rows + 1 > max_rows)) close(r);
-    if (cur_rows == 0) cur_start = r;
-    cur_rows++;
-    cur_nnz += len;
-    cur_empty += len == 0;
-    cur_max = std::max(cur_max, len);
-  }
-  close(m.n_rows);
-}
-
-// x tile as a set of column ranges: for every block collect the distinct columns it references, join
-// columns closer than GAP into ranges, cut the ranges into 64-column chunks.  A block whose chunks
-// fit `max_chunks` is "tiled": its nonzeros get 16-bit LDS slot indices (chunk*64 + offset) and its
-// chunk start columns go to chunk_starts.  d.cwidth = slots used (0 = not tiled).
+// The planners themselves -- merge-path cuts, chunk tiles, packed slots, seam placement, SCAN words / windows, SLICE --
+// are host-only code on plain arrays: plan_host.hpp (compiled and run under ASan / UBSan by `make asan`).
 int ensure_host_col_ind(cask_hip_matrix &m) {
   if (m.h_ci.size() == (size_t)m.nnz) return CASK_HIP_OK;
   m.h_ci.resize((size_t)m.nnz);
@@ -289,155 +222,6 @@ int ensure_host_col_ind(cask_hip_matrix &m) {
       return fail(CASK_HIP_ERR_INVALID, "column index out of range");
     }
   return CASK_HIP_OK;
-}
-
-void build_chunk_tiles(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks, int max_chunks,
-                       std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16) {
-  constexpr int GAP = 32;
-  const int *ci = m.h_ci.data();
-  ci16.assign((size_t)m.nnz + 8, 0);
-  chunk_starts.assign(blocks.size(), {});
-  auto work = [&](size_t b0, size_t b1) {
-    std::vector<int> uniq, starts;
-    for (size_t b = b0; b < b1; b++) {
-      BlockDesc &d = blocks[b];
-      d.cwidth = 0;
-      if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
-      const int k0 = d.nnz_start, k1 = d.nnz_start + d.nnz_count;
-      uniq.assign(ci + k0, ci + k1);
-      std::sort(uniq.begin(), uniq.end());
-      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-      starts.clear();
-      size_t i = 0;
-      while (i < uniq.size()) {
-        size_t j = i;
-        while (j + 1 < uniq.size() && uniq[j + 1] - uniq[j] <= GAP) j++;
-        for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) starts.push_back(c);   // even starts: the kernel loads the tile in 16-byte pairs
-        i = j + 1;
-      }
-      if ((int)starts.size() > max_chunks) continue;          // does not fit: the block gathers from L2
-      d.cmin = starts.empty() ? 0 : starts.front();
-      d.cwidth = (int)starts.size() * 64;
-      bool contiguous = !starts.empty();
-      for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
-      if (contiguous) d.kind_g |= KIND_CONTIG;
-      for (int k = k0; k < k1; k++) {
-        const int c = ci[k];
-        const int idx = (int)(std::upper_bound(starts.begin(), starts.end(), c) - starts.begin()) - 1;
-        ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
-      }
-      chunk_starts[b] = starts;
-    }
-  };
-  // blocks are independent (disjoint nonzero ranges): plan them on a few host threads
-  const size_t nb = blocks.size();
-  size_t n_threads = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-  if (m.nnz < 200000) n_threads = 1;
-  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
-  if (n_threads <= 1) {
-    work(0, nb);
-  } else {
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
-    for (auto &th : pool) th.join();
-  }
-}
-
-// 12-bit packed slots for the IPT = 8 merge kernel: record (b*wg + t) holds the eight slots thread t of block b
-// needs, in the order the kernel consumes them -- pair u (u = 0..3) is elements 2p, 2p+1 of pair index
-// p = min(first + u*wg + t, last) exactly as merge_load computes it.  Elements that are not the block's own
-// (the lead element of an odd start, the half-foreign last pair, clamped duplicates) get the slot of a
-// neighbouring own element, which is what the kernel's fix-up does for the 16-bit layout at run time.
-// Stored as 6 unsigned shorts (3 dwords, little endian bit stream) per record.
-void pack_slots12(const cask_hip_matrix &m, const std::vector<BlockDesc> &blocks, const std::vector<unsigned short> &ci16,
-                  int wg, std::vector<unsigned short> &packed) {
-  packed.assign(blocks.size() * (size_t)wg * 6, 0);
-  const int max_gpair = (int)((m.nnz + 1) / 2) - 1;
-  auto work = [&](size_t b0, size_t b1) {
-    for (size_t b = b0; b < b1; b++) {
-      const BlockDesc &d = blocks[b];
-      if ((d.kind_g & KIND_LONG) || d.cwidth <= 0) continue;   // long pieces and untiled blocks read 32-bit indices
-      const int base = d.nnz_start & ~1, lead = d.nnz_start - base, total = d.nnz_count + lead;
-      const int npairs = (total + 1) >> 1, first = base >> 1;
-      const int last = std::min(first + std::max(npairs - 1, 0), max_gpair);
-      const int own0 = d.nnz_start, own1 = d.nnz_start + d.nnz_count;      // own elements [own0, own1)
-      for (int t = 0; t < wg; t++) {
-        unsigned slots[8];
-        for (int u = 0; u < 4; u++) {
-          const int pr = std::min(first + u * wg + t, last);
-          int e0 = 2 * pr, e1 = 2 * pr + 1;
-          // replace foreign elements by the pair's own element (or the block's first nonzero)
-          const bool f0 = e0 < own0 || e0 >= own1, f1 = e1 < own0 || e1 >= own1;
-          if (f0 && !f1) e0 = e1;
-          if (f1 && !f0) e1 = e0;
-          if (f0 && f1) e0 = e1 = own0;
-          slots[2 * u] = ci16[e0];
-          slots[2 * u + 1] = ci16[e1];
-        }
-        unsigned w0 = slots[0] | (slots[1] << 12) | (slots[2] << 24);
-        unsigned w1 = (slots[2] >> 8) | (slots[3] << 4) | (slots[4] << 16) | (slots[5] << 28);
-        unsigned w2 = (slots[5] >> 4) | (slots[6] << 8) | (slots[7] << 20);
-        unsigned short *rec = packed.data() + (b * (size_t)wg + t) * 6;
-        rec[0] = (unsigned short)(w0 & 0xffff); rec[1] = (unsigned short)(w0 >> 16);
-        rec[2] = (unsigned short)(w1 & 0xffff); rec[3] = (unsigned short)(w1 >> 16);
-        rec[4] = (unsigned short)(w2 & 0xffff); rec[5] = (unsigned short)(w2 >> 16);
-      }
-    }
-  };
-  const size_t nb = blocks.size();
-  size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-  n_threads = std::min(n_threads, std::max<size_t>(nb, 1));
-  if (n_threads <= 1) {
-    work(0, nb);
-  } else {
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, nb * t / n_threads, nb * (t + 1) / n_threads);
-    for (auto &th : pool) th.join();
-  }
-}
-
-// Host twin of logical_block() (spmv_kernels.hpp).
-int logical_block_host(int hw, int n, bool remap) {
-  if (!remap) return hw;
-  const int xcd = hw & 7, idx = hw >> 3, q = n >> 3, rem = n & 7;
-  return xcd * q + std::min(xcd, rem) + idx;
-}
-
-// Sharded product: record every block's largest column in aux (the kernel's seam test) and move the
-// seam blocks -- the ones that read halo columns, i.e. wait for a round trip over xGMI -- to the slots
-// that are dispatched first, so that their longer life overlaps the rest of the launch instead of
-// extending its tail.  chunk_starts (may be empty) is permuted alongside.
-void place_seam_blocks(const cask_hip_matrix &m, std::vector<BlockDesc> &blocks,
-                       std::vector<std::vector<int>> &chunk_starts, bool remap) {
-  const int nb = (int)blocks.size();
-  const int *ci = m.h_ci.data();
-  std::vector<int> seam;
-  for (int b = 0; b < nb; b++) {
-    BlockDesc &d = blocks[b];
-    if (d.kind_g & KIND_LONG) continue;                       // long-row pieces test every column themselves
-    int cmax = -1;
-    for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++) cmax = std::max(cmax, ci[k]);
-    d.aux = cmax;
-    if (cmax >= m.halo_n_own) seam.push_back(b);
-  }
-  if (seam.empty() || (int)seam.size() > nb / 4) return;      // halo everywhere: no order helps
-  std::vector<char> is_seam(nb, 0), is_target(nb, 0);
-  for (int b : seam) is_seam[b] = 1;
-  std::vector<int> targets;
-  for (int hw = 0; hw < (int)seam.size(); hw++) {
-    const int lb = logical_block_host(hw, nb, remap);
-    targets.push_back(lb);
-    is_target[lb] = 1;
-  }
-  size_t ti = 0;
-  for (int b : seam) {
-    if (is_target[b]) continue;                               // already in an early slot
-    while (ti < targets.size() && is_seam[targets[ti]]) ti++; // that slot holds a seam block: leave it
-    if (ti == targets.size()) break;
-    const int t = targets[ti++];
-    std::swap(blocks[b], blocks[t]);
-    if (!chunk_starts.empty()) std::swap(chunk_starts[b], chunk_starts[t]);
-  }
 }
 
 template <int IPT>
@@ -455,51 +239,23 @@ const void *merge_wave_fn(int ipt, bool nt) {
 }
 
 // SCAN plan (scan_kernel.hpp): blocks of at most cap nonzeros snapped to rows; one word per thread with the row
-// ends of its run; far nonzeros (tile_width = near margin) through the column-panel pre-gather.
+// ends of its run; tile_width = an x window per block (the plan's own column stream then).
 int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   Plan &pl = m.plan;
   const int wg = prm.wg_size, ipt = prm.items_per_thread, cap = wg * ipt;
-  const int *rp = m.h_rp.data();
   std::vector<BlockDesc> blocks;
   std::vector<SplitRow> splits;
   int n_long = 0, n_slots = 0;
   // cap - 1 nonzeros per block: a block that starts on an odd nonzero streams one foreign element in front of its own
   // (16-byte loads), and the workgroup loads exactly cap elements
-  build_merge_blocks(m, cap - 1, 1 << 30, (long)cap * LONG_PIECE_FACTOR, wg, blocks, nullptr, splits, n_long, n_slots, false);
+  plan::build_merge_blocks(m.h_rp.data(), m.n_rows, cap - 1, 1 << 30, (long)cap * LONG_PIECE_FACTOR, wg, blocks, nullptr, splits,
+                           n_long, n_slots, false);
   pl.n_long_rows = n_long;
   pl.n_split_rows = (int)splits.size();
   pl.grid = pl.n_blocks = (int)blocks.size();
-  std::vector<unsigned> meta((size_t)blocks.size() * wg, 0u);
+  std::vector<unsigned> meta;
   std::vector<int> rowmap;
-  std::vector<int> ends((size_t)wg);
-  for (size_t b = 0; b < blocks.size(); b++) {
-    BlockDesc &d = blocks[b];
-    d.cmin = d.cwidth = 0;
-    if (d.kind_g & KIND_LONG) continue;
-    unsigned *mw = meta.data() + b * (size_t)wg;
-    std::fill(ends.begin(), ends.end(), 0);
-    const bool holes = (d.kind_g & KIND_HOLES) != 0;
-    if (holes) {
-      d.aux = (int)rowmap.size();
-      rowmap.push_back(0);                                    // [number of non-empty rows, their local rows ...]
-    }
-    for (int r = 0; r < d.n_rows; r++) {
-      const int row = d.row_start + r;
-      if (rp[row + 1] == rp[row]) continue;
-      const int e = rp[row + 1] - 1 - d.nnz_start;            // the row's last nonzero, block-relative
-      mw[e / ipt] |= 1u << (e % ipt);
-      ends[e / ipt]++;
-      if (holes) {
-        rowmap.push_back(r);
-        rowmap[(size_t)d.aux]++;
-      }
-    }
-    int ord = 0;
-    for (int t = 0; t < wg; t++) {
-      mw[t] |= (unsigned)ord << 16;
-      ord += ends[t];
-    }
-  }
+  plan::build_scan_meta(m.h_rp.data(), blocks, wg, ipt, meta, rowmap);
   HIP_TRY(pl.scan_meta.upload(meta));
   rowmap.push_back(0);                                        // never empty: the kernel forms rowmap + aux
   HIP_TRY(pl.scan_rowmap.upload(rowmap));
@@ -512,159 +268,17 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   pl.prm.far_columns = -1;
   pl.prm.tile_width = -1;
   pl.xu = 0;
-  const int base_lds = 8 * (cap + wg + 4) + 24 * 8;
-  const int nb = (int)blocks.size();
-  // ---- x window (tile_width) and far nonzeros (far_columns) ----------------------------------------------------
-  // Window: per block the contiguous column range of at most W entries that covers most of its nonzeros, staged
-  // in LDS; a nonzero inside it streams an LDS slot instead of a column (the plan's own column stream).
-  // Far: a nonzero outside its block's window whose column also lies outside the rows its XCD walks (XCD j runs
-  // the logical blocks [j*q + min(j, rem), ...): one contiguous run of rows, whose x entries its L2 keeps through
-  // the window loads) -- served through the column-panel pre-gather.
-  int want_w = prm.tile_width > 0 ? prm.tile_width : 0;
-  int xp = 0;
-  if (want_w > 0 && m.nnz > 0 && m.n_cols < SCAN_LDS_BIT) {
-    // r5: the window SHARES the product area's LDS (scan_kernel.hpp: dead once every thread holds its x values), so it
-    // is at most ipt * wg entries wide (xp <= ipt / 2) and costs no LDS -- with 16 KB of its own a 2 048-entry window took
-    // a 256 x 8 block from 8 to 4 workgroups per CU, which is what made windows lose on short rows (webbase2: 15.9 us
-    // with its own LDS, 15.2 shared, 16.2 without a window; profiles/r05_merge_forms.txt)
-    xp = 2;
-    while (xp < 8 && 2 * xp * wg < want_w) xp *= 2;
-    while (xp >= 2 && (2 * xp > ipt + 1 || 2 * xp * wg > 65536)) xp /= 2;
-    if (xp < 2) xp = 0;
-  }
-  const int W = 2 * xp * wg;
-  // far_columns: 1 = pre-gather as its own launch, 2 = by producer workgroups of the product launch; 0 / -1 = off --
-  // measured on the webbase-like matrix (profiles/r03_webbase_anatomy.txt) both cut the product kernel's time and
-  // the fabric traffic, and both cost more than they save (the producers' two dependent round trips)
-  const bool want_far = prm.far_columns >= 1 && nb >= 8 && prm.xcd_remap > 0 && m.nnz > 0 && m.n_cols < SCAN_LDS_BIT;
-  if (xp > 0 || want_far) {
+  // x window (tile_width): per block the contiguous column range of at most W entries that covers most of its nonzeros,
+  // staged in LDS (in the product area: no LDS of its own); a nonzero inside it streams an LDS slot instead of a column
+  int xp = (m.nnz > 0 && m.n_cols < SCAN_LDS_BIT) ? plan::scan_window_xp(prm.tile_width > 0 ? prm.tile_width : 0, wg, ipt) : 0;
+  if (xp > 0) {
     int rc = ensure_host_col_ind(m);
     if (rc) return rc;
-    const int *ci = m.h_ci.data();
     std::vector<int> sci(m.h_ci);
     sci.push_back(0);                                         // the kernel's last 8-byte pair of an odd nnz
-    long in_window = 0;
-    if (xp > 0) {
-      std::vector<long> covered(nb, 0);
-      auto work = [&](int b0, int b1) {
-        std::vector<int> cols;
-        for (int b = b0; b < b1; b++) {
-          BlockDesc &d = blocks[b];
-          if ((d.kind_g & KIND_LONG) || d.nnz_count == 0) continue;
-          cols.assign(ci + d.nnz_start, ci + d.nnz_start + d.nnz_count);
-          std::sort(cols.begin(), cols.end());
-          // densest range [s, s + W) with s even: two pointers over the sorted columns
-          size_t best_i = 0, best_n = 0, j = 0;
-          for (size_t i = 0; i < cols.size(); i++) {
-            const int s0 = cols[i] & ~1;
-            while (j < cols.size() && cols[j] < s0 + W) j++;
-            if (j - i > best_n) { best_n = j - i; best_i = i; }
-          }
-          if (best_n * 4 < cols.size()) continue;             // a window that serves under a quarter is not worth its loads
-          const int s0 = cols[best_i] & ~1, last_col = cols[best_i + best_n - 1];
-          d.cmin = s0;
-          d.cwidth = ((last_col - s0 + 2) & ~1);               // even, <= W
-          for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++)
-            if (ci[k] >= s0 && ci[k] < s0 + d.cwidth) sci[(size_t)k] = SCAN_LDS_BIT | (ci[k] - s0);
-          covered[b] = (long)best_n;
-        }
-      };
-      size_t n_threads = m.nnz < 200000 ? 1 : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-      n_threads = std::min<size_t>(n_threads, std::max(nb, 1));
-      if (n_threads <= 1) {
-        work(0, nb);
-      } else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < n_threads; t++) pool.emplace_back(work, (int)(nb * t / n_threads), (int)(nb * (t + 1) / n_threads));
-        for (auto &th : pool) th.join();
-      }
-      for (long c : covered) in_window += c;
-      if (in_window == 0) xp = 0;
-    }
-    int64_t n_far = 0;
-    std::vector<int> fcol;
-    if (want_far) {
-      const int panel_width = std::max(1, (m.n_cols + SCAN_PANELS - 1) / SCAN_PANELS);
-      const int q = nb >> 3, rem = nb & 7;
-      std::vector<int> lo(nb), hi(nb);                        // rows (= x entries) of every block's XCD
-      for (int j = 0; j < 8; j++) {
-        const int b0 = j * q + std::min(j, rem), b1 = b0 + q + (j < rem ? 1 : 0);
-        if (b0 >= b1) continue;
-        const int r0 = blocks[b0].row_start, r1 = blocks[b1 - 1].row_start + blocks[b1 - 1].n_rows;
-        for (int b = b0; b < b1; b++) { lo[b] = r0; hi[b] = r1; }
-      }
-      auto is_far = [&](int b, int64_t k) { return !(sci[(size_t)k] & SCAN_LDS_BIT) && (ci[k] < lo[b] || ci[k] >= hi[b]); };
-      // count per panel, then place: inside a panel in (block, nonzero) order
-      std::vector<int64_t> count(SCAN_PANELS + 1, 0);
-      for (int b = 0; b < nb; b++) {
-        const BlockDesc &d = blocks[b];
-        for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
-          if (is_far(b, k)) count[ci[k] / panel_width + 1]++;
-      }
-      // every panel's share of farx starts on a 128-byte line (16 entries): a chunk of a panel is then whole lines, so
-      // a line of farx is written by ONE producer -- a consumer that reads it after that producer's flag can never
-      // pull a half-written line into its L2 (fused pre-gather, scan_kernel.hpp)
-      int64_t n_real = 0;
-      for (int p = 0; p < SCAN_PANELS; p++) {
-        n_real += count[p + 1];
-        count[p + 1] = count[p] + ((count[p + 1] + 15) & ~(int64_t)15);
-      }
-      n_far = n_real ? count[SCAN_PANELS] : 0;
-      if (n_far > 0 && n_far < ((int64_t)1 << 30)) {
-        fcol.assign((size_t)n_far, 0);                        // (padding entries gather x[0])
-        std::vector<int64_t> fill(count.begin(), count.end() - 1);
-        for (int b = 0; b < nb; b++) {
-          const BlockDesc &d = blocks[b];
-          for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
-            if (is_far(b, k)) {
-              const int64_t at = fill[ci[k] / panel_width]++;
-              fcol[(size_t)at] = ci[k];
-              sci[(size_t)k] = ~(int)at;
-              blocks[b].kind_g |= KIND_FAR;                   // (long-row pieces test every reference themselves)
-            }
-        }
-        HIP_TRY(pl.scan_fcol.upload(fcol));
-        HIP_TRY(pl.scan_farx.alloc((size_t)n_far));
-        int per_panel = 0;
-        const int chunk = scan_far_chunk(wg);
-        for (int p = 0; p <= SCAN_PANELS; p++) pl.scan_far.panels.start[p] = (int)count[p];
-        for (int p = 0; p < SCAN_PANELS; p++) per_panel = std::max(per_panel, (int)((count[p + 1] - count[p] + chunk - 1) / chunk));
-        pl.scan_far.fcol = pl.scan_fcol.p;
-        pl.scan_far.n_far = (int)n_far;
-        pl.scan_far.grid = per_panel * SCAN_PANELS;
-        pl.prm.far_columns = prm.far_columns;
-        if (pl.prm.far_columns == 2) {
-          // the producers (hardware block ids: chunk index * 8 + panel) whose chunks hold a block's far entries
-          std::vector<int> needs((size_t)nb * SCAN_NEEDS, -1), mine;
-          for (int b = 0; b < nb; b++) {
-            BlockDesc &d = blocks[b];
-            if (!(d.kind_g & KIND_FAR)) continue;
-            mine.clear();
-            for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
-              if (sci[(size_t)k] < 0) {
-                const int at = ~sci[(size_t)k], p = ci[k] / panel_width;
-                const int h = (int)((at - count[p]) / chunk) * SCAN_PANELS + p;
-                if (std::find(mine.begin(), mine.end(), h) == mine.end()) mine.push_back(h);
-              }
-            if ((int)mine.size() > SCAN_NEEDS) {              // too scattered to wait for: this block gathers directly
-              for (int64_t k = d.nnz_start; k < (int64_t)d.nnz_start + d.nnz_count; k++)
-                if (sci[(size_t)k] < 0) sci[(size_t)k] = ci[k];
-              d.kind_g &= ~KIND_FAR;
-              continue;
-            }
-            std::copy(mine.begin(), mine.end(), needs.begin() + (size_t)b * SCAN_NEEDS);
-          }
-          HIP_TRY(pl.scan_needs.upload(needs));
-          HIP_TRY(pl.scan_sync.alloc((size_t)pl.scan_far.grid + (size_t)nb));
-          HIP_TRY(hipMemset(pl.scan_sync.p, 0, ((size_t)pl.scan_far.grid + (size_t)nb) * sizeof(int)));
-        }
-        pl.n_far = (int)n_far;
-      } else {
-        n_far = 0;
-      }
-    }
-    if (xp > 0 || n_far > 0) HIP_TRY(pl.scan_ci.upload(sci));
-    if (xp > 0) {
+    const int W = 2 * xp * wg;
+    if (plan::build_scan_window(m.h_ci.data(), m.nnz, blocks, W, sci) > 0) {
+      HIP_TRY(pl.scan_ci.upload(sci));
       pl.prm.tile_width = W;
       pl.xu = xp;
     } else {
@@ -673,7 +287,79 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
     }
   }
   HIP_TRY(pl.blocks.upload(blocks));
-  pl.lds_bytes = base_lds;                                    // (the window lives in the product area)
+  pl.lds_bytes = 8 * (cap + wg + 4) + 24 * 8;                 // (the window lives in the product area)
+  pl.ldsx = pl.xu > 0;
+  return CASK_HIP_OK;
+}
+
+// SLICE plan (slice_kernel.hpp, plan_host.hpp build_slice_plan): the short rows as row-mapped slices, the long rows as a
+// SCAN plan over a compacted copy; the plan owns copies of the value and column streams in that order.
+int build_slice_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
+  Plan &pl = m.plan;
+  const int wg = prm.wg_size, ipt = prm.items_per_thread, cap = wg * ipt, k = prm.lanes_per_row;
+  int rc = ensure_host_col_ind(m);
+  if (rc) return rc;
+  plan::SlicePlan sp;
+  plan::build_slice_plan(m.h_rp.data(), m.n_rows, k, slice_rows_per_thread(slice_kernel_km(k)) * wg, wg, ipt, sp);
+  const int64_t n_slice_nnz = (int64_t)sp.slice_src.size(), n_long_nnz = (int64_t)sp.long_src.size();
+  pl.slice_k = k;
+  pl.n_slice_blocks = (int)sp.slices.size();
+  pl.long_nnz = n_long_nnz;
+  pl.n_long_rows = sp.n_long_pieces_rows;
+  pl.n_split_rows = (int)sp.splits.size();
+  pl.n_blocks = (int)sp.blocks.size();
+  pl.grid = pl.n_blocks + pl.n_slice_blocks;
+  pl.prm.index16 = -1;
+  pl.prm.far_columns = -1;
+  pl.prm.tile_width = -1;
+  pl.prm.nontemporal = 1;                                     // (the slice kernels stream nontemporally: one instantiation)
+  pl.xu = 0;
+  // columns in plan order (host), values gathered on the device (the handle keeps no host copy of them)
+  std::vector<int> sci((size_t)n_slice_nnz + 2), lci((size_t)n_long_nnz + 2, 0);
+  for (int64_t i = 0; i < n_slice_nnz; i++) sci[(size_t)i] = m.h_ci[(size_t)sp.slice_src[(size_t)i]];
+  for (int64_t i = 0; i < n_long_nnz; i++) lci[(size_t)i] = m.h_ci[(size_t)sp.long_src[(size_t)i]];
+  if (n_long_nnz > 0) {
+    const int xp = plan::scan_window_xp(prm.tile_width > 0 ? prm.tile_width : 0, wg, ipt);
+    if (xp > 0) {
+      std::vector<int> plain(lci.begin(), lci.begin() + n_long_nnz);
+      const int W = 2 * std::min(xp, 4) * wg;                 // (the slice launch has window instantiations up to 4 loads per thread)
+      if (plan::build_scan_window(plain.data(), n_long_nnz, sp.blocks, W, lci) > 0) {
+        pl.prm.tile_width = W;
+        pl.xu = std::min(xp, 4);
+      } else {
+        for (BlockDesc &d : sp.blocks)
+          if (!(d.kind_g & KIND_LONG)) d.cmin = d.cwidth = 0;
+      }
+    }
+  }
+  HIP_TRY(pl.slices.upload(sp.slices));
+  HIP_TRY(pl.slice_slot.upload(sp.slot));
+  HIP_TRY(pl.slice_ci.upload(sci));
+  HIP_TRY(pl.scan_ci.upload(lci));
+  HIP_TRY(pl.blocks.upload(sp.blocks));
+  HIP_TRY(pl.scan_meta.upload(sp.meta));
+  if (sp.rowmap.empty()) sp.rowmap.push_back(0);
+  HIP_TRY(pl.scan_rowmap.upload(sp.rowmap));
+  if (!sp.splits.empty()) {
+    HIP_TRY(pl.split_rows.upload(sp.splits));
+    HIP_TRY(pl.partials.alloc(sp.n_partial_slots));
+  }
+  HIP_TRY(pl.slice_val.alloc((size_t)n_slice_nnz + 2));
+  HIP_TRY(pl.long_val.alloc((size_t)n_long_nnz + 2));
+  HIP_TRY(hipMemsetAsync(pl.slice_val.p, 0, ((size_t)n_slice_nnz + 2) * sizeof(double), m.stream));
+  HIP_TRY(hipMemsetAsync(pl.long_val.p, 0, ((size_t)n_long_nnz + 2) * sizeof(double), m.stream));
+  {
+    DevBuf<int> src;
+    HIP_TRY(src.upload(sp.slice_src));
+    gather_values(n_slice_nnz, src.p, m.d_val, pl.slice_val.p, m.stream);
+    DevBuf<int> lsrc;
+    HIP_TRY(lsrc.upload(sp.long_src));
+    gather_values(n_long_nnz, lsrc.p, m.d_val, pl.long_val.p, m.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m.stream));                  // (the index arrays die here)
+  }
+  const int slice_lds = 8 * slice_rows_per_thread(slice_kernel_km(k)) * wg;
+  pl.lds_bytes = std::max(8 * (cap + wg + 4) + 24 * 8, slice_lds);
   pl.ldsx = pl.xu > 0;
   return CASK_HIP_OK;
 }
@@ -698,15 +384,17 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.dot_part.release();
   pl.xspan.release();
   pl.n_long_rows = pl.n_split_rows = 0;
-  pl.n_far = 0;
+  pl.vec_long_rows = 0;
   pl.scan_meta.release();
   pl.scan_rowmap.release();
   pl.scan_ci.release();
-  pl.scan_fcol.release();
-  pl.scan_farx.release();
-  pl.scan_sync.release();
-  pl.scan_needs.release();
-  pl.scan_far = ScanFar{};
+  pl.slices.release();
+  pl.slice_slot.release();
+  pl.slice_val.release();
+  pl.long_val.release();
+  pl.slice_ci.release();
+  pl.n_slice_blocks = pl.slice_k = 0;
+  pl.long_nnz = 0;
   pl.grid = 0;
   pl.lds_bytes = 0;
   pl.ldsx = false;
@@ -720,7 +408,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     std::vector<BlockDesc> blocks, longs;
     std::vector<SplitRow> splits;
     int n_long = 0, n_slots = 0;
-    build_merge_blocks(m, cap, 127, 32768, 64, blocks, &longs, splits, n_long, n_slots);
+    plan::build_merge_blocks(m.h_rp.data(), m.n_rows, cap, 127, 32768, 64, blocks, &longs, splits, n_long, n_slots);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
     pl.n_blocks = (int)blocks.size();
@@ -746,13 +434,16 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   } else if (prm.variant == CASK_HIP_VARIANT_SCAN) {
     int rc2 = build_scan_plan(m, prm);
     if (rc2) return rc2;
+  } else if (prm.variant == CASK_HIP_VARIANT_SLICE) {
+    int rc2 = build_slice_plan(m, prm);
+    if (rc2) return rc2;
   } else if (prm.variant == CASK_HIP_VARIANT_MERGE) {
     const int cap = prm.wg_size * prm.items_per_thread;
     std::vector<BlockDesc> blocks;
     std::vector<SplitRow> splits;
     int n_long = 0, n_slots = 0;
-    build_merge_blocks(m, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, prm.wg_size, blocks, nullptr, splits,
-                       n_long, n_slots);
+    plan::build_merge_blocks(m.h_rp.data(), m.n_rows, cap, 2 * prm.wg_size - 1, (long)cap * LONG_PIECE_FACTOR, prm.wg_size, blocks,
+                             nullptr, splits, n_long, n_slots);
     for (const BlockDesc &b : blocks) pl.any_skew = pl.any_skew || (b.kind_g & KIND_SKEW);
     pl.n_long_rows = n_long;
     pl.n_split_rows = (int)splits.size();
@@ -777,9 +468,9 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       const int max_slots = std::min(tile, xu_cap * prm.wg_size);
       std::vector<std::vector<int>> chunk_starts;
       std::vector<unsigned short> ci16;
-      build_chunk_tiles(m, blocks, max_slots / 64, chunk_starts, ci16);
+      plan::build_chunk_tiles(m.h_ci.data(), m.nnz, blocks, max_slots / 64, chunk_starts, ci16);
       pl.prm.far_columns = -1;
-      if (m.halo_addr) place_seam_blocks(m, blocks, chunk_starts, prm.xcd_remap > 0);
+      if (m.halo_addr) plan::place_seam_blocks(m.h_ci.data(), m.halo_n_own, blocks, chunk_starts, prm.xcd_remap > 0);
       int max_used = 0;                                       // slots of the fullest tile
       for (const BlockDesc &d : blocks)
         if (!(d.kind_g & KIND_LONG)) max_used = std::max(max_used, d.cwidth);
@@ -802,7 +493,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         pl.slot_bytes_per_nnz = pl.packed12 ? 1.5 : 2.0;
         if (pl.packed12) {
           std::vector<unsigned short> packed;
-          pack_slots12(m, blocks, ci16, prm.wg_size, packed);
+          plan::pack_slots12(m.nnz, blocks, ci16, prm.wg_size, packed);
           HIP_TRY(pl.ci16.upload(packed));
         } else {
           HIP_TRY(pl.ci16.upload(ci16));
@@ -832,14 +523,14 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         int rc2 = ensure_host_col_ind(m);
         if (rc2) return rc2;
         std::vector<std::vector<int>> none;
-        place_seam_blocks(m, blocks, none, prm.xcd_remap > 0);
+        plan::place_seam_blocks(m.h_ci.data(), m.halo_n_own, blocks, none, prm.xcd_remap > 0);
         HIP_TRY(pl.blocks.upload(blocks));
       }
     } else if (m.halo_addr && m.nnz > 0) {
       int rc2 = ensure_host_col_ind(m);
       if (rc2) return rc2;
       std::vector<std::vector<int>> none;
-      place_seam_blocks(m, blocks, none, prm.xcd_remap > 0);
+      plan::place_seam_blocks(m.h_ci.data(), m.halo_n_own, blocks, none, prm.xcd_remap > 0);
       HIP_TRY(pl.blocks.upload(blocks));
     }
     if (!pl.ci16.p) pl.prm.index16 = -1;
@@ -849,6 +540,26 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     pl.ldsx = pl.xu > 0;
     pl.lds_bytes = base_lds + (merge_window_aliased(pl.xu, prm.items_per_thread) ? 0 : 8 * pl.xu * prm.wg_size);
   } else {
+    // rows far longer than the lanes suit leave the row-mapped kernel (r6): long-row pieces for k_spmv_long + the fix-up,
+    // the path the merge plans have -- L lanes walking a 4 700-entry row of a power-law matrix took 260-300 us
+    {
+      const int long_len = plan::vector_long_row_len(prm.lanes_per_row);
+      std::vector<BlockDesc> longs;
+      std::vector<SplitRow> splits;
+      int n_slots = 0;
+      plan::build_vector_long_pieces(m.h_rp.data(), m.n_rows, long_len, longs, splits, n_slots);
+      if (!longs.empty()) {
+        pl.vec_long_rows = long_len;
+        pl.n_long_blocks = (int)longs.size();
+        pl.n_split_rows = (int)splits.size();
+        HIP_TRY(pl.long_blocks.upload(longs));
+        if (!splits.empty()) {
+          HIP_TRY(pl.split_rows.upload(splits));
+          HIP_TRY(pl.partials.alloc(n_slots));
+        }
+        for (const BlockDesc &d : longs) pl.n_long_rows += !(d.kind_g & KIND_PARTIAL) || d.nnz_start == m.h_rp[d.row_start];
+      }
+    }
     // L >= 4: the pair-load kernel, VEC_RG row groups per wave (spmv_kernels.hpp)
     const int rows_per_wg = prm.wg_size / prm.lanes_per_row * (prm.lanes_per_row >= 4 ? VEC_RG : 1);
     pl.grid = (m.n_rows + rows_per_wg - 1) / rows_per_wg;
@@ -879,7 +590,8 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
 }
 
 // The plan of `src` for `dst`, a handle over the SAME matrix in other device arrays (the rotating copies of the
-// DSE's cold timing): every plan array is a function of the sparsity pattern alone, so it is copied device to device
+// DSE's cold timing): every plan array is a function of the sparsity pattern alone (a SLICE plan's value copies: of
+// the matrix, which is the same), so it is copied device to device
 // instead of being planned again on the host (13 of the 14 plans per design point: most of a sweep's wall time).
 int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
   Plan &d = dst.plan;
@@ -890,18 +602,17 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
   d.n_blocks = s.n_blocks; d.n_long_blocks = s.n_long_blocks; d.packed12 = s.packed12; d.one_window = s.one_window;
   d.slot_bytes_per_nnz = s.slot_bytes_per_nnz;
   d.maxch = s.maxch; d.any_skew = s.any_skew; d.n_long_rows = s.n_long_rows;
-  d.n_split_rows = s.n_split_rows; d.n_far = s.n_far;
-  d.scan_far = s.scan_far;
+  d.n_split_rows = s.n_split_rows; d.vec_long_rows = s.vec_long_rows;
+  d.n_slice_blocks = s.n_slice_blocks; d.slice_k = s.slice_k; d.long_nnz = s.long_nnz;
   HIP_TRY(d.blocks.copy_from(s.blocks)); HIP_TRY(d.long_blocks.copy_from(s.long_blocks));
   HIP_TRY(d.split_rows.copy_from(s.split_rows)); HIP_TRY(d.partials.copy_from(s.partials));
   HIP_TRY(d.ci16.copy_from(s.ci16)); HIP_TRY(d.xchunk.copy_from(s.xchunk)); HIP_TRY(d.dot_part.copy_from(s.dot_part));
   HIP_TRY(d.xspan.copy_from(s.xspan));
   HIP_TRY(d.scan_meta.copy_from(s.scan_meta)); HIP_TRY(d.scan_rowmap.copy_from(s.scan_rowmap));
-  HIP_TRY(d.scan_ci.copy_from(s.scan_ci)); HIP_TRY(d.scan_fcol.copy_from(s.scan_fcol));
-  HIP_TRY(d.scan_farx.copy_from(s.scan_farx)); HIP_TRY(d.scan_needs.copy_from(s.scan_needs));
-  HIP_TRY(d.scan_sync.copy_from(s.scan_sync));
-  if (d.scan_sync.p) HIP_TRY(hipMemset(d.scan_sync.p, 0, d.scan_sync.n * sizeof(int)));   // its own hand-off counters
-  d.scan_far.fcol = d.scan_fcol.p;
+  HIP_TRY(d.scan_ci.copy_from(s.scan_ci));
+  // SLICE: the plan's copies of the value stream are the same bits in every copy of the matrix
+  HIP_TRY(d.slices.copy_from(s.slices)); HIP_TRY(d.slice_slot.copy_from(s.slice_slot)); HIP_TRY(d.slice_ci.copy_from(s.slice_ci));
+  HIP_TRY(d.slice_val.copy_from(s.slice_val)); HIP_TRY(d.long_val.copy_from(s.long_val));
   return CASK_HIP_OK;
 }
 
@@ -916,14 +627,25 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   do {                                                                                                         \
     if (L >= 4)                                                                                                \
       hipLaunchKernelGGL((k_spmv_vector2<(L >= 4 ? L : 4), LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, \
-                         remap, tile, (int)m.nnz, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y);                  \
+                         remap, tile, (int)m.nnz, pl.vec_long_rows, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y); \
     else                                                                                                       \
       hipLaunchKernelGGL((k_spmv_vector<L, LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, remap, \
-                         tile, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y);                                     \
+                         tile, pl.vec_long_rows, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y);                   \
   } while (0)
   if (pl.ldsx) { if (nt) CASK_LAUNCH_V(true, true); else CASK_LAUNCH_V(true, false); }
   else         { if (nt) CASK_LAUNCH_V(false, true); else CASK_LAUNCH_V(false, false); }
 #undef CASK_LAUNCH_V
+  if (pl.n_long_blocks > 0) {                                 // the rows the row-mapped kernel left alone
+    if (nt)
+      hipLaunchKernelGGL((k_spmv_long<true>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
+                         m.d_val, x, y, pl.partials.p);
+    else
+      hipLaunchKernelGGL((k_spmv_long<false>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
+                         m.d_val, x, y, pl.partials.p);
+    if (pl.n_split_rows > 0)
+      hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p, pl.n_split_rows,
+                         pl.partials.p, y, DotEpilogue{nullptr, nullptr}, (const int *)nullptr);
+  }
   return CASK_HIP_OK;
 }
 
@@ -1027,27 +749,33 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
     HIP_TRY(hipGetLastError());
     return CASK_HIP_OK;
   }
-  if (pl.prm.variant == CASK_HIP_VARIANT_SCAN) {
+  if (pl.prm.variant == CASK_HIP_VARIANT_SCAN || pl.prm.variant == CASK_HIP_VARIANT_SLICE) {
+    const bool slice = pl.prm.variant == CASK_HIP_VARIANT_SLICE;
     ScanLaunch l{};
-    l.grid = pl.grid;
+    l.grid = slice ? pl.n_blocks : pl.grid;
     l.wg_size = pl.prm.wg_size;
     l.lds_bytes = pl.lds_bytes;
     l.remap = pl.prm.xcd_remap > 0;
-    l.nnz = (int)m.nnz;
+    l.nnz = slice ? (int)pl.long_nnz : (int)m.nnz;
     l.n_cols = m.n_cols;
     l.xp = pl.xu;
     l.nontemporal = pl.prm.nontemporal > 0;
     l.blocks = pl.blocks.p;
     l.rp = m.d_rp;
     l.ci = pl.scan_ci.p ? pl.scan_ci.p : m.d_ci;
-    l.val = m.d_val;
+    l.val = slice ? pl.long_val.p : m.d_val;
     l.meta = pl.scan_meta.p;
     l.rowmap = pl.scan_rowmap.p;
-    l.farx = pl.scan_farx.p;
-    l.sync = pl.scan_sync.p;
-    l.needs = pl.scan_needs.p;
     l.partials = pl.partials.p;
-    launch_scan(l, pl.scan_far, pl.prm.items_per_thread, x, y, s);
+    if (slice) {
+      l.n_slice_blocks = pl.n_slice_blocks;
+      l.slice_k = pl.slice_k;
+      l.slices = pl.slices.p;
+      l.slice_val = pl.slice_val.p;
+      l.slice_ci = pl.slice_ci.p;
+      l.slice_slot = pl.slice_slot.p;
+    }
+    launch_scan(l, pl.prm.items_per_thread, x, y, s);
     if (pl.n_split_rows > 0)
       hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
                          pl.n_split_rows, pl.partials.p, y, DotEpilogue{nullptr, nullptr}, (const int *)nullptr);

@@ -788,6 +788,7 @@ struct TriFactor {
   int n = 0;
   bool lower = true, unit = false;
   int mode = 0;                                                 // CASK_HIP_TRSV when the factor was built (forced_mode)
+  bool lanes_select = true;                                     // k_trsv_lanes masks by select (false: CASK_HIP_TRSV_LANES_MASK=mul, the A/B)
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
@@ -839,6 +840,7 @@ struct TriFactor {
     for (int r = 0; r < n; r++) ord[fill[level[r]]++] = r;
     steps.clear();
     mode = forced_mode();                                       // (read when the factor is built: a process may build factors under several)
+    lanes_select = lanes_mask_select();
     const int wide_from = mode == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
     for (int l = 0; l < n_levels;) {
       if (lp[l + 1] - lp[l] >= wide_from) {
@@ -1167,11 +1169,7 @@ struct TriFactor {
       (void)hipGetLastError();
       for (Step &st : steps) st.d0 = -1;
     }
-    bool ln_ok = !ln_words.empty() && lds_max >= (int)caskhip_lanes::LN_LDS_BYTES;
-    for (const void *fn : {reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 4>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 4>),
-                           reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 8>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 8>),
-                           reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<false, 16>), reinterpret_cast<const void *>(caskhip_lanes::k_trsv_lanes<true, 16>)})
-      ln_ok = ln_ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)caskhip_lanes::LN_LDS_BYTES) == hipSuccess;
+    bool ln_ok = !ln_words.empty() && lds_max >= (int)caskhip_lanes::LN_LDS_BYTES && lanes_kernels_usable(w2_progress.p);
     if (ln_ok) {
       std::vector<double> rdiag(pdiag.size());
       for (size_t i = 0; i < pdiag.size(); i++) rdiag[i] = 1.0 / pdiag[i];
@@ -1193,16 +1191,75 @@ struct TriFactor {
     return CASK_HIP_OK;
   }
 
-  // Schedules of a run of narrow levels, bit-identical to each other (tested): walk2 (walker + stagers + read-ahead in
-  // position space, r3: the default), packed (the four-wave walk, r2), levels (the row-indexed walk, r1).
-  // CASK_HIP_TRSV = levels | walk2 | packed forces one.  The one-launch synchronisation-free solve (r2: 210-270 ms per
-  // application against 225 for `levels`) and the single-walker-wave walk (r3: 36.5 against 32.2 ms) were removed in
-  // round 5: measured losses, docs/experiments.md.
+  // Every instantiation of the lane-group walk, by (unit diagonal, entries per lane, select / multiply mask).
+  static const void *lanes_kernel(bool unit, int e, bool sel) {
+    using namespace caskhip_lanes;
+#define CASK_LN_K(U, E, S) reinterpret_cast<const void *>(&k_trsv_lanes<U, E, S>)
+#define CASK_LN_E(U, S) (e == 4 ? CASK_LN_K(U, 4, S) : e == 8 ? CASK_LN_K(U, 8, S) : CASK_LN_K(U, 16, S))
+    return unit ? (sel ? CASK_LN_E(true, true) : CASK_LN_E(true, false)) : (sel ? CASK_LN_E(false, true) : CASK_LN_E(false, false));
+#undef CASK_LN_E
+#undef CASK_LN_K
+  }
+  // CASK_HIP_TRSV_LANES_MASK=mul: the round-5 mask (a multiplication by 0.0) instead of the select -- for the A/B only
+  static bool lanes_mask_select() {
+    const char *m = std::getenv("CASK_HIP_TRSV_LANES_MASK");
+    return !(m && std::string(m) == "mul");
+  }
+  // Once per process: may the lane-group kernels be used at all?  Their LDS attribute must be settable and -- the walker
+  // uses ABSOLUTE LDS byte addresses the host wrote (trsv_lanes.hpp: ring at 0, LN_ZERO, LN_BUF0) -- their dynamic LDS must
+  // start at address 0: every instantiation is launched once with an empty chunk range, in which it only compares its LDS
+  // base with 0 and reports through the progress word.  Anything else sends every run to walk2.
+  static bool lanes_kernels_usable(int *d_progress) {
+    static int state = -1;                                      // (factors are built under the caller's serialisation)
+    if (state >= 0) return state == 1;
+    using namespace caskhip_lanes;
+    bool ok = true;
+    const LanesTri none{nullptr, nullptr, nullptr};
+    for (int unit = 0; unit < 2 && ok; unit++)
+      for (int e : {4, 8, 16})
+        for (int sel = 0; sel < 2 && ok; sel++) {
+          const void *fn = lanes_kernel(unit != 0, e, sel != 0);
+          ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES) == hipSuccess;
+          if (!ok) break;
+          int word = 0, zero = 0;
+          const double *bp = nullptr;
+          double *xp = nullptr;
+          unsigned long long *dbg = nullptr;
+          LanesTri t = none;
+          void *args[] = {&t, &zero, &zero, &bp, &xp, &d_progress, &dbg};
+          ok = hipMemset(d_progress, 0, sizeof(int)) == hipSuccess &&
+               hipLaunchKernel(fn, dim3(1), dim3(LN_T), args, LN_LDS_BYTES, nullptr) == hipSuccess &&
+               hipMemcpy(&word, d_progress, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && word != LN_BAD_LDS_BASE;
+          if (!ok && word == LN_BAD_LDS_BASE)
+            std::fprintf(stderr, "cask_hip: k_trsv_lanes' dynamic LDS does not start at address 0 in this build: the lane-group "
+                                 "walk is off, runs of long-row levels use walk2\n");
+        }
+    if (!ok) (void)hipGetLastError();
+    state = ok ? 1 : 0;
+    return ok;
+  }
+
+  // Schedules of a run of narrow levels.  walk2 (walker + stagers + read-ahead in position space, r3), packed (the
+  // four-wave walk, r2) and levels (the row-indexed walk, r1) walk every row in stored order and are bit-identical to
+  // each other (tested); lanes (r5, the lane-group walk for runs with long rows) adds a row's products lane group by
+  // lane group and multiplies by a reciprocal diagonal: the same solution to rounding.  The default is lanes where a
+  // run's rows average more than 6 entries, walk2 elsewhere.  CASK_HIP_TRSV = levels | walk2 | packed | lanes forces
+  // one; any other value is an error on stderr and the default schedule (r6, ADVICE r5: `walk1` and `syncfree`, removed
+  // in round 5 as measured losses -- docs/experiments.md -- used to select the default without a word).
   static int forced_mode() {
     const char *force = std::getenv("CASK_HIP_TRSV");
-    if (!force) return 0;
+    if (!force || !*force) return 0;
     const std::string f(force);
-    return f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : f == "lanes" ? 6 : 0;
+    const int mode = f == "levels" ? 2 : f == "walk2" ? 4 : f == "packed" || f == "packed4" ? 5 : f == "lanes" ? 6 : f == "default" ? 0 : -1;
+    if (mode < 0) {
+      static bool warned = false;
+      if (!warned)
+        std::fprintf(stderr, "cask_hip: CASK_HIP_TRSV=%s is not a schedule (levels | packed | walk2 | lanes | default; walk1 and "
+                             "syncfree were removed in round 5): running the default schedule\n", force);
+      warned = true;
+      return 0;
+    }
+    return mode;
   }
 
   int solve(const double *d_b, double *d_x, hipStream_t s) const {
@@ -1219,12 +1276,14 @@ struct TriFactor {
                              w2_epos.p, w2_eval.p, w2_pdiag.p, w2_bp.p, w2_xp.p);
         else if (st.g0 >= 0) {
           using namespace caskhip_lanes;
-          auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(LN_GRID), dim3(LN_T), LN_LDS_BYTES, s, ln, st.g0, st.g1, w2_bp.p, w2_xp.p, w2_progress.p, w2_dbg.p);
-          };
-          if (st.ge == 4) unit ? go(k_trsv_lanes<true, 4>) : go(k_trsv_lanes<false, 4>);
-          else if (st.ge == 8) unit ? go(k_trsv_lanes<true, 8>) : go(k_trsv_lanes<false, 8>);
-          else unit ? go(k_trsv_lanes<true, 16>) : go(k_trsv_lanes<false, 16>);
+          const LanesTri t = ln;
+          const int c0 = st.g0, c1 = st.g1;
+          const double *bp = w2_bp.p;
+          double *xp = w2_xp.p;
+          int *progress = w2_progress.p;
+          unsigned long long *dbg = w2_dbg.p;
+          void *args[] = {const_cast<LanesTri *>(&t), const_cast<int *>(&c0), const_cast<int *>(&c1), &bp, &xp, &progress, &dbg};
+          PC_TRY(hipLaunchKernel(lanes_kernel(unit, st.ge, lanes_select), dim3(LN_GRID), dim3(LN_T), args, LN_LDS_BYTES, s));
         }
         else if (st.d0 < 0)
           hipLaunchKernelGGL(k_trsv_levels_p, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, u, level_ptr.p, w2_eptr.p, w2_epos.p,

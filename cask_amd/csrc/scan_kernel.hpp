@@ -32,13 +32,15 @@
 // plan).  Rows longer than CAP/2 are long-row pieces summed by the whole workgroup (+ the fix-up kernel when a row
 // has several).
 //
-// x window (XP > 0) and far columns (FARX > 0): the plan then keeps its own column stream.  A nonzero inside its
-// block's x window (per block the densest column range of <= 2 * XP * wg_size entries, loaded in 16-byte pairs in front
-// of the streams and parked in LDS) carries an LDS slot; a far nonzero -- outside the window and outside the rows its
-// XCD walks, i.e. outside what that XCD's L2 keeps anyway -- carries ~index into `farx`, which is filled column panel
-// by column panel either by k_far_panels just before this launch (FARX == 1) or by producer workgroups of this very
-// launch, handed off through per-producer flags (FARX == 2, below).  Both far forms cut the fabric traffic of the
-// webbase-like matrix from 2.3x to 1.28x the algorithmic bytes and both cost more time than they save.
+// x window (XP > 0): the plan then keeps its own column stream.  A nonzero inside its block's x window (per block the
+// densest column range of <= 2 * XP * wg_size entries, loaded in 16-byte pairs in front of the streams and parked in LDS)
+// carries an LDS slot.  (Rounds 3-5 also had "far columns" here -- the scattered nonzeros served from a column-panel
+// pre-gather, as its own launch or by producer workgroups of the product launch; both cut the fabric traffic of the
+// webbase-like matrix from 2.3x to 1.28x the algorithmic bytes and both cost more time than they saved: removed in
+// ABI 7, docs/experiments.md.)
+//
+// Sub-matrix blocks (r6, the long rows of a SLICE plan: slice_kernel.hpp): KIND_HOLES | KIND_NOFILL -- the row map names
+// the rows the block owns, every other row of its span belongs to somebody else and is left alone.
 //
 // Reference: the always-streaming multiply / reduce pipeline of src/spmv/src/SpmvKernel.java:18-309 and the
 // row-length driven read control of ParallelCsrReadControl.java:148-208 -- whose per-cycle "this entry ends a row"
@@ -48,76 +50,15 @@
 
 namespace caskhip {
 
-// ---- fused far pre-gather (FARX == 2): producer workgroups and the hand-off ----------------------------------
-// The far values a product block needs come from workgroups of the SAME launch (the first far.grid ones: dispatched
-// first, one chunk of one column panel each).  No global barrier and no atomics -- a counter every workgroup adds to
-// or polls serialises at the memory side (a first version with one "producers done" counter ran 127 us):
-//   * every producer h owns a word flag[h], every product block b a word epoch[b]; all start at 0 and every launch
-//     of the plan adds exactly 1 to each (launches of one plan are sequential: stream order), so in launch number E
-//     a block waits for flag[h] == E of the producers whose chunks hold its far entries -- inside a panel a block's
-//     far entries are one contiguous run, so that is one or two chunks per panel, at most SCAN_NEEDS words, each
-//     polled by its own lane of wave 0;
-//   * producer: chunk of farx stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup
-//     barrier, one lane stores flag[h] = E (sc1).  Consumer: sc1 polls, workgroup barrier, then plain loads of
-//     farx.  Plain loads are enough because a chunk is whole 128-byte lines (the planner aligns every panel's share
-//     of farx to a line and a chunk is a multiple of 16 entries): a line is written by one producer, nobody reads
-//     any part of it before that producer's flag says E, so neither an L1 nor an L2 can hold it from earlier in
-//     this launch -- and lines of the previous launch went with the kernel boundary.  (MI355X_MICROARCH "Workgroup
-//     dispatch, XCD placement & inter-workgroup visibility": the stale-line hazard is an L1/L2-resident line that
-//     another CU has since rewritten; here no such line can exist.)
-//   * the poll is bounded: a block that gives up (HIP promises no dispatch order: producers might not be resident
-//     while consumers hold every slot) gathers its far values from x itself through the far column list -- that
-//     costs time, never correctness.
-constexpr int SCAN_POLL_LIMIT = 1 << 12;
-struct ScanSync {
-  int *flag;                            // [far.grid]
-  int *epoch;                           // [n_blocks]
-  const int *needs;                     // [n_blocks][SCAN_NEEDS] producer ids, -1 = none
-};
-__device__ __forceinline__ bool scan_wait_far(const ScanSync &sy, int lb, int *lds_word) {
-  if (threadIdx.x < 64) {                                     // wave 0 polls, the others wait at the barrier
-    const int lane = threadIdx.x;
-    const int need = lane < SCAN_NEEDS ? sy.needs[(size_t)lb * SCAN_NEEDS + lane] : -1;
-    int e = 0;
-    if (lane == 0) {
-      e = sy.epoch[lb] + 1;                                   // this launch's number (own word: written by this block only)
-      sy.epoch[lb] = e;
-    }
-    e = __builtin_amdgcn_readfirstlane(e);
-    bool ok = need < 0;
-    int spins = 0;
-    while (true) {
-      if (!ok) ok = __hip_atomic_load(sy.flag + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - e >= 0;
-      if (__ballot(!ok) == 0 || ++spins >= SCAN_POLL_LIMIT) break;
-      __builtin_amdgcn_s_sleep(40);                           // ~1 us: pollers share the fabric with the streams
-    }
-    const bool all_in = __ballot(!ok) == 0;
-    if (lane == 0) *lds_word = all_in;
-  }
-  __syncthreads();
-  return *lds_word != 0;
-}
-__device__ __forceinline__ double far_value(const double *farx, const int *fcol, const double *x, int idx, bool ready) {
-  if (ready) return farx[idx];                                // plain: see "whole lines" above
-  return x[fcol[idx]];
-}
-
 // One piece of one long row (or a run of empty rows): the whole workgroup strides over it.
-template <bool NT, int FARX>
+template <bool NT>
 __device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *__restrict__ ci,
                                                 const double *__restrict__ val, const double *__restrict__ x,
-                                                const double *__restrict__ farx, double *__restrict__ y,
-                                                double *__restrict__ partials, double *red, const int *fcol,
-                                                const ScanSync &sy, int lb) {
+                                                double *__restrict__ y, double *__restrict__ partials, double *red) {
   const int WG = blockDim.x, tid = threadIdx.x;
   if (d.nnz_count == 0) {                                     // a run of empty rows
     for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = 0.0;
     return;
-  }
-  bool ready = true;
-  if (FARX == 2 && (d.kind_g & KIND_FAR)) {                   // workgroup-uniform
-    ready = scan_wait_far(sy, lb, reinterpret_cast<int *>(red + 20));
-    __syncthreads();
   }
   const int end = d.nnz_start + d.nnz_count;
   double acc = 0.0;
@@ -132,7 +73,7 @@ __device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *_
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      xv[u] = (FARX && c[u] < 0) ? (FARX == 2 ? far_value(farx, fcol, x, ~c[u], ready) : farx[~c[u]]) : x[c[u]];
+      xv[u] = x[c[u]];
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (k + u * WG < end) acc = fma(v[u], xv[u], acc);
@@ -148,20 +89,17 @@ __device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *_
   }
 }
 
-// Column references of the plan's own column stream (plans with an x window and/or far nonzeros; otherwise the
-// caller's col_ind is streamed as it is):  c >= 0 without SCAN_LDS_BIT: x[c];  with it: slot c & 0xffff of the block's
-// x window in LDS;  c < 0: farx[~c].
+// Column references of the plan's own column stream (plans with an x window; otherwise the caller's col_ind is
+// streamed as it is):  without SCAN_LDS_BIT: x[c];  with it: slot c & 0xffff of the block's x window in LDS.
 // r5: the x window SHARES the product area's LDS (it is dead once every thread holds its x values: one more barrier) --
 // a 2 048-entry window costs no LDS at 256 x 8 and the grid stays at 8 workgroups per CU; with 16 KB of its own the same
 // window took the kernel to 4 per CU, which is what made windows lose on short rows (profiles/r05_merge_forms.txt).
-template <int IPT, bool NT, int FARX, int XP>
+template <int IPT, bool NT, int XP>
 __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__restrict__ blocks, int n_blocks, int remap,
                                            int nnz, int n_cols, const int *__restrict__ rp, const int *__restrict__ ci,
                                            const double *__restrict__ val, const unsigned *__restrict__ meta,
                                            const int *__restrict__ rowmap, const double *__restrict__ x,
-                                           const double *__restrict__ farx, double *__restrict__ y,
-                                           double *__restrict__ partials, const int *__restrict__ fcol,
-                                           const ScanSync &sy) {
+                                           double *__restrict__ y, double *__restrict__ partials) {
   static_assert(IPT % 2 == 0 && IPT <= 16, "items per thread: even (16-byte loads), at most 16 (row-end bits)");
   extern __shared__ __align__(16) unsigned char smem[];
   const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
@@ -175,7 +113,7 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
   const int lb = logical_block(hw_block, n_blocks, remap);
   const BlockDesc d = blocks[lb];
   if (d.kind_g & KIND_LONG) {
-    scan_long_piece<NT, FARX>(d, ci, val, x, farx, y, partials, prod, fcol, sy, lb);
+    scan_long_piece<NT>(d, ci, val, x, y, partials, prod);
     return;
   }
 
@@ -223,40 +161,23 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
       if (u * WG + tid >= npairs - 1) c[u].y = c[u].x;
   }
   dbl2 xv[IPT / 2];
-  if (XP > 0 || FARX) {
+  if (XP > 0) {
     // global sources first (all of a lane's loads go out back to back), then the window slots from LDS
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
       const int cx = c[u].x, cy = c[u].y;
       xv[u].x = 0.0;
       xv[u].y = 0.0;
-      if (FARX == 2) {                                        // far values come later, behind the hand-off
-        if (cx >= 0 && (!(XP > 0) || !(cx & SCAN_LDS_BIT))) xv[u].x = x[cx];
-        if (cy >= 0 && (!(XP > 0) || !(cy & SCAN_LDS_BIT))) xv[u].y = x[cy];
-      } else {
-        const double *px = (FARX && cx < 0) ? farx + ~cx : x + cx;
-        const double *py = (FARX && cy < 0) ? farx + ~cy : x + cy;
-        if (!(XP > 0) || cx < 0 || !(cx & SCAN_LDS_BIT)) xv[u].x = *px;
-        if (!(XP > 0) || cy < 0 || !(cy & SCAN_LDS_BIT)) xv[u].y = *py;
-      }
+      if (!(cx & SCAN_LDS_BIT)) xv[u].x = x[cx];
+      if (!(cy & SCAN_LDS_BIT)) xv[u].y = x[cy];
     }
-    if (FARX == 2 && (d.kind_g & KIND_FAR)) {                 // workgroup-uniform
-      const bool ready = scan_wait_far(sy, lb, wflag + 15);
 #pragma unroll
-      for (int u = 0; u < IPT / 2; u++) {
-        if (c[u].x < 0) xv[u].x = far_value(farx, fcol, x, ~c[u].x, ready);
-        if (c[u].y < 0) xv[u].y = far_value(farx, fcol, x, ~c[u].y, ready);
-      }
+    for (int u = 0; u < IPT / 2; u++) {
+      const int cx = c[u].x, cy = c[u].y;
+      if (cx & SCAN_LDS_BIT) xv[u].x = xs[cx & 0xffff];
+      if (cy & SCAN_LDS_BIT) xv[u].y = xs[cy & 0xffff];
     }
-    if (XP > 0) {
-#pragma unroll
-      for (int u = 0; u < IPT / 2; u++) {
-        const int cx = c[u].x, cy = c[u].y;
-        if (cx >= 0 && (cx & SCAN_LDS_BIT)) xv[u].x = xs[cx & 0xffff];
-        if (cy >= 0 && (cy & SCAN_LDS_BIT)) xv[u].y = xs[cy & 0xffff];
-      }
-      __syncthreads();                                        // every thread has its x values: the window's LDS is the products' now
-    }
+    __syncthreads();                                          // every thread has its x values: the window's LDS is the products' now
   } else {
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
@@ -353,76 +274,21 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
   if (holes) {
     const int n_ends = rmap[0];
     for (int r = tid; r < n_ends; r += WG) y[d.row_start + rmap[1 + r]] = rsum[r];
-    for (int r = tid; r < d.n_rows; r += WG)                  // the block's empty rows (every y entry is written once)
-      if (rp[d.row_start + r] == rp[d.row_start + r + 1]) y[d.row_start + r] = 0.0;
+    if (!(d.kind_g & KIND_NOFILL))                            // (sub-matrix blocks: the other rows are somebody else's)
+      for (int r = tid; r < d.n_rows; r += WG)                // the block's empty rows (every y entry is written once)
+        if (rp[d.row_start + r] == rp[d.row_start + r + 1]) y[d.row_start + r] = 0.0;
   } else {
     for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = rsum[r];
   }
   CASK_STAMP(4);
 }
 
-// farx[k] = x[fcol[k]] for one chunk of U * blockDim.x far entries of one column panel (panel = chunk index mod 8:
-// hardware deals workgroups round-robin over the XCDs, so one XCD's L2 sees one panel of x).  SC1: the fused form,
-// whose stores must be in memory before the hand-off counter moves.
-template <int U, bool SC1>
-__device__ __forceinline__ void far_chunk(int chunk, const ScanPanels &panels, const int *__restrict__ fcol,
-                                          const double *__restrict__ x, double *__restrict__ farx) {
-  const int WG = blockDim.x;
-  const int panel = chunk & (SCAN_PANELS - 1), idx = chunk >> 3;
-  const int k0 = panels.start[panel] + idx * (U * WG), k1 = min(k0 + U * WG, panels.start[panel + 1]);
-  if (k0 >= k1) return;
-  int c[U];
-  double v[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) c[u] = __builtin_nontemporal_load(fcol + min(k0 + u * WG + (int)threadIdx.x, k1 - 1));
-#pragma unroll
-  for (int u = 0; u < U; u++) v[u] = x[c[u]];
-#pragma unroll
-  for (int u = 0; u < U; u++)
-    if (k0 + u * WG + (int)threadIdx.x < k1) {
-      if (SC1) __hip_atomic_store(farx + k0 + u * WG + threadIdx.x, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else farx[k0 + u * WG + threadIdx.x] = v[u];
-    }
-}
-
-constexpr int SCAN_FAR_U = 4;           // far entries per lane of a producer workgroup
-
-template <int IPT, bool NT, int FARX, int XP>
+template <int IPT, bool NT, int XP>
 __global__ void k_spmv_scan(const BlockDesc *__restrict__ blocks, int n_blocks, int remap, int nnz, int n_cols,
                             const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
                             const unsigned *__restrict__ meta, const int *__restrict__ rowmap,
-                            const double *__restrict__ x, double *__restrict__ farx, double *__restrict__ y,
-                            double *__restrict__ partials, ScanFar far, ScanSync sy) {
-  if (FARX == 2) {
-    if ((int)blockIdx.x < far.grid) {                         // producer workgroups: the lowest ids, dispatched first
-      const int e = sy.flag[blockIdx.x] + 1;                  // own word; the previous launch's value came with the boundary
-      far_chunk<SCAN_FAR_U, true>(blockIdx.x, far.panels, far.fcol, x, farx);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave, before the barrier
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(sy.flag + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    scan_block<IPT, NT, FARX, XP>(blockIdx.x - far.grid, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x,
-                                  farx, y, partials, far.fcol, sy);
-  } else {
-    scan_block<IPT, NT, FARX, XP>(blockIdx.x, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x, farx, y,
-                                  partials, nullptr, sy);
-  }
-}
-
-// ------------------------------------------------------------------ far columns, column panel by column panel
-// The scattered part of a power-law matrix: 0.9 M of the webbase-like matrix's gathers hit uniformly random
-// entries of an 8 MB x.  With rows dealt to XCDs every one of the eight L2s ends up fetching most lines of x
-// (128-byte fills for 8 useful bytes: 131 MB moved for 57 MB of algorithmic traffic, profiles/traffic_webbase-1M.json).
-// The reference meets scattered columns by column blocking (SparseMatrix.hpp:459-482, Spmv.cpp:42-107); here only
-// the far nonzeros are column-blocked: sorted by column panel (8 panels of x, one per XCD: workgroup b works on
-// panel b % 8, and hardware deals workgroups round-robin over the XCDs), so a line of x is filled from memory once.
-// farx is PANEL-major, inside a panel in (block, nonzero) order: this kernel's stores are one coalesced stream, and
-// the far values one product block needs from one panel are one contiguous run.  Placement is for speed only.
-template <int U>
-__global__ void k_far_panels(ScanPanels panels, const int *__restrict__ fcol, const double *__restrict__ x,
-                             double *__restrict__ farx) {
-  far_chunk<U, false>(blockIdx.x, panels, fcol, x, farx);
+                            const double *__restrict__ x, double *__restrict__ y, double *__restrict__ partials) {
+  scan_block<IPT, NT, XP>(blockIdx.x, blocks, n_blocks, remap, nnz, n_cols, rp, ci, val, meta, rowmap, x, y, partials);
 }
 
 }  // namespace caskhip

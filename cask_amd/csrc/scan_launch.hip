@@ -1,49 +1,81 @@
-// k_spmv_scan / k_far_panels instantiations (see scan_launch.hpp).
-#include "scan_kernel.hpp"
+// k_spmv_scan / k_spmv_slice instantiations (see scan_launch.hpp).
+#include "slice_kernel.hpp"
 
 namespace caskhip {
 
-constexpr int FAR_U = SCAN_FAR_U;       // far nonzeros per lane of k_far_panels and of the fused producers
-
 template <int IPT, int XP>
-static void launch_scan_ix(const ScanLaunch &l, const ScanFar &far, const double *x, double *y, hipStream_t s) {
-  const bool fused = l.farx && l.sync;
-  const dim3 grid(l.grid + (fused ? far.grid : 0)), block(l.wg_size);
+static void launch_scan_ix(const ScanLaunch &l, const double *x, double *y, hipStream_t s) {
+  const dim3 grid(l.grid), block(l.wg_size);
   if constexpr (XP > 0 && 2 * XP > IPT + 1) {                // the planner never builds a window the product area cannot hold
-    (void)grid; (void)block; (void)x; (void)y; (void)s; (void)far;
+    (void)grid; (void)block; (void)x; (void)y; (void)s;
     return;
   } else {
-#define CASK_LAUNCH_S(NT, FARX)                                                                                      \
-  hipLaunchKernelGGL((k_spmv_scan<IPT, NT, FARX, XP>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, \
-                     l.n_cols, l.rp, l.ci, l.val, l.meta, l.rowmap, x, l.farx, y, l.partials, far, ScanSync{l.sync, l.sync ? l.sync + far.grid : nullptr, l.needs})
-    if (fused)       { if (l.nontemporal) CASK_LAUNCH_S(true, 2); else CASK_LAUNCH_S(false, 2); }
-    else if (l.farx) { if (l.nontemporal) CASK_LAUNCH_S(true, 1); else CASK_LAUNCH_S(false, 1); }
-    else             { if (l.nontemporal) CASK_LAUNCH_S(true, 0); else CASK_LAUNCH_S(false, 0); }
-#undef CASK_LAUNCH_S
+    if (l.nontemporal)
+      hipLaunchKernelGGL((k_spmv_scan<IPT, true, XP>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, l.n_cols,
+                         l.rp, l.ci, l.val, l.meta, l.rowmap, x, y, l.partials);
+    else
+      hipLaunchKernelGGL((k_spmv_scan<IPT, false, XP>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, l.n_cols,
+                         l.rp, l.ci, l.val, l.meta, l.rowmap, x, y, l.partials);
   }
 }
 
 template <int IPT>
-static void launch_scan_i(const ScanLaunch &l, const ScanFar &far, const double *x, double *y, hipStream_t s) {
+static void launch_scan_i(const ScanLaunch &l, const double *x, double *y, hipStream_t s) {
   switch (l.xp) {
-    case 0:  launch_scan_ix<IPT, 0>(l, far, x, y, s); break;
-    case 2:  launch_scan_ix<IPT, 2>(l, far, x, y, s); break;
-    case 4:  launch_scan_ix<IPT, 4>(l, far, x, y, s); break;
-    default: launch_scan_ix<IPT, 8>(l, far, x, y, s); break;
+    case 0:  launch_scan_ix<IPT, 0>(l, x, y, s); break;
+    case 2:  launch_scan_ix<IPT, 2>(l, x, y, s); break;
+    case 4:  launch_scan_ix<IPT, 4>(l, x, y, s); break;
+    default: launch_scan_ix<IPT, 8>(l, x, y, s); break;
   }
 }
 
-int scan_far_chunk(int wg_size) { return FAR_U * wg_size; }
-
-void launch_scan(const ScanLaunch &l, const ScanFar &far, int items_per_thread, const double *x, double *y, hipStream_t s) {
-  if (l.farx && !l.sync && far.grid > 0)
-    hipLaunchKernelGGL((k_far_panels<FAR_U>), dim3(far.grid), dim3(l.wg_size), 0, s, far.panels, far.fcol, x, l.farx);
-  switch (items_per_thread) {
-    case 2:  launch_scan_i<2>(l, far, x, y, s); break;
-    case 4:  launch_scan_i<4>(l, far, x, y, s); break;
-    case 8:  launch_scan_i<8>(l, far, x, y, s); break;
-    default: launch_scan_i<16>(l, far, x, y, s); break;
+// SLICE: items_per_thread 4 or 8 for the long rows' blocks, K rounded up to the kernel's 2 / 4 / 8 planes
+template <int KM, int IPT, int XP>
+static void launch_slice_kix(const ScanLaunch &l, const double *x, double *y, hipStream_t s) {
+  if constexpr (XP > 0 && 2 * XP > IPT + 1) {
+    (void)l; (void)x; (void)y; (void)s;
+    return;
+  } else {
+    hipLaunchKernelGGL((k_spmv_slice<KM, IPT, XP>), dim3(l.grid + l.n_slice_blocks), dim3(l.wg_size), l.lds_bytes, s, l.blocks,
+                       l.grid, l.remap, l.nnz, l.n_cols, l.rp, l.ci, l.val, l.meta, l.rowmap, l.slices, l.n_slice_blocks,
+                       l.slice_val, l.slice_ci, l.slice_slot, x, y, l.partials);
   }
+}
+template <int KM, int IPT>
+static void launch_slice_ki(const ScanLaunch &l, const double *x, double *y, hipStream_t s) {
+  switch (l.xp) {
+    case 0:  launch_slice_kix<KM, IPT, 0>(l, x, y, s); break;
+    case 2:  launch_slice_kix<KM, IPT, 2>(l, x, y, s); break;
+    default: launch_slice_kix<KM, IPT, 4>(l, x, y, s); break;
+  }
+}
+template <int KM>
+static void launch_slice_k(const ScanLaunch &l, int items_per_thread, const double *x, double *y, hipStream_t s) {
+  if (items_per_thread == 4) launch_slice_ki<KM, 4>(l, x, y, s);
+  else launch_slice_ki<KM, 8>(l, x, y, s);
+}
+
+void launch_scan(const ScanLaunch &l, int items_per_thread, const double *x, double *y, hipStream_t s) {
+  if (l.n_slice_blocks > 0) {
+    switch (slice_kernel_km(l.slice_k)) {
+      case 2:  launch_slice_k<2>(l, items_per_thread, x, y, s); break;
+      case 4:  launch_slice_k<4>(l, items_per_thread, x, y, s); break;
+      default: launch_slice_k<8>(l, items_per_thread, x, y, s); break;
+    }
+    return;
+  }
+  switch (items_per_thread) {
+    case 2:  launch_scan_i<2>(l, x, y, s); break;
+    case 4:  launch_scan_i<4>(l, x, y, s); break;
+    case 8:  launch_scan_i<8>(l, x, y, s); break;
+    default: launch_scan_i<16>(l, x, y, s); break;
+  }
+}
+
+void gather_values(int64_t n, const int *d_idx, const double *d_src, double *d_dst, hipStream_t s) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<int64_t>(4096, (n + 255) / 256);
+  hipLaunchKernelGGL(k_gather_f64, dim3(grid), dim3(256), 0, s, n, d_idx, d_src, d_dst);
 }
 
 }  // namespace caskhip

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "plan_types.hpp"
+
 namespace caskhip {
 
 // Diagnostic build only (-DCASK_STAMPS, tools/stamps.py): wave 0 of every merge workgroup records
@@ -29,28 +31,6 @@ __device__ unsigned long long *g_stamps = nullptr;
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int    int2v __attribute__((ext_vector_type(2)));
-
-// One workgroup's share of the merge path.  32 bytes, read through the scalar
-// cache (address depends on blockIdx only).
-struct BlockDesc {
-  int32_t row_start;   // first row of the block
-  int32_t n_rows;      // rows finished by this block (1 for a long-row piece)
-  int32_t nnz_start;   // first nonzero
-  int32_t nnz_count;   // nonzeros in the block
-  int32_t cmin;        // smallest column referenced (x window start)
-  int32_t cwidth;      // window width in doubles (0 when the block has no nonzeros)
-  int32_t kind_g;      // bits 0-7: lanes per row in the reduce phase; bit 8: long-row piece; bit 9: piece writes a partial
-  int32_t aux;         // long-row piece: slot in the partials buffer; other blocks: largest column referenced
-};
-constexpr int KIND_LONG = 0x100;
-constexpr int KIND_PARTIAL = 0x200;
-constexpr int KIND_SKEW = 0x800;      // block holds rows much longer than its lanes-per-row suits: second, wave-per-row pass
-constexpr int KIND_CONTIG = 0x400;    // tiled block whose chunks are consecutive: chunk c starts at cmin + 64c
-constexpr int KIND_FAR = 0x1000;      // SCAN block with far nonzeros (x values through farx: scan_kernel.hpp)
-
-struct SplitRow {      // a row whose pieces are summed by the fix-up kernel
-  int32_t row, first_slot, n_slots, pad;
-};
 
 // Where a launch reads x from.  Without a halo every column comes from x[] (n_own = INT_MAX,
 // haddr = NULL).  With one (row-sharded product, include/cask_hip_p2p.h) columns >= n_own are
@@ -197,18 +177,6 @@ __device__ __forceinline__ T stream_load(const T *p) {
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
 }
-
-// MERGE: does the x window of this kernel shape share the product area's LDS?  (k_spmv_merge; the host plans the
-// launch's dynamic LDS with the same rule)
-__host__ __device__ constexpr bool merge_window_aliased(int xu, int ipt) { return xu == 8 && ipt >= 8; }
-
-// Rows longer than SKEW_FACTOR * (lanes per row) products get a whole wave each in a second pass.
-constexpr int SKEW_FACTOR = 32;
-// MERGE blocks with 1 or 2 lanes per row (hundreds of short rows per block): rows beyond SKEW_SHORT * G products
-// leave the first pass already and are summed by 16 lanes (up to SKEW_MED_MAX products) or a wave.
-constexpr int SKEW_SHORT = 8;
-constexpr int SKEW_MED_MAX = 512;
-__host__ __device__ constexpr int skew_short_max(int g) { return g <= 2 ? SKEW_SHORT * g : SKEW_FACTOR * g; }
 
 // The convergence flag is written by a workgroup of the launch that detects convergence while other workgroups
 // of the SAME launch may not have started yet (a grid is not guaranteed to be co-resident) -- and those still owe

@@ -41,8 +41,11 @@ __device__ __forceinline__ double row_dot(int s, int e, int j, const int *__rest
 // wave-instruction covers whole 128-byte lines.  Up to 4 L-chunks of a row are
 // in flight per lane.  x comes from an LDS window staged per workgroup when
 // the workgroup's column span fits the tile (LDSX), else from L2.
+// long_len > 0 (r6): rows of more than long_len nonzeros are NOT this kernel's -- a row-mapped kernel lets L lanes walk a
+// 4 700-entry row of a power-law matrix while the rest of the chip has finished (260-300 us on the webbase look-alikes);
+// the plan lists them as long-row pieces for k_spmv_long (+ the fix-up), as the merge plans do.
 template <int L, bool LDSX, bool NT>
-__global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width,
+__global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width, int long_len,
                               const int2v *__restrict__ xspan,
                               const int *__restrict__ rp, const int *__restrict__ ci,
                               const double *__restrict__ val, const double *__restrict__ x,
@@ -68,13 +71,15 @@ __global__ void k_spmv_vector(int n_rows, int n_wg, int remap, int tile_width,
   }
 
   double acc = 0.0;
-  if (row < n_rows) {
+  bool mine = row < n_rows;
+  if (mine) {
     const int s = rp[row], e = rp[row + 1];
-    if (LDSX && in_lds) acc = row_dot<L, true, NT>(s, e, j, ci, val, x, xs, cmin);
-    else                acc = row_dot<L, false, NT>(s, e, j, ci, val, x, xs, cmin);
+    if (long_len > 0 && e - s > long_len) mine = false;       // (the same answer in all L lanes of the row)
+    else if (LDSX && in_lds) acc = row_dot<L, true, NT>(s, e, j, ci, val, x, xs, cmin);
+    else                     acc = row_dot<L, false, NT>(s, e, j, ci, val, x, xs, cmin);
   }
   acc = group_sum<L>(acc);
-  if (j == 0 && row < n_rows) y[row] = acc;
+  if (j == 0 && mine) y[row] = acc;
 }
 
 // ------------------------------------------------ vector variant, pair loads (L >= 4)
@@ -88,7 +93,7 @@ constexpr int VEC_RG = 4;   // row groups per wave
 constexpr int VEC_U = 2;    // pair loads per lane and row before the first use
 constexpr int VEC_XW = 4;   // x-window loads per lane (windows of up to VEC_XW * wg_size entries are staged in LDS)
 template <int L, bool LDSX, bool NT>
-__global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, int nnz,
+__global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, int nnz, int long_len,
                                const int2v *__restrict__ xspan,
                                const int *__restrict__ rp, const int *__restrict__ ci,
                                const double *__restrict__ val, const double *__restrict__ x,
@@ -115,12 +120,15 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
   const int2v *ci2 = reinterpret_cast<const int2v *>(ci);
   const int max_gpair = ((nnz + 1) >> 1) - 1;                 // last valid pair of the arrays
   int s[VEC_RG], e[VEC_RG];
+  bool mine[VEC_RG];
 #pragma unroll
   for (int g = 0; g < VEC_RG; g++) {
     const int row = min(row0 + g * RPW, n_rows - 1);
     s[g] = rp[row];
     e[g] = rp[row + 1];
-    if (row0 + g * RPW >= n_rows) e[g] = s[g];                // past the matrix: an empty row
+    mine[g] = row0 + g * RPW < n_rows;
+    if (long_len > 0 && e[g] - s[g] > long_len) mine[g] = false;   // a long-row piece's (k_spmv_long): not summed, not stored here
+    if (!mine[g]) e[g] = s[g];                                // past the matrix / somebody else's: an empty row
   }
   int cmin = 0, span_hi = 0;                                  // span_hi: last staged window entry (gathers are clamped to it)
   bool in_lds = false;
@@ -197,7 +205,7 @@ __global__ void k_spmv_vector2(int n_rows, int n_wg, int remap, int tile_width, 
 #pragma unroll
   for (int g = 0; g < VEC_RG; g++) {
     const double r = group_sum<L>(acc[g]);
-    if (j == 0 && row0 + g * RPW < n_rows) y[row0 + g * RPW] = r;
+    if (j == 0 && mine[g]) y[row0 + g * RPW] = r;
   }
   CASK_STAMP(5);
 }

@@ -63,6 +63,7 @@ constexpr int LN_UNITS = LN_CHUNK_BYTES / 16;             // 16-byte units per c
 constexpr int LN_UJ = (LN_UNITS + LN_ST - 1) / LN_ST;     // ... per stager thread
 constexpr int LN_RJ = (LN_ROWS + LN_ST - 1) / LN_ST;      // right-hand sides per stager thread
 constexpr int LN_HDR_INTS = 16;   // per chunk: [8] first position, [9] positions, [10] [11] the same of the chunk LN_NG behind, [12] E
+constexpr int LN_BAD_LDS_BASE = -0x4C4453;                   // progress word of a launch whose dynamic LDS does not start at 0
 constexpr int LN_ZERO = 8 * LN_RING;                      // LDS byte address of a constant 0.0 ...
 constexpr int LN_DUMP = LN_ZERO + 8;                      // ... and of a slot nobody reads
 constexpr int LN_BUF0 = LN_ZERO + 16;
@@ -107,7 +108,10 @@ __device__ __forceinline__ void ln_st(int addr, T v) { *(LN_AS3 T *)(uintptr_t)(
 
 // One chunk by the walker wave: its slabs back to back, fully unrolled (straight-line code: the compiler counts the LDS
 // operations in flight).  base: the LDS byte address of the chunk's buffer.
-template <bool UNIT, int E>
+// SEL: how a lane of a narrower group ignores what a DPP step moves across its group's boundary -- true (the engine's):
+// a select on the moved value; false (the round-5 form, CASK_HIP_TRSV_LANES_MASK=mul, kept for the A/B): a multiplication
+// by 0.0, which is only right while every partial sum is finite (0 x Inf = NaN lands in a neighbour's row).
+template <bool UNIT, int E, bool SEL>
 __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
   constexpr int C = ln_slabs_per_chunk(E), LANE_BYTES = 12 * E, SLAB_BYTES = 64 * LANE_BYTES;
   constexpr int AHEAD = C >= 8 ? 3 : C >= 4 ? 2 : 1;          // slabs whose records are held ahead of the one being solved
@@ -151,19 +155,25 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
     double acc = NCH == 4 ? (ch[0] + ch[1]) + (ch[2] + ch[3]) : ch[0] + ch[1];
     // A group's sum ends up in its LAST lane: an inclusive scan over windows of 2, 4, .. lanes.  Groups start on multiples
     // of their sizes, widest first: a step of 2^(k-1) lanes reaches across a group boundary only in lanes whose own group
-    // is narrower than 2^k, and those add 0 x what came across (f[k]: 1.0 or 0.0, from the lane word, computed while the x
-    // values are on their way: a masked step costs the dependent chain what a plain one does; partial sums are finite).
+    // is narrower than 2^k, and those must ignore what came across.  r6: by a SELECT on the moved value (the comparison of
+    // the lane word's log2 G with k is made while the x values are on their way) -- round 5 multiplied it by f[k] = 0.0,
+    // and 0 x Inf = NaN put one overflowing row's NaN into slab neighbours that depend on nothing bad, where mkl_dcsrtrsv
+    // (MklLayer.hpp:29-85) and the other schedules contaminate true dependents only (tests/test_nonfinite_gpu.py).
     // lg: the widest group's log2 (lane 0's), a scalar.
+    auto step = [&](int k, double moved) {
+      if constexpr (SEL) acc += lgl > k ? moved : 0.0;
+      else acc = fma(f[k], moved, acc);
+    };
     if (lg >= 1) {
-      acc = fma(f[0], ln_dpp_moved<0x111, 0xf>(acc), acc);    // row_shr:1
+      step(0, ln_dpp_moved<0x111, 0xf>(acc));                 // row_shr:1
       if (lg >= 2) {
-        acc = fma(f[1], ln_dpp_moved<0x112, 0xf>(acc), acc);  // row_shr:2
+        step(1, ln_dpp_moved<0x112, 0xf>(acc));               // row_shr:2
         if (lg >= 3) {
-          acc = fma(f[2], ln_dpp_moved<0x114, 0xf>(acc), acc);                 // row_shr:4
+          step(2, ln_dpp_moved<0x114, 0xf>(acc));             // row_shr:4
           if (lg >= 4) {
-            acc = fma(f[3], ln_dpp_moved<0x118, 0xf>(acc), acc);               // row_shr:8
+            step(3, ln_dpp_moved<0x118, 0xf>(acc));           // row_shr:8
             if (lg >= 5) {
-              acc = fma(f[4], ln_dpp_moved<0x142, 0xa>(acc), acc);             // row_bcast15 -> rows 1, 3
+              step(4, ln_dpp_moved<0x142, 0xa>(acc));         // row_bcast15 -> rows 1, 3
               if (lg >= 6) acc += ln_dpp_moved<0x143, 0xc>(acc);               // row_bcast31 -> rows 2, 3 (one group of 64)
             }
           }
@@ -176,7 +186,7 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
   }
 }
 
-template <bool UNIT, int E>
+template <bool UNIT, int E, bool SEL = true>
 __global__ void __launch_bounds__(LN_T)
 k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *xp, int *progress,
              unsigned long long *dbg) {
@@ -213,6 +223,15 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
   extern __shared__ double ln_lds[];
   char *lds = reinterpret_cast<char *>(ln_lds);
   double *ring = ln_lds;
+  // The host wrote ABSOLUTE LDS byte addresses into the stream (ring at 0, LN_ZERO, LN_BUF0): that holds only while this
+  // kernel's dynamic LDS starts at address 0 -- no static __shared__ anywhere in it, no runtime reservation.  Checked on
+  // every launch (a scalar compare): a build or runtime that moves the base gets progress = LN_BAD_LDS_BASE and no solve
+  // (the host side reads the word after the first application of a factor and falls back to walk2: cask_hip_precond.hip).
+  if ((unsigned)(uintptr_t)(LN_AS3 char *)lds != 0u) {
+    if (threadIdx.x == 0) __hip_atomic_store(progress, LN_BAD_LDS_BASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (c0 >= c1) return;                                       // (the host's one-time probe of the check above: no chunks)
   const int tid = threadIdx.x, lane = tid & 63, sg = tid - 64;
   auto buf_base = [&](int which) { return LN_BUF0 + which * LN_BUF_BYTES; };
 
@@ -223,7 +242,7 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
       const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
       ln_barrier();                                           // chunk k is staged
       const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-      ln_walk_chunk<UNIT, E>(buf_base((k - c0) & 1), lane);
+      ln_walk_chunk<UNIT, E, SEL>(buf_base((k - c0) & 1), lane);
       if (dbg) {                                              // CASK_HIP_TRSV_STATS: cycles at the barrier / walking
         __builtin_amdgcn_s_waitcnt(0xC07F);
         d_wait += q1 - q0;

@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define CASK_HIP_ABI_VERSION 6   /* 6: measured losers removed -- variant MERGE_PAIR (5, xcd_remap = 2), index16 = 3 / 4 (run records),
+#define CASK_HIP_ABI_VERSION 7   /* 7: variant SLICE (row-mapped slices for short rows + nonzero-mapped blocks for long ones, one launch);
+                                  * VECTOR sends rows far longer than its lanes suit to the long-row pieces; SCAN's far_columns = 1 / 2
+                                  * removed (they cut fabric traffic and cost more time than they saved): rejected like the rest;
+                                  * cask_hip_spmv stages host vectors through pinned / registered memory (cask_hip_host_entry_*);
+                                  * 6: measured losers removed -- variant MERGE_PAIR (5, xcd_remap = 2), index16 = 3 / 4 (run records),
                                   * far_columns = 1 / 2 for MERGE: each is rejected with CASK_HIP_ERR_INVALID and a message naming
                                   * the replacement; 5: cask_hip_spmv_windows_device; 4: variant SCAN, CASK_HIP_PRECOND_ILU0_MC,
                                   * solver stride with an exchange callback */
@@ -45,10 +49,14 @@ extern "C" {
                                        * one BASELINE family, by 2 %); the value is rejected, never reused */
 #define CASK_HIP_VARIANT_SCAN     4   /* nonzero-mapped: equal nonzeros per workgroup, thread-owned runs of products and a
                                        * segmented scan of the carries; no row_ptr stream.  tile_width = x window staged in
-                                       * LDS (per block: the densest column range of that width); far_columns = 1 / 2:
-                                       * nonzeros outside the window and outside the rows their XCD walks are served by a
-                                       * column-panel pre-gather (1: its own launch, 2: producer workgroups of the product
-                                       * launch); 0 / -1 = off */
+                                       * LDS (per block: the densest column range of that width) */
+#define CASK_HIP_VARIANT_SLICE    6   /* short rows row-mapped, long rows nonzero-mapped, ONE launch (ABI 7): rows of at most
+                                       * K = lanes_per_row nonzeros (1..8; 0 = 4) are sorted by length inside windows of
+                                       * consecutive rows and stored as jagged planes -- a thread per row, sums in registers,
+                                       * y coalesced through a 16-bit slot map; longer rows are SCAN blocks over a compacted
+                                       * copy (wg_size, items_per_thread 4 / 8, tile_width as for SCAN).  The reference packs
+                                       * several short rows into one cycle under a lane mask:
+                                       * src/spmv/src/ParallelCsrReadControl.java:119-145,262-276 */
 
 typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launch plan */
 
@@ -58,7 +66,7 @@ typedef struct cask_hip_matrix cask_hip_matrix;   /* device-resident CSR + launc
  * DSE sweeps num_pipes/input_width/cache_size (src/runtime/Dse.cpp:103-109). */
 typedef struct cask_hip_params {
   int32_t variant;          /* CASK_HIP_VARIANT_*                                   */
-  int32_t lanes_per_row;    /* VECTOR: 1,2,4,...,64                                  */
+  int32_t lanes_per_row;    /* VECTOR: 1,2,4,...,64; SLICE: K, the longest row (nonzeros) a slice thread takes: 1..8 */
   int32_t tile_width;       /* doubles of x staged in LDS per workgroup; -1 = no tile */
   int32_t wg_size;          /* threads per workgroup: 64,128,256,512,1024            */
   int32_t items_per_thread; /* MERGE / MERGE_WAVE: merge items per lane: 2,4,8,16    */
@@ -70,10 +78,11 @@ typedef struct cask_hip_params {
                              * cask_hip_csr_get_params reports what the plan streams: 1 = 12-bit, 2 = 16-bit.
                              * The reference's own stream compaction is the RLE of empty-row runs,
                              * src/runtime/Spmv.hpp:213-250 */
-  int32_t far_columns;      /* SCAN only (see CASK_HIP_VARIANT_SCAN): 1 / 2 = far nonzeros through a column-panel
-                             * pre-gather -- the reference's column blocking (SparseMatrix.hpp:459-482) applied to the
-                             * scattered part only; 0 / -1 = off.  Opt-in: it cuts fabric traffic, not time.  MERGE's
-                             * far slots (ABI <= 5) were removed: 1 / 2 with another variant is rejected */
+  int32_t far_columns;      /* retired (ABI 7): 0 / -1 only.  ABI 4-6 served the scattered nonzeros of a SCAN plan through a
+                             * column-panel pre-gather (1: its own launch, 2: producer workgroups of the product launch) -- the
+                             * reference's column blocking (SparseMatrix.hpp:459-482) applied to the far part only; it cut the
+                             * fabric traffic of the webbase-like matrix from 2.3x to 1.28x the algorithmic bytes and cost more
+                             * time than it saved (docs/experiments.md).  1 / 2 are rejected with a reason */
 } cask_hip_params;
 
 typedef struct cask_hip_csr_info {

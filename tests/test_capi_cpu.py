@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in header_symbols():
         assert hasattr(lib, name)
-    assert lib.cask_hip_abi_version() == 6
+    assert lib.cask_hip_abi_version() == 7
 
 
 def test_dfe_compat_triple_is_exported():

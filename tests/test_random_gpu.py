@@ -39,7 +39,7 @@ def random_csr(rng, n_rows, n_cols, kind):
 
 
 def random_design_point(rng):
-    variant = rng.choice(["merge", "merge", "merge", "vector", "merge_wave", "scan", "scan"])
+    variant = rng.choice(["merge", "merge", "merge", "vector", "merge_wave", "scan", "scan", "slice", "slice"])
     if variant == "merge":
         return dict(variant="merge", items_per_thread=int(rng.choice([2, 4, 8, 8, 16])), wg_size=int(rng.choice([64, 128, 256, 512])),
                     tile_width=int(rng.choice([-1, 64, 512, 1024, 4096])), index16=int(rng.choice([-1, 1, 1, 2, 0])),
@@ -49,8 +49,12 @@ def random_design_point(rng):
                     tile_width=int(rng.choice([-1, 1024])))
     if variant == "scan":
         return dict(variant="scan", items_per_thread=int(rng.choice([2, 4, 8, 8, 16])), wg_size=int(rng.choice([64, 128, 256, 512])),
-                    tile_width=int(rng.choice([-1, 64, 1024, 4096])), far_columns=int(rng.choice([-1, 0, 1, 2, 2])),
+                    tile_width=int(rng.choice([-1, 64, 1024, 4096])),
                     xcd_remap=int(rng.choice([-1, 1])), nontemporal=int(rng.choice([-1, 1])))
+    if variant == "slice":
+        return dict(variant="slice", lanes_per_row=int(rng.integers(1, 9)), items_per_thread=int(rng.choice([4, 8])),
+                    wg_size=int(rng.choice([64, 128, 256, 512])), tile_width=int(rng.choice([-1, 64, 1024, 4096])),
+                    xcd_remap=int(rng.choice([-1, 1])))
     return dict(variant="merge_wave", items_per_thread=int(rng.choice([2, 4, 8, 16])), wg_size=int(rng.choice([64, 256])))
 
 

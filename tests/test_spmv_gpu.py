@@ -40,12 +40,17 @@ DESIGN_POINTS = [
     dict(variant="scan", items_per_thread=2, wg_size=64, nontemporal=-1),
     dict(variant="scan", items_per_thread=4, wg_size=128, xcd_remap=-1),
     dict(variant="scan", items_per_thread=16, wg_size=256),
-    dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=4096, far_columns=1),     # x window in LDS + far panels
-    dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=2048, far_columns=-1),    # window only
-    dict(variant="scan", items_per_thread=4, wg_size=64, tile_width=-1, far_columns=1, nontemporal=-1),   # far panels only
-    dict(variant="scan", items_per_thread=16, wg_size=128, tile_width=300, far_columns=1, xcd_remap=-1),
-    dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=-1, far_columns=2),       # far panels by producer workgroups
-    dict(variant="scan", items_per_thread=2, wg_size=64, tile_width=128, far_columns=2, nontemporal=-1),
+    dict(variant="scan", items_per_thread=8, wg_size=256, tile_width=4096),                    # x window in LDS (the product area)
+    dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=2048),
+    dict(variant="scan", items_per_thread=16, wg_size=128, tile_width=300, xcd_remap=-1),
+    dict(variant="scan", items_per_thread=2, wg_size=64, tile_width=128, nontemporal=-1),
+    dict(variant="slice"),                                                                     # r6: short rows row-mapped (K = 4), long rows SCAN blocks
+    dict(variant="slice", lanes_per_row=1, wg_size=64, items_per_thread=4, tile_width=-1),
+    dict(variant="slice", lanes_per_row=2, wg_size=128, items_per_thread=8, tile_width=512),
+    dict(variant="slice", lanes_per_row=3, wg_size=256, items_per_thread=8, tile_width=2048),
+    dict(variant="slice", lanes_per_row=8, wg_size=512, items_per_thread=4, tile_width=4096, xcd_remap=-1),
+    dict(variant="slice", lanes_per_row=6, wg_size=1024, items_per_thread=4, tile_width=-1),
+    dict(variant="slice", lanes_per_row=5, wg_size=256, items_per_thread=4, tile_width=1024),
     dict(),   # AUTO / all defaults
 ]
 DP_IDS = ["-".join(f"{k[:3]}{v}" for k, v in dp.items()) or "auto" for dp in DESIGN_POINTS]
@@ -123,7 +128,9 @@ def test_baseline_configs_full_size(name):
     for dp in (dict(variant="merge"), dict(variant="vector"), dict(variant="merge", tile_width=-1),
                dict(variant="merge_wave"), dict(variant="merge", wg_size=512, items_per_thread=8),
                dict(variant="vector", lanes_per_row=8, tile_width=-1), dict(variant="scan"),
-               dict(variant="scan", tile_width=-1, far_columns=-1), dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=4096, far_columns=1)):
+               dict(variant="scan", tile_width=-1), dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=4096),
+               dict(variant="slice"), dict(variant="slice", lanes_per_row=2, wg_size=512, items_per_thread=4, tile_width=-1),
+               dict(variant="slice", lanes_per_row=8, tile_width=2048)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         y1, y2 = m.spmv(x1), m.spmv(x2)
         y12 = m.spmv(2.0 * x1 - 0.5 * x2)
@@ -140,14 +147,16 @@ def _cant3_small():
 
 
 def test_removed_design_points_are_rejected_with_a_reason():
-    """ABI 6: the measured losers are gone from the shipped engine -- variant MERGE_PAIR (5,
-    xcd_remap = 2), run records (index16 = 3 / 4), far slots for MERGE (far_columns = 1 / 2) -- and asking for one is an
-    error that names the replacement, at create and at set_params."""
+    """ABI 6 / 7: the measured losers are gone from the shipped engine -- variant MERGE_PAIR (5,
+    xcd_remap = 2), run records (index16 = 3 / 4), the far-column pre-gathers (far_columns = 1 / 2: MERGE's in ABI 6, SCAN's
+    in ABI 7) -- and asking for one is an error that names the replacement, at create and at set_params."""
     n, rp, ci, va = synth.small("cant", factor=16)
-    assert capi.load().cask_hip_abi_version() >= 6
+    assert capi.load().cask_hip_abi_version() >= 7
     for bad, word in ((dict(variant=capi.VARIANT_MERGE_PAIR_REMOVED), "MERGE_PAIR"), (dict(variant="merge", xcd_remap=2), "MERGE_PAIR"),
                       (dict(variant="merge", index16=4), "run records"), (dict(variant="merge", index16=3), "run records"),
-                      (dict(variant="merge", far_columns=1), "SCAN only"), (dict(variant="vector", far_columns=2), "SCAN only")):
+                      (dict(variant="merge", far_columns=1), "were removed"), (dict(variant="vector", far_columns=2), "were removed"),
+                      (dict(variant="scan", far_columns=1), "pre-gather"), (dict(variant="scan", far_columns=2), "pre-gather"),
+                      (dict(variant="slice", lanes_per_row=9), "1..8"), (dict(variant="slice", items_per_thread=16), "4 or 8")):
         with pytest.raises(ValueError, match=word):
             capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**bad))
     m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
@@ -233,7 +242,8 @@ def test_long_rows_split_across_workgroups():
                dict(variant="merge_wave", items_per_thread=2), dict(variant="merge_wave", items_per_thread=16, wg_size=64),
                dict(variant="vector", lanes_per_row=64), dict(variant="vector", lanes_per_row=1),
                dict(variant="scan", wg_size=64, items_per_thread=2), dict(variant="scan", wg_size=256, items_per_thread=8),
-               dict(variant="scan", wg_size=64, items_per_thread=4, tile_width=512, far_columns=1)):
+               dict(variant="scan", wg_size=64, items_per_thread=4, tile_width=512),
+               dict(variant="slice", wg_size=64, items_per_thread=4), dict(variant="slice", lanes_per_row=8, wg_size=256, tile_width=512)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         info = m.info
         got = m.spmv(x)
@@ -594,82 +604,99 @@ def test_scan_kernel_rows_that_span_threads_waves_and_holes():
         va = rng.standard_normal(ci.size)
         x = rng.standard_normal(m_cols)
         want = oracle.csr_spmv(rp, ci, va, x)
-        for extra in (dict(tile_width=-1, far_columns=-1), dict(tile_width=1024, far_columns=1)):
-            m = capi.CsrMatrix.from_host(n, m_cols, rp, ci, va, capi.make_params(variant="scan", wg_size=wg,
-                                                                                 items_per_thread=ipt, **extra))
-            assert m.params.as_dict()["variant"] == "scan"
+        for extra in (dict(variant="scan", tile_width=-1), dict(variant="scan", tile_width=1024)) + \
+                ((dict(variant="slice", lanes_per_row=3, tile_width=-1), dict(variant="slice", lanes_per_row=ipt, tile_width=512)) if ipt in (4, 8) else ()):
+            m = capi.CsrMatrix.from_host(n, m_cols, rp, ci, va, capi.make_params(wg_size=wg, items_per_thread=ipt, **extra))
+            assert m.params.as_dict()["variant"] == extra["variant"]
             got, again = m.spmv(x), m.spmv(x)
             m.close()
             oracle.assert_almost_equal(got, want, what=f"scan {wg}x{ipt} {extra}")
             assert np.array_equal(got, again)
 
 
-def test_scan_window_and_far_panels_are_taken_and_exact():
-    """SCAN on the power-law family with its x window (LDS slots instead of columns) and its far nonzeros (columns
-    outside the window and outside the rows their XCD walks) served by the column-panel pre-gather: the same products
-    in the same order whichever way x arrives => identical bits."""
+def test_scan_window_is_taken_and_exact():
+    """SCAN on the power-law family with its x window (LDS slots instead of columns): the same products in the same order
+    whichever way x arrives => identical bits.  (The far-column pre-gathers of rounds 3-5 left the engine in ABI 7.)"""
     n, rp, ci, va = synth.webbase_like()
     x = np.random.default_rng(22).uniform(-1, 1, n)
     want = oracle.csr_spmv(rp, ci, va, x)
     ys = {}
-    for tile, far in ((-1, -1), (4096, -1), (-1, 1), (4096, 0), (2048, 1), (-1, 2), (4096, 2)):
-        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=tile, far_columns=far))
+    for tile in (-1, 4096, 2048, 512):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=tile))
         prm = m.params.as_dict()
-        ys[(tile, far)] = (m.spmv(x), prm["tile_width"], prm["far_columns"])
-        assert np.array_equal(ys[(tile, far)][0], m.spmv(x))
+        ys[tile] = (m.spmv(x), prm["tile_width"], prm["far_columns"])
+        assert np.array_equal(ys[tile][0], m.spmv(x))
         m.close()
-        oracle.assert_almost_equal(ys[(tile, far)][0], want, what=f"scan tile {tile} far {far}")
+        oracle.assert_almost_equal(ys[tile][0], want, what=f"scan tile {tile}")
     # (r5: the window lives in the product area's LDS, so it is at most wg_size * items_per_thread = 2 048 entries wide)
-    assert ys[(-1, -1)][1:] == (-1, -1) and ys[(4096, -1)][1:] == (2048, -1) and ys[(-1, 1)][1:] == (-1, 1)
-    assert ys[(4096, 0)][1:] == (2048, -1)                   # far panels are opt-in (measured: they do not pay)
-    assert ys[(-1, 2)][1:] == (-1, 2) and ys[(4096, 2)][1:] == (2048, 2)
+    assert ys[-1][1:] == (-1, -1) and ys[4096][1:] == (2048, -1) and ys[2048][1:] == (2048, -1) and ys[512][1:] == (1024, -1)
     for key in ys:
-        assert np.array_equal(ys[key][0], ys[(-1, -1)][0]), key
+        assert np.array_equal(ys[key][0], ys[-1][0]), key
 
 
-def test_scan_fused_far_handoff_with_a_changing_operand():
-    """far_columns = 2: the far values are produced by workgroups of the product launch itself and handed to the
-    product blocks through counters (scan_kernel.hpp).  What could go wrong is a product block reading a far value
-    one launch late (a stale line, a counter that did not reset): 60 back-to-back products -- eager and as a replayed
-    HIP graph -- each on a different x, every result compared with the separately launched pre-gather's bits."""
+def test_slice_plan_shapes_and_bits():
+    """Variant SLICE (r6) on the power-law look-alikes: a short row is added in stored order by ONE thread, so the rows
+    of one nonzero carry the SAME BITS whatever K is; the plan reports K, the long rows' window, and a grid of nonzero-mapped
+    + row-mapped workgroups; run to run bitwise reproducible; also as a captured graph with a changing operand."""
     import torch
-    n, rp, ci, va = synth.webbase_like()
+    n, rp, ci, va = synth.webbase2_like()
+    lens = np.diff(rp)
+    x = np.random.default_rng(23).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    got = {}
+    for k in (1, 2, 3, 4, 6, 8):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="slice", lanes_per_row=k, tile_width=2048))
+        prm, info = m.params.as_dict(), m.info
+        assert prm["variant"] == "slice" and prm["lanes_per_row"] == k and prm["tile_width"] == 2048
+        rows_per_block = 512 if k <= 4 else 256
+        assert info.grid >= (n + rows_per_block - 1) // rows_per_block
+        got[k] = m.spmv(x)
+        assert np.array_equal(got[k], m.spmv(x))
+        m.close()
+        oracle.assert_almost_equal(got[k], want, what=f"slice K={k}")
+    short = lens <= 1
+    for k in got:
+        assert np.array_equal(got[k][short], got[1][short])    # a one-nonzero row is one product wherever it runs
+    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="slice", lanes_per_row=4))
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(33)
-    m2 = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=-1, far_columns=2))
-    m0 = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="scan", tile_width=-1, far_columns=-1))
-    assert m2.params.as_dict()["far_columns"] == 2
-    xs = [torch.from_numpy(rng.uniform(-1, 1, n)).to(dev) for _ in range(6)]
-    x = torch.zeros(n, dtype=torch.float64, device=dev)
-    y2 = torch.zeros(n, dtype=torch.float64, device=dev)
-    y0 = torch.zeros(n, dtype=torch.float64, device=dev)
-    for it in range(30):
-        x.copy_(xs[it % 6])
-        m2.spmv_device(x, y2)
-        m0.spmv_device(x, y0)
-        assert torch.equal(y2, y0), f"eager product {it}"
-    # the same inside a graph: copy, product, copy, product ... replayed
-    outs = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(6)]
+    xs = [torch.from_numpy(np.random.default_rng(40 + i).uniform(-1, 1, n)).to(dev) for i in range(4)]
+    xt = torch.zeros(n, dtype=torch.float64, device=dev)
+    yt = torch.zeros(n, dtype=torch.float64, device=dev)
+    outs = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(4)]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        m2.spmv_device(x, y2)
+        m.spmv_device(xt, yt)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for k in range(6):
-            x.copy_(xs[k])
-            m2.spmv_device(x, outs[k])
-    for _ in range(5):
-        for o in outs:
-            o.fill_(float("nan"))
+        for i in range(4):
+            xt.copy_(xs[i])
+            m.spmv_device(xt, yt)
+            outs[i].copy_(yt)
+    for _ in range(3):
         g.replay()
-        torch.cuda.synchronize()
-        for k in range(6):
-            m0.spmv_device(xs[k], y0)
-            torch.cuda.synchronize()
-            assert torch.equal(outs[k], y0), f"graph product {k}"
-    oracle.assert_almost_equal(y0.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xs[5].cpu().numpy()), what="scan fused")
-    m2.close()
-    m0.close()
+    torch.cuda.synchronize()
+    for i in range(4):
+        oracle.assert_almost_equal(outs[i].cpu().numpy(), oracle.csr_spmv(rp, ci, va, xs[i].cpu().numpy()), what=f"graph product {i}")
+    m.close()
+
+
+def test_vector_long_rows_take_the_long_row_path():
+    """r6: the row-mapped VECTOR family hands rows of more than max(64, 32 L) nonzeros to long-row
+    pieces (k_spmv_long + the fix-up for rows of several pieces), as the merge plans do -- it let L lanes walk a
+    4 700-entry row before (260-300 us on the webbase look-alikes)."""
+    n, rp, ci, va = synth.webbase_like()
+    lens = np.diff(rp)
+    x = np.random.default_rng(24).uniform(-1, 1, n)
+    want = oracle.csr_spmv(rp, ci, va, x)
+    for lanes in (1, 2, 8, 64):
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="vector", lanes_per_row=lanes, tile_width=-1))
+        info = m.info
+        assert info.n_long_rows == int((lens > max(64, 32 * lanes)).sum())
+        assert info.n_split_rows == int((lens > 4096).sum())
+        got = m.spmv(x)
+        assert np.array_equal(got, m.spmv(x))
+        m.close()
+        oracle.assert_almost_equal(got, want, what=f"vector L={lanes}")
