@@ -109,3 +109,22 @@ build/libcask_hip_diag%.so: cask_amd/csrc/cask_hip.hip $(ENGINEHDR)
 build/ingest_time: tools/ingest_time.cpp $(HOSTHDR)
 	mkdir -p build
 	$(CXX) $(CXXFLAGS) -O2 -o $@ $<
+
+# CPU sanitizers on everything that is host code: the host surface's unit tests, the ingest timer,
+# the oracle's C restatement and the launch planners (plan_host.hpp, trsv_lanes_plan.hpp: host-only headers) under
+# AddressSanitizer + UndefinedBehaviorSanitizer.  CPU build only -- no GPU-side sanitizer, no xnack+ code objects.
+SANFLAGS := -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all -Wall -Iinclude -Icask_amd/csrc
+build/asan/test_host: tests/cpp/test_host.cpp $(HOSTHDR)
+	mkdir -p build/asan
+	$(CXX) $(SANFLAGS) -o $@ $<
+build/asan/ingest_time: tools/ingest_time.cpp $(HOSTHDR)
+	mkdir -p build/asan
+	$(CXX) $(SANFLAGS) -o $@ $<
+build/asan/test_planners: tests/cpp/test_planners.cpp cask_amd/csrc/plan_host.hpp cask_amd/csrc/plan_types.hpp cask_amd/csrc/trsv_lanes_plan.hpp $(HOSTHDR)
+	mkdir -p build/asan
+	$(CXX) $(SANFLAGS) -pthread -o $@ $<
+build/asan/libcask_oracle.so: oracle/cask_oracle.c
+	mkdir -p build/asan
+	gcc -std=c11 -O1 -g -fno-omit-frame-pointer -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=all -fPIC -shared -o $@ $< -lm
+asan: build/asan/test_host build/asan/ingest_time build/asan/test_planners build/asan/libcask_oracle.so
+.PHONY: asan

@@ -171,7 +171,10 @@ int resolve_params(const cask_hip_matrix &m, const cask_hip_params &in, cask_hip
     return fail(CASK_HIP_ERR_INVALID, "far_columns = 1 / 2 were removed (MERGE's far slots in ABI 6, SCAN's column-panel pre-gather "
                                       "in ABI 7): the pre-gather cost more time than the line fills it saved, docs/experiments.md; "
                                       "use 0 / -1");
-  if (m.nnz < 2 && !m.halo_addr) out.variant = CASK_HIP_VARIANT_VECTOR;     // the merge kernels stream 16-byte pairs
+  if (m.nnz < 2 && !m.halo_addr) {                                          // the merge kernels stream 16-byte pairs
+    if (out.variant == CASK_HIP_VARIANT_SLICE) out.lanes_per_row = 0;       // (it carried K, not lanes)
+    out.variant = CASK_HIP_VARIANT_VECTOR;
+  }
   if (out.variant == CASK_HIP_VARIANT_SLICE) {
     // K, the longest row a slice thread takes, travels in lanes_per_row; the long rows' blocks are SCAN blocks
     if (out.lanes_per_row == 0) out.lanes_per_row = 4;

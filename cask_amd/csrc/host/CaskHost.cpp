@@ -33,7 +33,7 @@ void check(int rc, const char *what) {
 
 // Run-time overrides for unchanged clients (the reference selects a design with test_spmv's optional implId
 // argument and a target with -t {dfe,sim,dfe_mock}; a GPU build has one target and many design points):
-//   CASK_HIP_VARIANT = auto | vector | merge | merge_wave | scan   overrides the variant of every matrix uploaded
+//   CASK_HIP_VARIANT = auto | vector | merge | merge_wave | scan | slice   overrides the variant of every matrix uploaded
 //   CASK_HIP_TILE    = <doubles> | -1                        overrides the x tile width (-1: no tile)
 cask_hip_params with_env_overrides(const cask_hip_params *p) {
   cask_hip_params out{};
@@ -45,7 +45,8 @@ cask_hip_params with_env_overrides(const cask_hip_params *p) {
     else if (s == "merge") out.variant = CASK_HIP_VARIANT_MERGE;
     else if (s == "merge_wave") out.variant = CASK_HIP_VARIANT_MERGE_WAVE;
     else if (s == "scan") out.variant = CASK_HIP_VARIANT_SCAN;
-    else throw std::invalid_argument("CASK_HIP_VARIANT must be auto, vector, merge, merge_wave or scan");
+    else if (s == "slice") out.variant = CASK_HIP_VARIANT_SLICE;
+    else throw std::invalid_argument("CASK_HIP_VARIANT must be auto, vector, merge, merge_wave, scan or slice");
   }
   if (const char *t = std::getenv("CASK_HIP_TILE")) out.tile_width = std::atoi(t);
   return out;

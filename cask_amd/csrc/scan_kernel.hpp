@@ -162,20 +162,32 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
   }
   dbl2 xv[IPT / 2];
   if (XP > 0) {
-    // global sources first (all of a lane's loads go out back to back), then the window slots from LDS
+    // Global sources first (all of a lane's loads go out back to back), then the window slots from LDS -- every load
+    // UNCONDITIONAL, the choice made by selects afterwards.  (r5 loaded under `if (!(c & SCAN_LDS_BIT))` / `if (c &
+    // SCAN_LDS_BIT)`: the compiler joins a conditionally loaded register with its default at the end of the branch and
+    // waits there -- s_waitcnt vmcnt(0) between the gathers: three dependent trips where one was meant.)  A lane whose
+    // reference is a window slot gathers the window's first entry: the lanes share that address, one request per wave.
+    int gx[IPT / 2], gy[IPT / 2];
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
-      const int cx = c[u].x, cy = c[u].y;
-      xv[u].x = 0.0;
-      xv[u].y = 0.0;
-      if (!(cx & SCAN_LDS_BIT)) xv[u].x = x[cx];
-      if (!(cy & SCAN_LDS_BIT)) xv[u].y = x[cy];
+      gx[u] = (c[u].x & SCAN_LDS_BIT) ? d.cmin : c[u].x;
+      gy[u] = (c[u].y & SCAN_LDS_BIT) ? d.cmin : c[u].y;
     }
 #pragma unroll
     for (int u = 0; u < IPT / 2; u++) {
-      const int cx = c[u].x, cy = c[u].y;
-      if (cx & SCAN_LDS_BIT) xv[u].x = xs[cx & 0xffff];
-      if (cy & SCAN_LDS_BIT) xv[u].y = xs[cy & 0xffff];
+      xv[u].x = x[gx[u]];
+      xv[u].y = x[gy[u]];
+    }
+    dbl2 xl[IPT / 2];
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xl[u].x = xs[(c[u].x & SCAN_LDS_BIT) ? (c[u].x & 0xffff) : 0];
+      xl[u].y = xs[(c[u].y & SCAN_LDS_BIT) ? (c[u].y & 0xffff) : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = (c[u].x & SCAN_LDS_BIT) ? xl[u].x : xv[u].x;
+      xv[u].y = (c[u].y & SCAN_LDS_BIT) ? xl[u].y : xv[u].y;
     }
     __syncthreads();                                          // every thread has its x values: the window's LDS is the products' now
   } else {

@@ -32,6 +32,11 @@ __device__ __forceinline__ void slice_block(const SliceDesc &d, const double *__
   extern __shared__ __align__(16) unsigned char smem[];
   double *sums = reinterpret_cast<double *>(smem);            // R * wg_size doubles
   const int WG = blockDim.x, tid = threadIdx.x;
+  // Every load below is UNCONDITIONAL with a clamped index -- a lane behind a plane's end re-reads the plane's last
+  // element (one request per wave: the lanes share the address) -- and masks come as selects at the very end.  The first
+  // version loaded under `if (position < cnt[j])`: the compiler then joins the loaded register with its default at the
+  // end of every branch and waits THERE (s_waitcnt vmcnt(1) behind each plane's pair of loads), which made the eight
+  // loads of a thread eight serial round trips: 18.2-19.9 us on webbase2 where SCAN takes 15.6.
   // issue order: the planes (the long pole: values + columns, then the dependent gathers), then the slot map
   double v[R][KM];
   int c[R][KM];
@@ -39,32 +44,24 @@ __device__ __forceinline__ void slice_block(const SliceDesc &d, const double *__
 #pragma unroll
   for (int j = 0; j < KM; j++) {
     const int cj = d.cnt[j];                                  // scalar: the descriptor came through the scalar cache
+    const int last = off + max(cj - 1, 0);                    // (cj == 0: one element that is some plane's, or the arrays' spare one)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const int s = r * WG + tid;
-      v[r][j] = 0.0;
-      c[r][j] = 0;
-      if (s < cj) {
-        v[r][j] = stream_load<NT>(sval + off + s);
-        c[r][j] = stream_load<NT>(sci + off + s);
-      }
+      const int e = min(off + r * WG + tid, last);
+      v[r][j] = stream_load<NT>(sval + e);
+      c[r][j] = stream_load<NT>(sci + e);
     }
     off += cj;
   }
   unsigned sl[R];
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int i = r * WG + tid;
-    sl[r] = i < d.n_rows ? (unsigned)stream_load<NT>(slot + d.row_start + i) : (unsigned)SLICE_NOT_MINE;
-  }
+  for (int r = 0; r < R; r++)
+    sl[r] = (unsigned)stream_load<NT>(slot + d.row_start + min(r * WG + tid, d.n_rows - 1));
   double xv[R][KM];
 #pragma unroll
   for (int j = 0; j < KM; j++)
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      xv[r][j] = 0.0;
-      if (r * WG + tid < (int)d.cnt[j]) xv[r][j] = x[c[r][j]];
-    }
+    for (int r = 0; r < R; r++) xv[r][j] = x[c[r][j]];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int s = r * WG + tid;
@@ -77,7 +74,7 @@ __device__ __forceinline__ void slice_block(const SliceDesc &d, const double *__
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int i = r * WG + tid;
-    if (sl[r] != (unsigned)SLICE_NOT_MINE) y[d.row_start + i] = sums[sl[r]];
+    if (i < d.n_rows && sl[r] != (unsigned)SLICE_NOT_MINE) y[d.row_start + i] = sums[sl[r]];
   }
 }
 

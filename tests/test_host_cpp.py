@@ -24,6 +24,46 @@ def test_host_unit_tests(plain_mtx_dir):
     assert re.search(r"\d+ checks, 0 failures", out.stdout)
 
 
+def test_host_code_under_sanitizers(plain_mtx_dir, tmp_path):
+    """`make asan` (SURVEY section 5 "sanitizers"; the reference has coverage flags only,
+    CMakeLists.txt:3): everything that is HOST code under AddressSanitizer + UBSan (-fno-sanitize-recover) on the CPU --
+    the host surface's unit tests, the MatrixMarket ingest, the oracle's C restatement (the whole of tests/test_oracle.py
+    against the instrumented library) and the launch planners: every plan of plan_host.hpp / trsv_lanes_plan.hpp built
+    for the 43 reference fixtures and the five small synthetic families, invariants checked (tests/cpp/test_planners.cpp).
+    No GPU-side sanitizer is involved."""
+    import sys
+    import numpy as np
+    from cask_amd import synth
+    make("asan")
+    asan = REPO / "build" / "asan"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([str(asan / "test_host"), str(plain_mtx_dir)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and re.search(r"\d+ checks, 0 failures", out.stdout), out.stdout[-2000:] + out.stderr[-4000:]
+    out = subprocess.run([str(asan / "ingest_time"), str(plain_mtx_dir / "matrices" / "OPF_3754.mtx")], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    dumps = tmp_path / "dumps"
+    dumps.mkdir()
+    for name in synth.GENERATORS:
+        n, rp, ci, va = synth.small(name)
+        with open(dumps / f"{name}.csr", "wb") as f:
+            np.array([n, n, ci.size], dtype=np.int32).tofile(f)
+            rp.astype(np.int32).tofile(f)
+            ci.astype(np.int32).tofile(f)
+            va.astype(np.float64).tofile(f)
+    out = subprocess.run([str(asan / "test_planners"), str(plain_mtx_dir), str(dumps)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-4000:]
+    m = re.search(r"(\d+) matrices, (\d+) lane-group runs \((\d+) chunks\), (\d+) checks, 0 failures", out.stdout)
+    assert m and int(m.group(1)) >= 48 and int(m.group(2)) >= 10 and int(m.group(4)) > 10_000_000, out.stdout[-500:]
+    # the oracle's restatement: the CPU suite's oracle tests against the instrumented library (python itself is not
+    # instrumented: the sanitizer runtimes are preloaded; CPython's own arenas make a leak check meaningless here)
+    pre = ":".join(subprocess.run(["gcc", f"-print-file-name={lib}"], capture_output=True, text=True, check=True).stdout.strip()
+                   for lib in ("libasan.so", "libubsan.so"))
+    out = subprocess.run([sys.executable, "-m", "pytest", str(REPO / "tests" / "test_oracle.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, cwd=str(REPO),
+                         env=dict(os.environ, LD_PRELOAD=pre, ASAN_OPTIONS="detect_leaks=0", CASK_ORACLE_LIB=str(asan / "libcask_oracle.so")))
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_generated_library_exports_the_loader_constructor():
     """The seam the reference's clients link against: the loader ctor, both variants."""
     make("cask_amd/lib/lib-generated/libSpmv_hip.so")
