@@ -778,6 +778,11 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
       l.slice_ci = pl.slice_ci.p;
       l.slice_slot = pl.slice_slot.p;
     }
+    if (slice) {                                              // development only: time the two kinds of workgroup apart
+      static const int diag = std::getenv("CASK_HIP_SLICE_DIAG") ? std::atoi(std::getenv("CASK_HIP_SLICE_DIAG")) : 0;
+      if (diag == 1) l.n_slice_blocks = 0;                    // the long rows' blocks alone (the result is incomplete)
+      if (diag == 2) l.grid = 0;                              // the slices alone
+    }
     launch_scan(l, pl.prm.items_per_thread, x, y, s);
     if (pl.n_split_rows > 0)
       hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,

@@ -788,7 +788,6 @@ struct TriFactor {
   int n = 0;
   bool lower = true, unit = false;
   int mode = 0;                                                 // CASK_HIP_TRSV when the factor was built (forced_mode)
-  bool lanes_select = true;                                     // k_trsv_lanes masks by select (false: CASK_HIP_TRSV_LANES_MASK=mul, the A/B)
   DevBuf<int> rp, ci, order, level_ptr;
   DevBuf<double> val;
   int n_levels = 0;
@@ -840,7 +839,6 @@ struct TriFactor {
     for (int r = 0; r < n; r++) ord[fill[level[r]]++] = r;
     steps.clear();
     mode = forced_mode();                                       // (read when the factor is built: a process may build factors under several)
-    lanes_select = lanes_mask_select();
     const int wide_from = mode == 2 ? WIDE_LEVEL_ROWWALK : WIDE_LEVEL;
     for (int l = 0; l < n_levels;) {
       if (lp[l + 1] - lp[l] >= wide_from) {
@@ -1191,19 +1189,14 @@ struct TriFactor {
     return CASK_HIP_OK;
   }
 
-  // Every instantiation of the lane-group walk, by (unit diagonal, entries per lane, select / multiply mask).
-  static const void *lanes_kernel(bool unit, int e, bool sel) {
+  // Every instantiation of the lane-group walk, by (unit diagonal, entries per lane).
+  static const void *lanes_kernel(bool unit, int e) {
     using namespace caskhip_lanes;
-#define CASK_LN_K(U, E, S) reinterpret_cast<const void *>(&k_trsv_lanes<U, E, S>)
-#define CASK_LN_E(U, S) (e == 4 ? CASK_LN_K(U, 4, S) : e == 8 ? CASK_LN_K(U, 8, S) : CASK_LN_K(U, 16, S))
-    return unit ? (sel ? CASK_LN_E(true, true) : CASK_LN_E(true, false)) : (sel ? CASK_LN_E(false, true) : CASK_LN_E(false, false));
+#define CASK_LN_K(U, E) reinterpret_cast<const void *>(&k_trsv_lanes<U, E>)
+#define CASK_LN_E(U) (e == 4 ? CASK_LN_K(U, 4) : e == 8 ? CASK_LN_K(U, 8) : CASK_LN_K(U, 16))
+    return unit ? CASK_LN_E(true) : CASK_LN_E(false);
 #undef CASK_LN_E
 #undef CASK_LN_K
-  }
-  // CASK_HIP_TRSV_LANES_MASK=mul: the round-5 mask (a multiplication by 0.0) instead of the select -- for the A/B only
-  static bool lanes_mask_select() {
-    const char *m = std::getenv("CASK_HIP_TRSV_LANES_MASK");
-    return !(m && std::string(m) == "mul");
   }
   // Once per process: may the lane-group kernels be used at all?  Their LDS attribute must be settable and -- the walker
   // uses ABSOLUTE LDS byte addresses the host wrote (trsv_lanes.hpp: ring at 0, LN_ZERO, LN_BUF0) -- their dynamic LDS must
@@ -1216,9 +1209,10 @@ struct TriFactor {
     bool ok = true;
     const LanesTri none{nullptr, nullptr, nullptr};
     for (int unit = 0; unit < 2 && ok; unit++)
-      for (int e : {4, 8, 16})
-        for (int sel = 0; sel < 2 && ok; sel++) {
-          const void *fn = lanes_kernel(unit != 0, e, sel != 0);
+      for (int e : {4, 8, 16}) {
+        if (!ok) break;
+        {
+          const void *fn = lanes_kernel(unit != 0, e);
           ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES) == hipSuccess;
           if (!ok) break;
           int word = 0, zero = 0;
@@ -1234,6 +1228,7 @@ struct TriFactor {
             std::fprintf(stderr, "cask_hip: k_trsv_lanes' dynamic LDS does not start at address 0 in this build: the lane-group "
                                  "walk is off, runs of long-row levels use walk2\n");
         }
+      }
     if (!ok) (void)hipGetLastError();
     state = ok ? 1 : 0;
     return ok;
@@ -1283,7 +1278,7 @@ struct TriFactor {
           int *progress = w2_progress.p;
           unsigned long long *dbg = w2_dbg.p;
           void *args[] = {const_cast<LanesTri *>(&t), const_cast<int *>(&c0), const_cast<int *>(&c1), &bp, &xp, &progress, &dbg};
-          PC_TRY(hipLaunchKernel(lanes_kernel(unit, st.ge, lanes_select), dim3(LN_GRID), dim3(LN_T), args, LN_LDS_BYTES, s));
+          PC_TRY(hipLaunchKernel(lanes_kernel(unit, st.ge), dim3(LN_GRID), dim3(LN_T), args, LN_LDS_BYTES, s));
         }
         else if (st.d0 < 0)
           hipLaunchKernelGGL(k_trsv_levels_p, dim3(1), dim3(TRSV_WG), 0, s, st.l0, st.l1, u, level_ptr.p, w2_eptr.p, w2_epos.p,

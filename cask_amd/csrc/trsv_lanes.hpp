@@ -77,10 +77,7 @@ __device__ __forceinline__ void ln_st(int addr, T v) { *(LN_AS3 T *)(uintptr_t)(
 
 // One chunk by the walker wave: its slabs back to back, fully unrolled (straight-line code: the compiler counts the LDS
 // operations in flight).  base: the LDS byte address of the chunk's buffer.
-// SEL: how a lane of a narrower group ignores what a DPP step moves across its group's boundary -- true (the engine's):
-// a select on the moved value; false (the round-5 form, CASK_HIP_TRSV_LANES_MASK=mul, kept for the A/B): a multiplication
-// by 0.0, which is only right while every partial sum is finite (0 x Inf = NaN lands in a neighbour's row).
-template <bool UNIT, int E, bool SEL>
+template <bool UNIT, int E>
 __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
   constexpr int C = ln_slabs_per_chunk(E), LANE_BYTES = 12 * E, SLAB_BYTES = 64 * LANE_BYTES;
   constexpr int AHEAD = C >= 8 ? 3 : C >= 4 ? 2 : 1;          // slabs whose records are held ahead of the one being solved
@@ -111,9 +108,6 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
     double rd = 1.0;
     if constexpr (!UNIT) rd = ln_ld<double>(brow + (LN_OFF_D - LN_OFF_B));
     const int lg = (__builtin_amdgcn_readfirstlane(tw[s]) >> 27) & 7, lgl = (tw[s] >> 27) & 7;
-    double f[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) f[k] = lgl > k ? 1.0 : 0.0;
     asm volatile("" ::: "memory");                            // the x reads go out first: the chain below waits for them
     if (s + AHEAD < C) preload(s + AHEAD);
     double ch[NCH];
@@ -125,14 +119,12 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
     // A group's sum ends up in its LAST lane: an inclusive scan over windows of 2, 4, .. lanes.  Groups start on multiples
     // of their sizes, widest first: a step of 2^(k-1) lanes reaches across a group boundary only in lanes whose own group
     // is narrower than 2^k, and those must ignore what came across.  r6: by a SELECT on the moved value (the comparison of
-    // the lane word's log2 G with k is made while the x values are on their way) -- round 5 multiplied it by f[k] = 0.0,
-    // and 0 x Inf = NaN put one overflowing row's NaN into slab neighbours that depend on nothing bad, where mkl_dcsrtrsv
-    // (MklLayer.hpp:29-85) and the other schedules contaminate true dependents only (tests/test_nonfinite_gpu.py).
+    // the lane word's log2 G with k is made while the x values are on their way) -- round 5 multiplied it by a 0.0 / 1.0
+    // factor, and 0 x Inf = NaN put one overflowing row's NaN into slab neighbours that depend on nothing bad, where
+    // mkl_dcsrtrsv (MklLayer.hpp:29-85) and the other schedules contaminate true dependents only
+    // (tests/test_nonfinite_gpu.py; the A/B: +0.4 %, inside the noise -- profiles/r06_lanes_mask.txt).
     // lg: the widest group's log2 (lane 0's), a scalar.
-    auto step = [&](int k, double moved) {
-      if constexpr (SEL) acc += lgl > k ? moved : 0.0;
-      else acc = fma(f[k], moved, acc);
-    };
+    auto step = [&](int k, double moved) { acc += lgl > k ? moved : 0.0; };
     if (lg >= 1) {
       step(0, ln_dpp_moved<0x111, 0xf>(acc));                 // row_shr:1
       if (lg >= 2) {
@@ -155,7 +147,7 @@ __device__ __forceinline__ void ln_walk_chunk(int base, int lane) {
   }
 }
 
-template <bool UNIT, int E, bool SEL = true>
+template <bool UNIT, int E>
 __global__ void __launch_bounds__(LN_T)
 k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *xp, int *progress,
              unsigned long long *dbg) {
@@ -211,7 +203,7 @@ k_trsv_lanes(LanesTri t, int c0, int c1, const double *__restrict__ bp, double *
       const unsigned long long q0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
       ln_barrier();                                           // chunk k is staged
       const unsigned long long q1 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-      ln_walk_chunk<UNIT, E, SEL>(buf_base((k - c0) & 1), lane);
+      ln_walk_chunk<UNIT, E>(buf_base((k - c0) & 1), lane);
       if (dbg) {                                              // CASK_HIP_TRSV_STATS: cycles at the barrier / walking
         __builtin_amdgcn_s_waitcnt(0xC07F);
         d_wait += q1 - q0;

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Device time of one ILU(0) application (two triangular solves) on a BASELINE look-alike, per schedule:
-    python tools/trsv_bench.py [matrix] [kind]        (CASK_HIP_TRSV=levels|packed|walk2|lanes forces a schedule;
-    CASK_HIP_TRSV_LANES_MASK=mul the round-5 DPP mask of the lane-group walk)
+    python tools/trsv_bench.py [matrix] [kind]        (CASK_HIP_TRSV=levels|packed|walk2|lanes forces a schedule)
 Prints one JSON line: milliseconds per application (best of 5), dependency levels, launches."""
 import json
 import os
