@@ -126,5 +126,12 @@ build/asan/test_planners: tests/cpp/test_planners.cpp cask_amd/csrc/plan_host.hp
 build/asan/libcask_oracle.so: oracle/cask_oracle.c
 	mkdir -p build/asan
 	gcc -std=c11 -O1 -g -fno-omit-frame-pointer -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=all -fPIC -shared -o $@ $< -lm
-asan: build/asan/test_host build/asan/ingest_time build/asan/test_planners build/asan/libcask_oracle.so
+# the threaded staging copy of the host-vector entry point: ASan / UBSan, and ThreadSanitizer in a build of its own
+build/asan/test_host_copy: tests/cpp/test_host_copy.cpp cask_amd/csrc/host_copy.hpp
+	mkdir -p build/asan
+	$(CXX) $(SANFLAGS) -pthread -o $@ $<
+build/asan/test_host_copy_tsan: tests/cpp/test_host_copy.cpp cask_amd/csrc/host_copy.hpp
+	mkdir -p build/asan
+	$(CXX) -std=c++17 -O1 -g -fsanitize=thread -Wall -Icask_amd/csrc -pthread -o $@ $<
+asan: build/asan/test_host build/asan/ingest_time build/asan/test_planners build/asan/libcask_oracle.so build/asan/test_host_copy build/asan/test_host_copy_tsan
 .PHONY: asan

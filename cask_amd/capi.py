@@ -30,8 +30,9 @@ EXPORTED_SYMBOLS = (
     "cask_hip_precond_create", "cask_hip_precond_destroy", "cask_hip_precond_factor_values", "cask_hip_precond_info",
     "cask_hip_precond_apply", "cask_hip_precond_apply_device", "cask_hip_trsolve", "cask_hip_pcg",
     "cask_hip_solve_device", "cask_hip_spmv_sequence_device", "cask_hip_spmv_windows_device",
-    "cask_hip_device_pci_bus_id",
+    "cask_hip_device_pci_bus_id", "cask_hip_host_entry_mode", "cask_hip_host_register", "cask_hip_host_unregister",
 )
+HOST_ENTRY_MODES = {"auto": 0, "pageable": 1, "staged": 2, "register_cache": 3}
 SOLVER_CG, SOLVER_BICG = 1, 2
 SOLVER_AUTO, SOLVER_COMPOSED, SOLVER_CLASSIC = 0, 1, 2
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_int32, c_void_p, c_void_p)
@@ -511,6 +512,26 @@ class Preconditioner:
             self.close()
         except Exception:
             pass
+
+
+def host_entry_mode(mode) -> str:
+    """Process-wide choice of how ``cask_hip_spmv`` moves host vectors (include/cask_hip.h); returns the previous one."""
+    names = {v: k for k, v in HOST_ENTRY_MODES.items()}
+    return names[load().cask_hip_host_entry_mode(HOST_ENTRY_MODES[mode] if isinstance(mode, str) else int(mode))]
+
+
+def host_register(a: np.ndarray):
+    """Declare a numpy array long-lived host memory the GPU may access in place (it must stay alive until
+    ``host_unregister``)."""
+    L = load()
+    L.cask_hip_host_register.argtypes = [c_void_p, ctypes.c_size_t]
+    _check(L.cask_hip_host_register(c_void_p(a.ctypes.data), a.nbytes))
+
+
+def host_unregister(a: np.ndarray):
+    L = load()
+    L.cask_hip_host_unregister.argtypes = [c_void_p]
+    _check(L.cask_hip_host_unregister(c_void_p(a.ctypes.data)))
 
 
 def trsolve(n, row_ptr, col_ind, values, rhs, lower=True) -> np.ndarray:

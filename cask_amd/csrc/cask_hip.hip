@@ -4,18 +4,21 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "blas1_kernels.hpp"
 #include "cask_hip.h"
+#include "host_copy.hpp"
 #include "cask_hip_p2p.h"
 #include "merge_launch.hpp"
 #include "plan_host.hpp"
@@ -112,6 +115,28 @@ struct SolverWorkspace {
   DevBuf<int> flags;
 };
 
+// Pinned, GPU-mapped host memory (the staging buffers of the host-vector entry point).
+struct PinBuf {
+  double *p = nullptr, *dev = nullptr;   // host address / the address the GPU uses for it
+  size_t n = 0;
+  ~PinBuf() { release(); }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = dev = nullptr;
+    n = 0;
+  }
+  hipError_t ensure(size_t count) {
+    if (p && n == count) return hipSuccess;
+    release();
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(double), hipHostMallocMapped);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p, 0);
+    if (e != hipSuccess) { release(); return e; }
+    n = count;
+    return hipSuccess;
+  }
+};
+
 }  // namespace
 
 struct cask_hip_matrix {
@@ -133,6 +158,7 @@ struct cask_hip_matrix {
   int64_t halo_shift = 0;          // bytes added to every halo address (set per launch by the sharded solvers)
   hipStream_t stream = nullptr;    // for the host-vector entry points and timing
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
+  PinBuf pin_x, pin_y;             // ... and its pinned host side (the staged entry: host_entry below)
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
   bool has_fingerprint = false;    // content fingerprint of the device CSR (internal.hpp csr_fp_*), computed on first need
@@ -1233,19 +1259,228 @@ int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint6
   return rc;
 }
 
+// ---- the host-vector entry point (row a6: the function the reference's clients call) ---------------------------------
+// ABI <= 6: hipMemcpyAsync from the caller's pageable x, launch, hipMemcpyAsync into the caller's pageable y,
+// synchronise -- 77-83 us per call on the cant-like matrix for 1 MB of vectors and an 8.5 us product (the runtime stages
+// pageable copies through its own pinned buffers with one thread).  Round 2 tried "memcpy into pinned buffers + two DMAs"
+// and measured 83: the two single-threaded host copies ARE the cost.  Now (include/cask_hip.h above cask_hip_spmv):
+//   staged      host copies by a few threads (host_copy.hpp), a copy kernel that pulls x from the pinned buffer (no SDMA
+//               start-up), y written by the product straight into pinned host memory;
+//   registered  vectors inside a range the caller registered: no host copy, the same two kernels on the caller's memory.
+}  // extern "C"
+namespace {
+
+__global__ void k_pull_f64(int64_t n, const double *__restrict__ src, double *__restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+std::atomic<int> g_host_entry_mode{-1};                       // -1: not decided yet (environment on first use)
+
+int host_entry_mode() {
+  int mode = g_host_entry_mode.load(std::memory_order_relaxed);
+  if (mode >= 0) return mode;
+  mode = CASK_HIP_HOST_ENTRY_AUTO;
+  if (const char *e = std::getenv("CASK_HIP_HOST_ENTRY")) {
+    const std::string v(e);
+    if (v == "pageable") mode = CASK_HIP_HOST_ENTRY_PAGEABLE;
+    else if (v == "staged") mode = CASK_HIP_HOST_ENTRY_STAGED;
+    else if (v == "register_cache") mode = CASK_HIP_HOST_ENTRY_REGISTER_CACHE;
+    else if (v != "auto" && !v.empty())
+      std::fprintf(stderr, "cask_hip: CASK_HIP_HOST_ENTRY=%s is not a mode (auto | pageable | staged | register_cache): auto\n", e);
+  }
+  g_host_entry_mode.store(mode, std::memory_order_relaxed);
+  return mode;
+}
+
+HostCopyPool &copy_pool() {
+  static HostCopyPool pool([] {
+    int helpers = 3;
+    if (const char *e = std::getenv("CASK_HIP_HOST_THREADS")) helpers = std::max(0, std::min(15, std::atoi(e) - 1));
+    const int cores = (int)std::thread::hardware_concurrency();
+    return std::max(0, std::min(helpers, cores - 1));
+  }());
+  return pool;
+}
+
+// Host ranges the GPU may access in place: the caller's (cask_hip_host_register: reference-counted) and, in
+// register_cache mode, the engine's own (keyed by pointer + length, at most REG_CACHE ranges, least recently used out).
+struct HostRange {
+  const char *base;
+  size_t bytes;
+  char *dev;
+  int refs;                                                   // > 0: the caller's; 0: a cache entry
+  uint64_t used;
+};
+constexpr size_t REG_CACHE = 16;
+std::mutex g_reg_mu;
+std::vector<HostRange> g_ranges;
+uint64_t g_reg_clock = 0;
+
+// (Nothing is unregistered at process exit: the runtime may be gone by the time static destructors run, and the
+// caller's memory certainly may be.)
+
+// the GPU's address for [p, p + bytes) if it lies inside a registered range (NULL if not).  callers_only: ranges the
+// CALLER declared (cask_hip_host_register) -- a cache entry is only ever trusted in register_cache mode.
+char *registered_device_pointer(const void *p, size_t bytes, bool callers_only) {
+  const char *c = static_cast<const char *>(p);
+  for (HostRange &r : g_ranges)
+    if ((!callers_only || r.refs > 0) && c >= r.base && c + bytes <= r.base + r.bytes) {
+      r.used = ++g_reg_clock;
+      return r.dev + (c - r.base);
+    }
+  return nullptr;
+}
+
+int register_range(const void *ptr, size_t bytes, int refs) {
+  char *dev = nullptr;
+  hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterMapped);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CASK_HIP_ERR_RUNTIME, std::string("hipHostRegister: ") + hipGetErrorString(e));
+  }
+  e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), const_cast<void *>(ptr), 0);
+  if (e != hipSuccess) {
+    (void)hipHostUnregister(const_cast<void *>(ptr));
+    return fail(CASK_HIP_ERR_RUNTIME, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+  }
+  g_ranges.push_back(HostRange{static_cast<const char *>(ptr), bytes, dev, refs, ++g_reg_clock});
+  return CASK_HIP_OK;
+}
+
+// register_cache mode: the GPU's address for this vector, registering it (and evicting the least recently used cache
+// entry) if need be; NULL if the registration failed (the call then takes the staged path)
+char *cached_device_pointer(const void *p, size_t bytes) {
+  if (char *d = registered_device_pointer(p, bytes, false)) return d;
+  size_t n_cache = 0, lru = g_ranges.size();
+  for (size_t i = 0; i < g_ranges.size(); i++)
+    if (g_ranges[i].refs == 0) {
+      n_cache++;
+      if (lru == g_ranges.size() || g_ranges[i].used < g_ranges[lru].used) lru = i;
+    }
+  // a range that overlaps a cache entry without lying inside it (the same buffer seen with another length): drop the old one
+  const char *c = static_cast<const char *>(p);
+  for (size_t i = 0; i < g_ranges.size();)
+    if (g_ranges[i].refs == 0 && c < g_ranges[i].base + g_ranges[i].bytes && g_ranges[i].base < c + bytes) {
+      (void)hipHostUnregister(const_cast<char *>(g_ranges[i].base));
+      g_ranges.erase(g_ranges.begin() + (long)i);
+      n_cache--;
+      lru = g_ranges.size();
+      for (size_t k = 0; k < g_ranges.size(); k++)
+        if (g_ranges[k].refs == 0 && (lru == g_ranges.size() || g_ranges[k].used < g_ranges[lru].used)) lru = k;
+    } else {
+      i++;
+    }
+  if (n_cache >= REG_CACHE && lru < g_ranges.size()) {
+    (void)hipHostUnregister(const_cast<char *>(g_ranges[lru].base));
+    g_ranges.erase(g_ranges.begin() + (long)lru);
+  }
+  if (register_range(p, bytes, 0) != CASK_HIP_OK) return nullptr;
+  return g_ranges.back().dev;
+}
+
+}  // namespace
+extern "C" {
+
+int cask_hip_host_entry_mode(int mode) {
+  const int prev = host_entry_mode();
+  if (mode < CASK_HIP_HOST_ENTRY_AUTO || mode > CASK_HIP_HOST_ENTRY_REGISTER_CACHE) return prev;
+  if (prev == CASK_HIP_HOST_ENTRY_REGISTER_CACHE && mode != prev) {
+    // leaving the cache mode: its entries go (unregistered while the caller's vectors are, by that mode's contract,
+    // still mapped) -- no other mode may ever meet a range the caller did not declare itself
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_ranges.size();)
+      if (g_ranges[i].refs == 0) {
+        (void)hipHostUnregister(const_cast<char *>(g_ranges[i].base));
+        g_ranges.erase(g_ranges.begin() + (long)i);
+      } else {
+        i++;
+      }
+  }
+  g_host_entry_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
+int cask_hip_host_register(const void *ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(CASK_HIP_ERR_INVALID, "cask_hip_host_register: empty range");
+  int rc = ensure_device();
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (HostRange &r : g_ranges)
+    if (r.base == ptr) {
+      if (r.bytes < bytes) return fail(CASK_HIP_ERR_INVALID, "cask_hip_host_register: this address is registered with a shorter length");
+      r.refs++;                                               // (a cache entry becomes the caller's)
+      return CASK_HIP_OK;
+    }
+  return register_range(ptr, bytes, 1);
+}
+
+int cask_hip_host_unregister(const void *ptr) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (size_t i = 0; i < g_ranges.size(); i++)
+    if (g_ranges[i].base == ptr && g_ranges[i].refs > 0) {
+      if (--g_ranges[i].refs == 0) {
+        HIP_TRY(hipHostUnregister(const_cast<void *>(ptr)));
+        g_ranges.erase(g_ranges.begin() + (long)i);
+      }
+      return CASK_HIP_OK;
+    }
+  return fail(CASK_HIP_ERR_INVALID, "cask_hip_host_unregister: not a registered range");
+}
+
 int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   if ((m->n_cols > 0 && !x) || (m->n_rows > 0 && !y)) return fail(CASK_HIP_ERR_INVALID, "NULL vector");
   HIP_TRY(hipSetDevice(m->device));
   if (m->d_x.n != (size_t)m->n_cols || !m->d_x.p) HIP_TRY(m->d_x.alloc(m->n_cols));
   if (m->d_y.n != (size_t)m->n_rows || !m->d_y.p) HIP_TRY(m->d_y.alloc(m->n_rows));
-  if (m->n_cols)
-    HIP_TRY(hipMemcpyAsync(m->d_x.p, x, (size_t)m->n_cols * sizeof(double), hipMemcpyHostToDevice, m->stream));
-  int rc = launch_spmv(*m, m->d_x.p, m->d_y.p, m->stream);
+  const size_t xb = (size_t)m->n_cols * sizeof(double), yb = (size_t)m->n_rows * sizeof(double);
+  int mode = host_entry_mode();
+  // vectors the GPU may touch in place: inside a range the caller registered, or (register_cache) any vector
+  char *x_dev = nullptr, *y_dev = nullptr;
+  if (mode != CASK_HIP_HOST_ENTRY_PAGEABLE && mode != CASK_HIP_HOST_ENTRY_STAGED) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (mode == CASK_HIP_HOST_ENTRY_REGISTER_CACHE) {
+      if (xb) x_dev = cached_device_pointer(x, xb);
+      if (yb) y_dev = cached_device_pointer(y, yb);
+    } else if (!g_ranges.empty()) {
+      if (xb) x_dev = registered_device_pointer(x, xb, true);
+      if (yb) y_dev = registered_device_pointer(y, yb, true);
+    }
+  }
+  // Measured (profiles/r06_host_entry.txt): 1 MB of vectors (cant-like) 70 us pageable, 44 staged with 4 host threads, 38
+  // in place; 25 MB (G3_circuit-like) 504 pageable -- the runtime pipelines its staging copies with the DMA, and that much
+  // is PCIe time whoever moves it -- against 636-1051 staged.  So: staged from 64 KiB to 4 MiB of vectors, pageable outside.
+  if (mode == CASK_HIP_HOST_ENTRY_AUTO || mode == CASK_HIP_HOST_ENTRY_REGISTER_CACHE)
+    mode = (xb + yb >= 64 * 1024 && xb + yb <= 4 * 1024 * 1024) ? CASK_HIP_HOST_ENTRY_STAGED : CASK_HIP_HOST_ENTRY_PAGEABLE;
+  auto pull = [&](const double *src) {                        // x over PCIe into the device operand (16-byte aligned: the kernels' need)
+    const int grid = (int)std::min<int64_t>(512, ((int64_t)m->n_cols + 255) / 256);
+    hipLaunchKernelGGL(k_pull_f64, dim3(grid), dim3(256), 0, m->stream, (int64_t)m->n_cols, src, m->d_x.p);
+  };
+  // ---- x
+  if (xb) {
+    if (x_dev) {
+      pull(reinterpret_cast<const double *>(x_dev));
+    } else if (mode == CASK_HIP_HOST_ENTRY_STAGED) {
+      HIP_TRY(m->pin_x.ensure((size_t)m->n_cols));
+      copy_pool().copy(m->pin_x.p, x, xb);
+      pull(m->pin_x.dev);
+    } else {
+      HIP_TRY(hipMemcpyAsync(m->d_x.p, x, xb, hipMemcpyHostToDevice, m->stream));
+    }
+  }
+  // ---- the product; y goes where the CPU will read it
+  double *y_target = m->d_y.p;
+  if (yb && y_dev) y_target = reinterpret_cast<double *>(y_dev);
+  else if (yb && mode == CASK_HIP_HOST_ENTRY_STAGED) {
+    HIP_TRY(m->pin_y.ensure((size_t)m->n_rows));
+    y_target = m->pin_y.dev;
+  }
+  int rc = launch_spmv(*m, m->d_x.p, y_target, m->stream);
   if (rc) return rc;
-  if (m->n_rows)
-    HIP_TRY(hipMemcpyAsync(y, m->d_y.p, (size_t)m->n_rows * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  if (yb && y_target == m->d_y.p) HIP_TRY(hipMemcpyAsync(y, m->d_y.p, yb, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  if (yb && !y_dev && y_target != m->d_y.p) copy_pool().copy(y, m->pin_y.p, yb);
   return CASK_HIP_OK;
 }
 

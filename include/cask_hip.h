@@ -18,6 +18,7 @@
 #ifndef CASK_HIP_H
 #define CASK_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -165,11 +166,35 @@ int cask_hip_csr_set_params(cask_hip_matrix *m, const cask_hip_params *params);
 int cask_hip_csr_get_params(const cask_hip_matrix *m, cask_hip_params *out);
 int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out);
 
-/* y = A x with host vectors: copies x up, runs, copies y down, synchronously.
+/* y = A x with host vectors: x up, one launch, y down, synchronously.
  * Replaces Spmv::spmv (src/runtime/Spmv.cpp:185-328): the x half of
  * dramWrite, the run function Spmv_<id>(...) and dramRead
- * (GeneratedImplSupport.hpp:31-49). x has n_cols entries, y n_rows. */
+ * (GeneratedImplSupport.hpp:31-49; the reference re-uploads the MATRIX too, every call). x has n_cols entries, y n_rows.
+ * How the vectors travel (ABI 7; CASK_HIP_HOST_ENTRY_* below, or the environment variable CASK_HIP_HOST_ENTRY =
+ * auto | pageable | staged | register_cache):
+ *   staged (the default for 64 KiB .. 4 MiB of vectors; smaller and larger ones go the pageable way, which is as fast
+ *     there): x is copied into the handle's pinned staging buffer by a few host threads
+ *     (one core moves 500 KB in 25-35 us: most of what a call used to cost), pulled over PCIe by a copy kernel in front of
+ *     the product, and the product writes y straight into pinned host memory; one synchronisation, a threaded copy out.
+ *     Safe for any pointer: the caller's memory is only ever touched by the CPU.
+ *   registered: a vector inside a range given to cask_hip_host_register is read / written by the GPU in place (no host
+ *     copy at all).  That is a CONTRACT, not a cache: the range must stay mapped until cask_hip_host_unregister -- a GPU
+ *     access to a registered range whose pages were returned to the OS is a fatal fault, and nothing can detect a free()
+ *     behind the engine's back.  CASK_HIP_HOST_ENTRY=register_cache applies it to every vector a call sees (16 ranges,
+ *     least recently used out) for processes that can promise that -- e.g. with glibc's mmap threshold raised so that
+ *     free() never unmaps.
+ *   pageable: hipMemcpyAsync from / to the caller's pageable memory (ABI <= 6). */
 int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y);
+#define CASK_HIP_HOST_ENTRY_AUTO      0
+#define CASK_HIP_HOST_ENTRY_PAGEABLE  1
+#define CASK_HIP_HOST_ENTRY_STAGED    2
+#define CASK_HIP_HOST_ENTRY_REGISTER_CACHE 3
+/* Process-wide override of the choice above (tools, tests); returns the previous mode. */
+int cask_hip_host_entry_mode(int mode);
+/* Declare [ptr, ptr + bytes) long-lived host memory the GPU may access in place (hipHostRegister): cask_hip_spmv then
+ * moves a vector that lies inside it without any host copy.  Ranges are reference-counted by their start address. */
+int cask_hip_host_register(const void *ptr, size_t bytes);
+int cask_hip_host_unregister(const void *ptr);
 
 /* y = A x with device vectors on `stream` (a hipStream_t; NULL = default
  * stream), asynchronously.  d_x must be 16-byte aligned (any hipMalloc'd vector is).  This is the device run function alone, the

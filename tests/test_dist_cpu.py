@@ -150,6 +150,32 @@ def test_solver_callbacks_carry_a_distributed_cg():
     np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
 
 
+def test_world_eight_sharded_spmv_and_distributed_cg():
+    """World 8 -- BASELINE configs[3] / [4] are "across 8 x MI355X" and a session may put at most 6 processes on its one
+    GPU (profiles/r06_world_dryrun.txt), so the 8-rank control flow runs here, over gloo: nnz-balanced (uneven) row
+    blocks of the power-law look-alike, ONE padded-stride all-gather per product, the all-reduced dots, and the sharded
+    CG driven through the solver's real callbacks to the oracle's iteration count."""
+    world = 8
+    n, rp, ci, va = synth.small("webbase-1M", factor=32)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    bounds = cdist.partition_rows_by_nnz(rp, world)
+    assert len(bounds) == world + 1 and len({bounds[g + 1] - bounds[g] for g in range(world)}) > 1
+    res = run_world(world, {"matrix": (n, rp, ci, va), "bounds": bounds, "x": x})
+    assert len(res) == world
+    assert np.array_equal(np.concatenate([r["y"] for r in res]), oracle.csr_spmv(rp, ci, va, x))
+    for r in res:
+        assert abs(r["dot"] - float(x @ x)) <= 1e-12 * float(x @ x)
+    n, rp, ci, va = synth.small("cant", factor=32)
+    x0 = np.arange(n) * 0.25 / n
+    b = oracle.csr_spmv(rp, ci, va, x0)
+    want, want_it, want_conv = oracle.cg_full(rp, ci, va, b)
+    bounds = cdist.partition_rows_by_nnz(rp, world)
+    res = run_world(world, {"matrix": (n, rp, ci, va), "bounds": bounds, "x": x0, "b": b, "cg": True})
+    assert all(r["cg_conv"] == want_conv for r in res)
+    assert all(abs(r["cg_it"] - want_it) <= 1 for r in res), ([r["cg_it"] for r in res], want_it)
+    np.testing.assert_allclose(np.concatenate([r["cg_x"] for r in res]), want, rtol=1e-7, atol=1e-9)
+
+
 def test_transpose_csr_matches_oracle():
     n, rp, ci, va = synth.small("atmosmodd", factor=64)
     trp, tci, tva = cdist.transpose_csr(n, n, rp, ci, va)

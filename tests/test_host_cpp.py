@@ -27,7 +27,8 @@ def test_host_unit_tests(plain_mtx_dir):
 def test_host_code_under_sanitizers(plain_mtx_dir, tmp_path):
     """`make asan` (SURVEY section 5 "sanitizers"; the reference has coverage flags only,
     CMakeLists.txt:3): everything that is HOST code under AddressSanitizer + UBSan (-fno-sanitize-recover) on the CPU --
-    the host surface's unit tests, the MatrixMarket ingest, the oracle's C restatement (the whole of tests/test_oracle.py
+    the host surface's unit tests, the MatrixMarket ingest, the threaded staging copy of the host-vector entry (also under
+    ThreadSanitizer), the oracle's C restatement (the whole of tests/test_oracle.py
     against the instrumented library) and the launch planners: every plan of plan_host.hpp / trsv_lanes_plan.hpp built
     for the 43 reference fixtures and the five small synthetic families, invariants checked (tests/cpp/test_planners.cpp).
     No GPU-side sanitizer is involved."""
@@ -54,6 +55,9 @@ def test_host_code_under_sanitizers(plain_mtx_dir, tmp_path):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-4000:]
     m = re.search(r"(\d+) matrices, (\d+) lane-group runs \((\d+) chunks\), (\d+) checks, 0 failures", out.stdout)
     assert m and int(m.group(1)) >= 48 and int(m.group(2)) >= 10 and int(m.group(4)) > 10_000_000, out.stdout[-500:]
+    for exe in ("test_host_copy", "test_host_copy_tsan"):      # the threaded staging copy (host_copy.hpp): ASan / UBSan, then TSan
+        out = subprocess.run([str(asan / exe)], capture_output=True, text=True, env=env)
+        assert out.returncode == 0 and re.search(r"\d+ checks, 0 failures", out.stdout), exe + out.stdout[-1000:] + out.stderr[-3000:]
     # the oracle's restatement: the CPU suite's oracle tests against the instrumented library (python itself is not
     # instrumented: the sanitizer runtimes are preloaded; CPython's own arenas make a leak check meaningless here)
     pre = ":".join(subprocess.run(["gcc", f"-print-file-name={lib}"], capture_output=True, text=True, check=True).stdout.strip()
