@@ -682,9 +682,8 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
 // (16 doubles) in dynamic LDS behind the x tile
 int dot_lds_bytes(int wg_size) { return 16 * wg_size + 128; }
 
-template <int IPT>
-int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot,
-                   const SolverPass *pass) {
+// What a merge launch needs from the handle and its plan.
+MergeLaunch merge_launch_of(const cask_hip_matrix &m, const DotEpilogue &dot, const SolverPass *pass) {
   const Plan &pl = m.plan;
   MergeLaunch l{};
   l.grid = pl.grid;
@@ -711,15 +710,26 @@ int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStre
   l.partials = pl.partials.p;
   l.halo = XHalo{m.halo_n_own, m.halo_addr, m.halo_shift};
   l.dot = dot;
-  launch_merge_blocks<IPT>(l, x, y, s);
-  if (pl.n_split_rows > 0 && !(pass && pass->final_only)) {   // (a final_only launch runs no product: nothing to fix up)
-    // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
-    // launch stored (b_new), or the plain vector the pass names (wa without wb)
-    const double *fw = pass ? (dot.dot_part ? (pass->wa && !pass->wb ? pass->wa : pass->b_new) : nullptr) : dot.w;
-    const DotEpilogue fix{fw, fw ? dot.dot_part + pl.grid : nullptr};
-    hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
-                       pl.n_split_rows, pl.partials.p, y, fix, pass ? (const int *)pass->done : (const int *)nullptr);
-  }
+  return l;
+}
+
+// the pieces of split long rows, summed in piece order behind the product launch
+void launch_merge_fixup(const cask_hip_matrix &m, double *y, hipStream_t s, const DotEpilogue &dot, const SolverPass *pass) {
+  const Plan &pl = m.plan;
+  if (pl.n_split_rows <= 0 || (pass && pass->final_only)) return;   // (a final_only launch runs no product: nothing to fix up)
+  // a solver pass's dot operand is a stored vector by the time the fix-up runs: the direction this very
+  // launch stored (b_new), or the plain vector the pass names (wa without wb)
+  const double *fw = pass ? (dot.dot_part ? (pass->wa && !pass->wb ? pass->wa : pass->b_new) : nullptr) : dot.w;
+  const DotEpilogue fix{fw, fw ? dot.dot_part + pl.grid : nullptr};
+  hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p,
+                     pl.n_split_rows, pl.partials.p, y, fix, pass ? (const int *)pass->done : (const int *)nullptr);
+}
+
+template <int IPT>
+int launch_merge_i(const cask_hip_matrix &m, const double *x, double *y, hipStream_t s, const DotEpilogue &dot,
+                   const SolverPass *pass) {
+  launch_merge_blocks<IPT>(merge_launch_of(m, dot, pass), x, y, s);
+  launch_merge_fixup(m, y, s, dot, pass);
   return CASK_HIP_OK;
 }
 
@@ -836,6 +846,28 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
   }
   HIP_TRY(hipGetLastError());
   return CASK_HIP_OK;
+}
+
+// Two INDEPENDENT products in one launch where the plans allow it (merge_kernel.hpp k_spmv_merge_dual): ya = A xa (with the
+// shares of w.ya when w is given) and yb = B xb.  Anything else -- other variants, other shapes -- is the two launches.
+int launch_spmv_pair(cask_hip_matrix &a, const double *xa, double *ya, const double *w, cask_hip_matrix &b, const double *xb,
+                     double *yb, hipStream_t s) {
+  static const bool off = std::getenv("CASK_HIP_NO_DUAL") != nullptr;     // (the A/B switch: the two-launch pass)
+  Plan &pa = a.plan, &pb = b.plan;
+  const bool merge8 = pa.prm.variant == CASK_HIP_VARIANT_MERGE && pb.prm.variant == CASK_HIP_VARIANT_MERGE &&
+                      pa.prm.items_per_thread == 8 && pb.prm.items_per_thread == 8 && pa.grid > 0 && pb.grid > 0;
+  if (!off && merge8 && (!w || plan_fuses_dot(pa))) {
+    const DotEpilogue dot{w, w ? pa.dot_part.p : nullptr}, none{nullptr, nullptr};
+    if (launch_merge_dual8(merge_launch_of(a, dot, nullptr), xa, ya, merge_launch_of(b, none, nullptr), xb, yb, s)) {
+      launch_merge_fixup(a, ya, s, dot, nullptr);
+      launch_merge_fixup(b, yb, s, none, nullptr);
+      HIP_TRY(hipGetLastError());
+      return CASK_HIP_OK;
+    }
+  }
+  int rc = launch_spmv(a, xa, ya, s, w);
+  if (rc) return rc;
+  return launch_spmv(b, xb, yb, s);
 }
 
 int check_csr(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row_ptr) {
@@ -1598,12 +1630,12 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
                   cask_hip_tune_point *results, int32_t max_results, int32_t *n_results, int32_t *best_index) {
   if (!m) return fail(CASK_HIP_ERR_INVALID, "matrix is NULL");
   static const int32_t def_variants[] = {CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE,
-                                         CASK_HIP_VARIANT_SCAN};
+                                         CASK_HIP_VARIANT_SCAN, CASK_HIP_VARIANT_SLICE};
   static const int32_t def_lanes[] = {4, 8, 16, 32};
   static const int32_t def_tiles[] = {-1, 1024, 4096};
   static const int32_t def_wg[] = {256, 512};
   static const int32_t def_items[] = {4, 8};
-  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 4; }
+  if (!variants || n_variants <= 0) { variants = def_variants; n_variants = 5; }
   if (!lanes || n_lanes <= 0) { lanes = def_lanes; n_lanes = 4; }
   if (!tiles || n_tiles <= 0) { tiles = def_tiles; n_tiles = 3; }
   if (!wg_sizes || n_wg_sizes <= 0) { wg_sizes = def_wg; n_wg_sizes = 2; }
@@ -1687,18 +1719,21 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
         for (int il = 0; il < n_lanes; il++)
           for (int iva = 0; iva < n_variants; iva++) {
             const int variant = variants[iva];
-            // SCAN: items per thread like the merge kernels; its tile axis is the near margin of the far pre-gather
+            // SCAN: items per thread like the merge kernels, its tile axis is its LDS x window; SLICE (r6): the lanes axis
+            // carries K (1..8: the longest row a slice thread takes), items / tile / workgroup those of its SCAN blocks
+            const bool slice = variant == CASK_HIP_VARIANT_SLICE;
             const bool is_merge = variant == CASK_HIP_VARIANT_MERGE || variant == CASK_HIP_VARIANT_MERGE_WAVE ||
-                                  variant == CASK_HIP_VARIANT_SCAN;
+                                  variant == CASK_HIP_VARIANT_SCAN || slice;
             // a block with halo sources runs the MERGE variant only: a winner from another family could not be applied
             if (saved_halo && variant != CASK_HIP_VARIANT_MERGE) continue;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
-            if (is_merge && il != 0) continue;
+            if (is_merge && !slice && il != 0) continue;
+            if (slice && (lanes[il] < 1 || lanes[il] > SLICE_KMAX || (items[iv] != 4 && items[iv] != 8))) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel
             Cand c{};
             c.pt.params = saved;
             c.pt.params.variant = variant;
-            c.pt.params.lanes_per_row = variant == CASK_HIP_VARIANT_VECTOR ? lanes[il] : 0;
+            c.pt.params.lanes_per_row = (variant == CASK_HIP_VARIANT_VECTOR || slice) ? lanes[il] : 0;
             c.pt.params.items_per_thread = is_merge ? items[iv] : 0;
             c.pt.params.tile_width = tiles[it];
             c.pt.params.wg_size = wg_sizes[iw];
@@ -1712,7 +1747,7 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             if (variant == CASK_HIP_VARIANT_VECTOR)
               c.prior = 4.0 * std::fabs(l2(lanes[il]) - l2(std::min(mean_row, 64.0) / 2.0)) + d_wg + d_tile;
             else
-              c.prior = 2.0 * std::fabs(l2(items[iv]) - l2(8)) + d_wg + d_tile;
+              c.prior = 2.0 * std::fabs(l2(items[iv]) - l2(8)) + d_wg + d_tile + (slice ? std::fabs(l2(lanes[il]) - l2(2)) : 0.0);
             cands.push_back(c);
           }
   count = (int)cands.size();
@@ -2122,10 +2157,23 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       // classic: q = A p with the shares of p.q (pt.q) from the same launch when the plan has the epilogue
       const bool fused = plan_fuses_dot(m->plan);
       const double *w = bicg ? slot(SLOT_PT0) : slot(SLOT_P0);
-      rc = product(m, SLOT_P0, q.p, fused ? w : nullptr, x_full);
-      if (rc) return rc;
       if (bicg) {
-        rc = product(st.At, SLOT_PT0, qt.p, nullptr, x_full_t);
+        // q = A p and qt = A^T pt are independent: ONE launch where the two plans share the kernel shape (r6)
+        const double *op_a = slot(SLOT_P0), *op_b = slot(SLOT_PT0);
+        if (st.exchange) {
+          if (st.exchange(slot(SLOT_P0), x_full.p, s, st.exchange_user) != 0 || st.exchange(slot(SLOT_PT0), x_full_t.p, s, st.exchange_user) != 0)
+            return fail(CASK_HIP_ERR_RUNTIME, "the operand-exchange callback of the sharded solver failed");
+          op_a = x_full.p;
+          op_b = x_full_t.p;
+        }
+        m->halo_shift = (int64_t)SLOT_P0 * st.S * 8;
+        st.At->halo_shift = (int64_t)SLOT_PT0 * st.S * 8;
+        rc = launch_spmv_pair(*m, op_a, q.p, fused ? w : nullptr, *st.At, op_b, qt.p, s);
+        m->halo_shift = 0;
+        st.At->halo_shift = 0;
+        if (rc) return rc;
+      } else {
+        rc = product(m, SLOT_P0, q.p, fused ? w : nullptr, x_full);
         if (rc) return rc;
       }
       if (fused) {

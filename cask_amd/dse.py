@@ -30,7 +30,7 @@ INFINITY_CACHE_BYTES = 256 << 20
 
 # default ranges (the analogue of src/frontend/params.json)
 DEFAULT_RANGES = {
-    "variant": ["vector", "merge", "merge_wave", "scan"],
+    "variant": ["vector", "merge", "merge_wave", "scan", "slice"],
     "lanes_per_row": [4, 8, 16, 32],
     "tile_width": [-1, 1024, 4096],
     "wg_size": [256, 512],
@@ -54,6 +54,10 @@ def design_points(ranges=None):
                             dp = dict(variant=var, lanes_per_row=lanes, tile_width=tile, wg_size=wg)
                         elif var in ("merge", "scan"):         # scan: tile_width = its LDS x window
                             dp = dict(variant=var, items_per_thread=ipt, tile_width=tile, wg_size=wg)
+                        elif var == "slice":                   # lanes_per_row carries K (1..8); items of its SCAN blocks: 4 / 8
+                            if not (1 <= lanes <= 8 and ipt in (4, 8)):
+                                continue
+                            dp = dict(variant=var, lanes_per_row=lanes, items_per_thread=ipt, tile_width=tile, wg_size=wg)
                         else:
                             dp = dict(variant=var, items_per_thread=ipt, wg_size=wg)
                         key = tuple(sorted(dp.items()))
@@ -96,9 +100,9 @@ def ranges_of(points):
     """The ranges a list of design points spans (the C odometer takes ranges, not points)."""
     def vals(key, fam=None):
         return sorted({p[key] for p in points if key in p and (fam is None or p["variant"] in fam)})
-    return {"variant": [v for v in ("vector", "merge", "merge_wave", "scan") if any(p["variant"] == v for p in points)],
-            "lanes_per_row": vals("lanes_per_row", ("vector",)), "tile_width": vals("tile_width"),
-            "wg_size": vals("wg_size"), "items_per_thread": vals("items_per_thread", ("merge", "merge_wave", "scan"))}
+    return {"variant": [v for v in ("vector", "merge", "merge_wave", "scan", "slice") if any(p["variant"] == v for p in points)],
+            "lanes_per_row": vals("lanes_per_row", ("vector", "slice")), "tile_width": vals("tile_width"),
+            "wg_size": vals("wg_size"), "items_per_thread": vals("items_per_thread", ("merge", "merge_wave", "scan", "slice"))}
 
 
 def explore(mats, x_t=None, y_t=None, points=None, steps=0, reps=3):

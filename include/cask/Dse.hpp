@@ -63,7 +63,8 @@ class DseParameters {
   cask::utils::Parameter<> numControllers{"numControllers", 1, 1, 1};
   std::vector<int> wgSize{256, 512};
   std::vector<int> itemsPerThread{4, 8};
-  std::vector<int> variants{CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE, CASK_HIP_VARIANT_SCAN};
+  std::vector<int> variants{CASK_HIP_VARIANT_VECTOR, CASK_HIP_VARIANT_MERGE, CASK_HIP_VARIANT_MERGE_WAVE, CASK_HIP_VARIANT_SCAN,
+                            CASK_HIP_VARIANT_SLICE};
   bool alsoWithoutTile = true;       // add tile_width = -1 (x from L2) to the cacheSize range
   int warmup = 3, iterations = 20;
 };

@@ -150,10 +150,10 @@ def test_env_override_selects_the_variant(plain_mtx_dir):
     make("clients")
     exe = REPO / "build" / "test_spmv_hip"
     mtx = str(plain_mtx_dir / "matrices" / "test_cage6.mtx")
-    out = subprocess.run([str(exe), "--variants", "vector,merge,merge_wave,scan,auto,!fpga", mtx], capture_output=True, text=True,
+    out = subprocess.run([str(exe), "--variants", "vector,merge,merge_wave,scan,slice,auto,!fpga", mtx], capture_output=True, text=True,
                          timeout=300)
-    assert out.returncode == 0 and "6 of 6 variants behaved" in out.stdout, (out.stdout[-900:], out.stderr[-300:])
-    assert out.stdout.count("Test passed!") == 5 and "Variant fpga rejected as it must be" in out.stdout
+    assert out.returncode == 0 and "7 of 7 variants behaved" in out.stdout, (out.stdout[-900:], out.stderr[-300:])
+    assert out.stdout.count("Test passed!") == 6 and "Variant fpga rejected as it must be" in out.stdout
     bad = subprocess.run([str(exe), mtx], capture_output=True, text=True, env=dict(os.environ, CASK_HIP_VARIANT="fpga"), timeout=300)
     assert bad.returncode != 0
 
