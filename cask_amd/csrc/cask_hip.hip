@@ -848,28 +848,6 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
   return CASK_HIP_OK;
 }
 
-// Two INDEPENDENT products in one launch where the plans allow it (merge_kernel.hpp k_spmv_merge_dual): ya = A xa (with the
-// shares of w.ya when w is given) and yb = B xb.  Anything else -- other variants, other shapes -- is the two launches.
-int launch_spmv_pair(cask_hip_matrix &a, const double *xa, double *ya, const double *w, cask_hip_matrix &b, const double *xb,
-                     double *yb, hipStream_t s) {
-  static const bool off = std::getenv("CASK_HIP_NO_DUAL") != nullptr;     // (the A/B switch: the two-launch pass)
-  Plan &pa = a.plan, &pb = b.plan;
-  const bool merge8 = pa.prm.variant == CASK_HIP_VARIANT_MERGE && pb.prm.variant == CASK_HIP_VARIANT_MERGE &&
-                      pa.prm.items_per_thread == 8 && pb.prm.items_per_thread == 8 && pa.grid > 0 && pb.grid > 0;
-  if (!off && merge8 && (!w || plan_fuses_dot(pa))) {
-    const DotEpilogue dot{w, w ? pa.dot_part.p : nullptr}, none{nullptr, nullptr};
-    if (launch_merge_dual8(merge_launch_of(a, dot, nullptr), xa, ya, merge_launch_of(b, none, nullptr), xb, yb, s)) {
-      launch_merge_fixup(a, ya, s, dot, nullptr);
-      launch_merge_fixup(b, yb, s, none, nullptr);
-      HIP_TRY(hipGetLastError());
-      return CASK_HIP_OK;
-    }
-  }
-  int rc = launch_spmv(a, xa, ya, s, w);
-  if (rc) return rc;
-  return launch_spmv(b, xb, yb, s);
-}
-
 int check_csr(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row_ptr) {
   if (n_rows < 0 || n_cols < 0 || nnz < 0) return fail(CASK_HIP_ERR_INVALID, "negative dimension");
   if (nnz >= (int64_t)std::numeric_limits<int32_t>::max())
@@ -2157,23 +2135,12 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       // classic: q = A p with the shares of p.q (pt.q) from the same launch when the plan has the epilogue
       const bool fused = plan_fuses_dot(m->plan);
       const double *w = bicg ? slot(SLOT_PT0) : slot(SLOT_P0);
+      rc = product(m, SLOT_P0, q.p, fused ? w : nullptr, x_full);
+      if (rc) return rc;
       if (bicg) {
-        // q = A p and qt = A^T pt are independent: ONE launch where the two plans share the kernel shape (r6)
-        const double *op_a = slot(SLOT_P0), *op_b = slot(SLOT_PT0);
-        if (st.exchange) {
-          if (st.exchange(slot(SLOT_P0), x_full.p, s, st.exchange_user) != 0 || st.exchange(slot(SLOT_PT0), x_full_t.p, s, st.exchange_user) != 0)
-            return fail(CASK_HIP_ERR_RUNTIME, "the operand-exchange callback of the sharded solver failed");
-          op_a = x_full.p;
-          op_b = x_full_t.p;
-        }
-        m->halo_shift = (int64_t)SLOT_P0 * st.S * 8;
-        st.At->halo_shift = (int64_t)SLOT_PT0 * st.S * 8;
-        rc = launch_spmv_pair(*m, op_a, q.p, fused ? w : nullptr, *st.At, op_b, qt.p, s);
-        m->halo_shift = 0;
-        st.At->halo_shift = 0;
-        if (rc) return rc;
-      } else {
-        rc = product(m, SLOT_P0, q.p, fused ? w : nullptr, x_full);
+        // (q = A p and qt = A^T pt are independent; as ONE launch -- r6, k_spmv_merge_dual -- the pass measured 72.67
+        // against 72.84 us: nothing, profiles/r06_bicg_dual.txt; on a second stream it lost, docs/experiments.md)
+        rc = product(st.At, SLOT_PT0, qt.p, nullptr, x_full_t);
         if (rc) return rc;
       }
       if (fused) {

@@ -568,8 +568,9 @@ __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int 
 // Measured (profiles/r05_merge_forms.txt): G3_circuit-like 21.5 -> 20.6 us, atmosmodd-like 21.2 -> 19.6; on the
 // 1 024-entry window of the cant-like plan (6 -> 8 workgroups per CU) it is 1 % SLOWER, which is why narrower windows
 // keep their own LDS.
-// One workgroup of a merge launch: hardware block `hw_block` of a grid of `n_blocks`.  k_spmv_merge calls it with its
-// own block index; k_spmv_merge_dual (below) with the index inside whichever of its two plans the workgroup belongs to.
+// One workgroup of a merge launch: hardware block `hw_block` of a grid of `n_blocks`.  (Factored out of k_spmv_merge in
+// round 6 for a launch that carried the workgroups of TWO plans -- the A and A^T products of a BiCG pass: bit-identical,
+// -0.2 %, removed, profiles/r06_bicg_dual.txt; the EXT = 0 kernels compile to the same instructions as before.)
 template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT>
 __device__ __forceinline__ void merge_workgroup(int hw_block, const BlockDesc *__restrict__ blocks, int n_blocks, int remap,
                                                 int n_cols, int nnz, const int *__restrict__ rp, const int *__restrict__ ci,
@@ -706,33 +707,6 @@ __global__ void k_spmv_merge(const BlockDesc *__restrict__ blocks, int n_blocks,
                              PassArg<EXT> pass_arg) {
   merge_workgroup<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT>(blockIdx.x, blocks, n_blocks, remap, n_cols, nnz, rp, ci, ci16, xchunk,
                                                           maxch, val, x, y, partials, halo, dot, pass_arg);
-}
-
-// Two INDEPENDENT products in one launch (r6): a BiCG pass multiplies by A and by A^T (q = A p, qt = A^T pt,
-// SparseLinearSolvers.hpp:55-61) -- two plans of the same design point, nothing in common but the launch.  As two
-// launches each pays its own head (descriptor trip, ramp) and tail (the last workgroups' row sums with an emptying chip);
-// as ONE grid of n_a + n_b workgroups -- the block index picks the plan, scalar-uniform -- the first product's tail runs
-// under the second one's stream (tools/overlap_probe.py measured 20.5 -> 18.9 us per product for two overlapping chains on
-// the G3_circuit-like matrix).  Every workgroup does exactly what it does in the two-launch pass: the same bits.
-struct MergeOperand {                                         // the per-plan arguments of k_spmv_merge
-  const BlockDesc *blocks;
-  int n_blocks, n_cols, nnz, maxch;
-  const int *rp, *ci;
-  const unsigned *ci16;
-  const int *xchunk;
-  const double *val, *x;
-  double *y, *partials;
-  XHalo halo;
-  DotEpilogue dot;
-};
-template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW>
-__global__ void k_spmv_merge_dual(MergeOperand a, MergeOperand b, int remap) {
-  // ONE copy of the workgroup code: the operand set is picked first (scalar selects of kernel arguments)
-  const bool first = (int)blockIdx.x < a.n_blocks;            // scalar
-  const MergeOperand &p = first ? a : b;
-  merge_workgroup<IPT, XU, NT, C16, C12, WIDE, SKEW, 1>(first ? (int)blockIdx.x : (int)blockIdx.x - a.n_blocks, p.blocks, p.n_blocks,
-                                                        remap, p.n_cols, p.nnz, p.rp, p.ci, p.ci16, p.xchunk, p.maxch, p.val, p.x, p.y,
-                                                        p.partials, p.halo, p.dot, PassArg<1>{});
 }
 
 }  // namespace caskhip

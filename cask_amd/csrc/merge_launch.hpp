@@ -31,12 +31,6 @@ struct MergeLaunch {
 template <int IPT>
 void launch_merge_blocks(const MergeLaunch &l, const double *x, double *y, hipStream_t s);
 
-// Two independent products of one design point in ONE launch (k_spmv_merge_dual: the A and A^T products of a BiCG pass).
-// Exists for the shape the solvers run -- 8 items per thread, 12-bit packed slots, streaming loads, no skewed blocks --
-// and returns false (nothing launched) for any other pair: the caller then launches the two one after the other.
-bool launch_merge_dual8(const MergeLaunch &a, const double *xa, double *ya, const MergeLaunch &b, const double *xb, double *yb,
-                        hipStream_t s);
-
 extern template void launch_merge_blocks<2>(const MergeLaunch &, const double *, double *, hipStream_t);
 extern template void launch_merge_blocks<4>(const MergeLaunch &, const double *, double *, hipStream_t);
 extern template void launch_merge_blocks<8>(const MergeLaunch &, const double *, double *, hipStream_t);

@@ -164,5 +164,14 @@ def write_dse_out(path, entries, took):
             "matrices": [e["matrix"]],
             "points_evaluated": e["points"],
         })
+        # the runner-up of the winner's family when it is within 1 %: run to run either may come out on top, so the
+        # counter evidence (tools/dse_evidence.py) is collected for both (r6: a run that timed the runner-up found no file)
+        keys = ("variant", "lanes_per_row", "tile_width", "wg_size", "items_per_thread", "xcd_remap", "nontemporal", "index16", "far_columns")
+        close = [r for r in e.get("rows", []) if r.get("valid") and r["variant"] == b["variant"] and r["usec"] <= 1.01 * b["usec"]
+                 and any(r[k] != b[k] for k in keys)]
+        if close:
+            ru = min(close, key=lambda r: r["usec"])
+            doc["best_architectures"][-1]["runner_up_within_1pct"] = {"measured_usec": ru["usec"],
+                                                                       "architecture_params": {k: ru[k] for k in keys}}
     Path(path).write_text(json.dumps(doc, indent=2))
     return doc

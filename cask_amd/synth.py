@@ -47,10 +47,13 @@ def _disk_cached(fn):
         if root == "0":
             return fn(*args, **kwargs)
         key = hashlib.sha1((fn.__name__ + repr(args) + repr(sorted(kwargs.items())) + _SOURCE_HASH).encode()).hexdigest()[:20]
-        d = Path(root or os.path.join(tempfile.gettempdir(), "cask_synth_cache"))
+        # per user, mode 0700 (r6, ADVICE r5: a shared, predictable <tmp>/cask_synth_cache let another user of the box plant a
+        # matrix under the right key)
+        d = Path(root or os.path.join(tempfile.gettempdir(), f"cask_synth_cache_{os.getuid()}"))
         stem = d / f"{fn.__name__}_{key}"
         try:
-            if (d / f"{stem.name}.done").exists():
+            private = bool(root) or (d.exists() and d.stat().st_uid == os.getuid() and not (d.stat().st_mode & 0o077))
+            if private and (d / f"{stem.name}.done").exists():
                 n = int(np.load(f"{stem}_n.npy"))
                 return n, np.load(f"{stem}_rp.npy"), np.load(f"{stem}_ci.npy"), np.load(f"{stem}_va.npy")
         except Exception:  # noqa: BLE001 - a damaged cache entry: regenerate
@@ -58,7 +61,9 @@ def _disk_cached(fn):
         n, rp, ci, va = fn(*args, **kwargs)
         if ci.size >= 200_000:
             try:
-                d.mkdir(parents=True, exist_ok=True)
+                d.mkdir(parents=True, exist_ok=True, mode=0o700)
+                if not root and (d.stat().st_uid != os.getuid() or (d.stat().st_mode & 0o077)):
+                    raise OSError("cache directory is not private to this user")
                 for tag, arr in (("n", np.asarray(n)), ("rp", rp), ("ci", ci), ("va", va)):
                     tmp = f"{stem}_{tag}.{os.getpid()}.tmp.npy"
                     np.save(tmp, arr)

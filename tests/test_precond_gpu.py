@@ -246,7 +246,7 @@ def test_packed_walk_random_dependency_graphs(seed):
                                what="random upper")
 
 
-def test_triangular_solve_schedules_agree_bit_for_bit():
+def test_triangular_solve_schedules_agree_bit_for_bit(tmp_path):
     """Schedules of the same triangular solve (cask_hip_precond.hip): walker + stagers in position space (walk2), the
     four-wave packed walk of narrow-level runs (packed, r2) and the row-indexed walk of round 1
     (CASK_HIP_TRSV=levels).  (The one-walker-wave kernel and the one-launch synchronisation-free solve, measured losses,
@@ -322,11 +322,12 @@ for mode in sys.argv[2:]:
     # packed = the four-wave walk (r2); walk2 = r3; lanes = the lane-group walk for every run of levels that qualifies (r5);
     # default = lanes where the rows are long (the FEM-like factor), walk2 elsewhere
     modes = ("levels", "packed", "walk2", "lanes", "lanes4", "lanes16", "default")
-    res = subprocess.run([sys.executable, "-c", code, "/tmp/cask_trsv_", *modes], capture_output=True, text=True, timeout=600,
+    stem = str(tmp_path / "cask_trsv_")                              # (r6, ADVICE r5: fixed /tmp names collided across concurrent suites)
+    res = subprocess.run([sys.executable, "-c", code, stem, *modes], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, CASK_HIP_TRSV_STATS="1"), cwd=str(REPO))
     assert res.returncode == 0, res.stderr[-1500:]
     assert all(int(line) > 500 for line in res.stdout.strip().splitlines()[-len(modes):])
-    outs = {("" if m == "default" else m): np.load(f"/tmp/cask_trsv_{m}.npy") for m in modes}
+    outs = {("" if m == "default" else m): np.load(f"{stem}{m}.npy") for m in modes}
     stderr = {}
     for part in res.stderr.split("MODE ")[1:]:
         name, _, text = part.partition("\n")

@@ -218,43 +218,3 @@ def test_solvers_on_scan_plans():
             assert conv == want_conv and abs(it - want_it) <= 2, (name, dp, it, want_it)
             np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
 
-
-def test_bicg_dual_launch_gives_the_two_launch_pass_bit_for_bit(tmp_path):
-    """r6: q = A p and qt = A^T pt of a classic BiCG pass are ONE launch (k_spmv_merge_dual: the block
-    index picks the plan) when the two plans share the kernel shape.  Every workgroup does what it does in the two-launch
-    pass (CASK_HIP_NO_DUAL=1), so iterates, iteration count and solution are the same bits; 56 iterations = the
-    oracle's on the atmosmodd-like system; a matrix whose A and A^T plans differ in shape takes the two launches."""
-    import subprocess
-    import sys
-    from conftest import REPO
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, ".")
-from cask_amd import capi, synth
-out = []
-for name, kw in (("atmosmodd", {}), ("atmosmodd_small", {}), ("webbase-1M_small", {}), ("cant_small", dict(tile_width=-1))):
-    if name.endswith("_small"):
-        n, rp, ci, va = synth.small(name[:-6])
-    else:
-        n, rp, ci, va = synth.GENERATORS[name]()
-    if name.startswith("webbase"):
-        va = va.copy(); va[rp[:-1]] += 40.0                      # (first entry of every row: keeps BiCG from breaking down)
-    b = np.ones(n)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(variant="merge", **kw))
-    x, it, conv, _ = m.bicg(b, maxiters=80, tol=1e-6)
-    out += [x, np.array([it, conv], dtype=np.float64)]
-    m.close()
-np.save(sys.argv[1], np.concatenate(out))
-'''
-    res = {}
-    for arm, env in (("dual", {}), ("two", {"CASK_HIP_NO_DUAL": "1"})):
-        path = tmp_path / f"{arm}.npy"
-        r = subprocess.run([sys.executable, "-c", code, str(path)], capture_output=True, text=True, timeout=600, cwd=str(REPO),
-                           env=dict(__import__("os").environ, **env))
-        assert r.returncode == 0, r.stderr[-1500:]
-        res[arm] = np.load(path)
-    assert np.array_equal(res["dual"], res["two"])
-    n, rp, ci, va = synth.GENERATORS["atmosmodd"]()
-    want, want_it, want_conv = oracle.bicg(rp, ci, va, np.ones(n), maxiters=80, tol=1e-6)
-    assert int(res["dual"][n]) == want_it and bool(res["dual"][n + 1]) == want_conv
-    np.testing.assert_allclose(res["dual"][:n], want, rtol=1e-7, atol=1e-9)

@@ -8,6 +8,7 @@ against the chip's peak"; the reference's writer: src/main.cpp:81-117).  Run on 
 2. tools/pmc_point.sh at THAT design point: three separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, read requests
    by size) of bench.py forced to the winner, FETCH_SIZE corrected by the factor measured on the calibration kernel in
    the same session (tools/traffic_summary.py);
+   -- and, r6, at the runner-up of the winner's family when it is within 1 % (a later run may time that one);
 3. the winner's entry gains hbm_bytes_per_launch_measured, hbm_gbs_measured, pct_hbm_peak_measured (bytes the counters
    saw / the winner's cold launch time) next to measured_gbs_algorithmic."""
 import json
@@ -20,11 +21,10 @@ tag, out = sys.argv[1], Path(sys.argv[2])
 mats = sys.argv[3:]
 subprocess.run([sys.executable, str(REPO / "tools" / "dse.py"), "--out", str(out)] + mats, check=True)
 doc = json.loads(out.read_text())
-for arch in doc["best_architectures"]:
-    w = arch["matrices"][0]
-    p = arch["architecture_params"]
+def profile_point(w, p):
+    """Three PMC passes of bench.py forced to design point p of workload w -> (label, traffic record or None)."""
     label = f'{p["variant"]}_w{p["wg_size"]}_i{p["items_per_thread"]}_t{p["tile_width"]}_l{p["lanes_per_row"]}'.replace("-", "m")
-    flags = ["--variant", p["variant"], "--wg", str(p["wg_size"]), "--tile", str(p["tile_width"]), "--far", str(p["far_columns"])]
+    flags = ["--variant", p["variant"], "--wg", str(p["wg_size"]), "--tile", str(p["tile_width"])]
     if p["items_per_thread"] > 0:
         flags += ["--items", str(p["items_per_thread"])]
     if p["lanes_per_row"] > 0:
@@ -32,10 +32,21 @@ for arch in doc["best_architectures"]:
     subprocess.run(["bash", str(REPO / "tools" / "pmc_point.sh"), tag, w, label] + flags, check=False,
                    stdout=subprocess.DEVNULL)
     tf = REPO / "gpurun_out" / f"traffic_{w}_{label}_{tag}.json"
-    if not tf.exists():
+    return label, (json.loads(tf.read_text()) if tf.exists() else None)
+
+
+for arch in doc["best_architectures"]:
+    w = arch["matrices"][0]
+    label, t = profile_point(w, arch["architecture_params"])
+    ru = arch.get("runner_up_within_1pct")
+    if ru:                                                       # within 1 % of the winner: a later run may time this one
+        ru_label, ru_t = profile_point(w, ru["architecture_params"])
+        ru["design_point_label"] = ru_label
+        ru["traffic_file"] = f"profiles/traffic_{w}_{ru_label}.json" if ru_t else None
+        ru["hbm_bytes_per_launch_measured"] = ru_t.get("hbm_bytes_per_launch") if ru_t else None
+    if t is None:
         arch["hbm_bytes_per_launch_measured"] = None
         continue
-    t = json.loads(tf.read_text())
     b = t.get("hbm_bytes_per_launch")
     arch["design_point_label"] = label
     arch["traffic_file"] = f"profiles/traffic_{w}_{label}.json"
