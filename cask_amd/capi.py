@@ -43,7 +43,7 @@ class SolverConfig(Structure):
     _fields_ = [("kind", c_int32), ("mode", c_int32), ("d_shared_base", c_void_p), ("stride", c_int64),
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", c_void_p), ("exchange", EXCHANGE_FN),
                 ("exchange_user", c_void_p), ("n_full", c_int64)]
-PRECOND_JACOBI, PRECOND_ILU0, PRECOND_ILU0_UNIT, PRECOND_ILU0_MC = 1, 2, 3, 4
+PRECOND_JACOBI, PRECOND_ILU0, PRECOND_ILU0_UNIT = 1, 2, 3          # (4, the multicolour ILU(0), was removed in ABI 7)
 
 
 class Params(Structure):
@@ -470,8 +470,7 @@ class Preconditioner:
     """Jacobi or ILU(0) (``cask_hip_precond*``): factored once on the host, applied on the device."""
 
     def __init__(self, kind, n, row_ptr, col_ind, values):
-        kind = {"jacobi": PRECOND_JACOBI, "ilu0": PRECOND_ILU0, "ilu0_unit": PRECOND_ILU0_UNIT,
-                "ilu0_mc": PRECOND_ILU0_MC}.get(kind, kind)
+        kind = {"jacobi": PRECOND_JACOBI, "ilu0": PRECOND_ILU0, "ilu0_unit": PRECOND_ILU0_UNIT}.get(kind, kind)
         rp, ci, va = _np(row_ptr, np.int32), _np(col_ind, np.int32), _np(values, np.float64)
         if rp.size != n + 1 or ci.size != va.size:
             raise ValueError("malformed CSR arrays")

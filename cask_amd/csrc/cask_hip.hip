@@ -90,6 +90,7 @@ struct Plan {
   // VECTOR
   DevBuf<int2v> xspan;
   int vec_long_rows = 0;           // VECTOR: rows longer than this go to the long-row pieces (long_blocks); 0 = none do
+  bool vec_long_wave = false;      //   ... which a wave each sums (short pieces) instead of a workgroup of 256
   // SCAN (scan_kernel.hpp): per-thread row-end words, the row map of blocks that span empty rows, and -- with an x window --
   // the plan's own column stream (LDS slots)
   DevBuf<unsigned> scan_meta;
@@ -161,8 +162,6 @@ struct cask_hip_matrix {
   PinBuf pin_x, pin_y;             // ... and its pinned host side (the staged entry: host_entry below)
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
-  bool has_fingerprint = false;    // content fingerprint of the device CSR (internal.hpp csr_fp_*), computed on first need
-  uint64_t fingerprint = 0;
   ~cask_hip_matrix() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -414,6 +413,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.xspan.release();
   pl.n_long_rows = pl.n_split_rows = 0;
   pl.vec_long_rows = 0;
+  pl.vec_long_wave = false;
   pl.scan_meta.release();
   pl.scan_rowmap.release();
   pl.scan_ci.release();
@@ -586,7 +586,12 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
           HIP_TRY(pl.split_rows.upload(splits));
           HIP_TRY(pl.partials.alloc(n_slots));
         }
-        for (const BlockDesc &d : longs) pl.n_long_rows += !(d.kind_g & KIND_PARTIAL) || d.nnz_start == m.h_rp[d.row_start];
+        long long piece_nnz = 0;
+        for (const BlockDesc &d : longs) {
+          pl.n_long_rows += !(d.kind_g & KIND_PARTIAL) || d.nnz_start == m.h_rp[d.row_start];
+          piece_nnz += d.nnz_count;
+        }
+        pl.vec_long_wave = piece_nnz / (long long)longs.size() < 1024;
       }
     }
     // L >= 4: the pair-load kernel, VEC_RG row groups per wave (spmv_kernels.hpp)
@@ -631,7 +636,7 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
   d.n_blocks = s.n_blocks; d.n_long_blocks = s.n_long_blocks; d.packed12 = s.packed12; d.one_window = s.one_window;
   d.slot_bytes_per_nnz = s.slot_bytes_per_nnz;
   d.maxch = s.maxch; d.any_skew = s.any_skew; d.n_long_rows = s.n_long_rows;
-  d.n_split_rows = s.n_split_rows; d.vec_long_rows = s.vec_long_rows;
+  d.n_split_rows = s.n_split_rows; d.vec_long_rows = s.vec_long_rows; d.vec_long_wave = s.vec_long_wave;
   d.n_slice_blocks = s.n_slice_blocks; d.slice_k = s.slice_k; d.long_nnz = s.long_nnz;
   HIP_TRY(d.blocks.copy_from(s.blocks)); HIP_TRY(d.long_blocks.copy_from(s.long_blocks));
   HIP_TRY(d.split_rows.copy_from(s.split_rows)); HIP_TRY(d.partials.copy_from(s.partials));
@@ -665,11 +670,14 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   else         { if (nt) CASK_LAUNCH_V(false, true); else CASK_LAUNCH_V(false, false); }
 #undef CASK_LAUNCH_V
   if (pl.n_long_blocks > 0) {                                 // the rows the row-mapped kernel left alone
+    // a wave per piece when the pieces are short (a power-law matrix has thousands of rows of 40-200 nonzeros: a
+    // workgroup of 256 for each kept the chip busy with 8 blocks per CU of mostly idle lanes), a workgroup when they are long
+    const dim3 lb(pl.vec_long_wave ? 64 : 256);
     if (nt)
-      hipLaunchKernelGGL((k_spmv_long<true>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
+      hipLaunchKernelGGL((k_spmv_long<true>), dim3(pl.n_long_blocks), lb, 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
                          m.d_val, x, y, pl.partials.p);
     else
-      hipLaunchKernelGGL((k_spmv_long<false>), dim3(pl.n_long_blocks), dim3(256), 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
+      hipLaunchKernelGGL((k_spmv_long<false>), dim3(pl.n_long_blocks), lb, 0, s, pl.long_blocks.p, pl.n_long_blocks, m.d_ci,
                          m.d_val, x, y, pl.partials.p);
     if (pl.n_split_rows > 0)
       hipLaunchKernelGGL(k_spmv_fixup, dim3((pl.n_split_rows + 63) / 64), dim3(64), 0, s, pl.split_rows.p, pl.n_split_rows,
@@ -1490,7 +1498,7 @@ int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
   if (rc) return rc;
   if (yb && y_target == m->d_y.p) HIP_TRY(hipMemcpyAsync(y, m->d_y.p, yb, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  if (yb && !y_dev && y_target != m->d_y.p) copy_pool().copy(y, m->pin_y.p, yb);
+  if (yb && !y_dev && y_target != m->d_y.p) copy_pool().copy(y, m->pin_y.p, yb, 1);
   return CASK_HIP_OK;
 }
 
@@ -2264,140 +2272,6 @@ int cask_hip_bicg(cask_hip_matrix *m, const double *rhs, double *x, int32_t maxi
 // preconditioner applied on the device: r = b - A x ; z = M^-1 r ; p = z ; rsold = r.z ; then per pass
 // Ap = A p ; alpha = rsold / p.Ap ; x += alpha p ; r -= alpha Ap ; z = M^-1 r ; rsnew = r.z ;
 // stop if rsnew <= tol^2 ; p = z + (rsnew/rsold) p.  `iterations` as the reference counts them.
-// out[i] = in[perm[i]] (into colour order) / out[perm[i]] = in[i] (back)
-__global__ void k_permute_in(int64_t n, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
-}
-__global__ void k_permute_out(int64_t n, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[perm[i]] = in[i];
-}
-
-// PCG with the multicolour ILU(0) (CASK_HIP_PRECOND_ILU0_MC, r4): the whole solve runs in COLOUR ORDER.  b and the
-// initial guess are permuted once on the way in, x once on the way out; the product is the engine's own kernel on
-// P A P^T (a handle built once and kept on the preconditioner); the x / r update of a pass rides in the forward sweeps
-// and the shares of r.z come out of the backward sweeps, so a pass is   product + p.Ap  |  C forward  |  C backward  |
-// p update   = 2 C + 2 launches with no permutation pass and no separate dot (round 3: 8 sweeps + 2 permutations + a
-// generic pass = 134 us on the G3_circuit-like system; this form: see profiles/r04_pcg_mc.txt).  Recurrence, stopping
-// rule and `iterations` as pcg (SparseLinearSolvers.hpp:162-239).
-// The fingerprint of the handle's device arrays (they do not change while the handle exists: cask_hip.h).
-__global__ void k_csr_fingerprint(int n_rows, int64_t nnz, const int *__restrict__ rp, const int *__restrict__ ci,
-                                  const double *__restrict__ val, unsigned long long *out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long acc = 0;
-  for (int64_t r = t0; r <= n_rows; r += stride) acc += csr_fp_row((uint64_t)r, (uint64_t)rp[r]);
-  for (int64_t k = t0; k < nnz; k += stride)
-    acc += csr_fp_entry((uint64_t)k, (uint64_t)ci[k], (uint64_t)__double_as_longlong(val[k]));
-  atomicAdd(out, acc);                                          // integer: any order gives the same sum
-}
-static int matrix_fingerprint(cask_hip_matrix *m, uint64_t *fp) {
-  if (!m->has_fingerprint) {
-    DevBuf<unsigned long long> acc;
-    HIP_TRY(acc.alloc(1));
-    HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), m->stream));
-    const int grid = (int)std::min<int64_t>(2048, (m->nnz + 255) / 256 + 1);
-    hipLaunchKernelGGL(k_csr_fingerprint, dim3(grid), dim3(256), 0, m->stream, m->n_rows, m->nnz, m->d_rp, m->d_ci, m->d_val,
-                       acc.p);
-    HIP_TRY(hipGetLastError());
-    unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, acc.p, sizeof(h), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    m->fingerprint = h;
-    m->has_fingerprint = true;
-  }
-  *fp = m->fingerprint;
-  return CASK_HIP_OK;
-}
-
-// (returns PCG_MC_NOT_APPLICABLE before any work is queued when the permuted matrix's plan cannot leave the shares of
-// p.Ap behind -- LDS budget, a grid of long-row pieces only: the caller then runs the generic pass)
-constexpr int PCG_MC_NOT_APPLICABLE = -1;
-static int pcg_multicolour(cask_hip_matrix *m, cask_hip_precond *precond, const cask_hip_mc_view &mc, const double *rhs,
-                           double *x, int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
-                           double *usec_per_iteration) {
-  const int64_t n = m->n_rows;
-  hipStream_t s = m->stream;
-  int rc;
-  if (!*mc.product) {
-    cask_hip_params prm{};
-    prm.variant = CASK_HIP_VARIANT_MERGE;                      // (the fused dot epilogue lives in the merge kernel)
-    rc = cask_hip_csr_create(m->n_rows, m->n_cols, m->nnz, mc.h_rp, mc.h_ci, mc.h_va, &prm, mc.product);
-    if (rc) return rc;
-  }
-  cask_hip_matrix *mp = *mc.product;
-  if (!plan_fuses_dot(mp->plan)) return PCG_MC_NOT_APPLICABLE;
-  DevBuf<double> dx, db, xin, r, z, p, Ap, part_rz, scal;
-  DevBuf<int> flags;
-  HIP_TRY(xin.upload(x, n)); HIP_TRY(db.upload(rhs, n));
-  HIP_TRY(dx.alloc(n)); HIP_TRY(r.alloc(n)); HIP_TRY(z.alloc(n + 1)); HIP_TRY(p.alloc(n)); HIP_TRY(Ap.alloc(n));
-  HIP_TRY(part_rz.alloc((size_t)std::max(mc.n_part_rz, 1))); HIP_TRY(scal.alloc(4)); HIP_TRY(flags.alloc(2));
-  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  HIP_TRY(hipMemsetAsync(z.p + n, 0, sizeof(double), s));
-  double *rs[2] = {scal.p, scal.p + 1};
-  int *done = flags.p, *iters = flags.p + 1;
-  const int g = blas_grid(n);
-  const dim3 bg(g), bw(BLAS_WG);
-  hipLaunchKernelGGL(k_permute_in, bg, bw, 0, s, n, mc.d_perm, xin.p, dx.p);
-  hipLaunchKernelGGL(k_permute_in, bg, bw, 0, s, n, mc.d_perm, db.p, xin.p);             // xin now holds P b
-  rc = launch_spmv(*mp, dx.p, r.p, s);                                                   // :189-190
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, xin.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
-                     r.p, (const int *)nullptr);
-  cask_hip_mc_sweep_args sw{};
-  sw.r = r.p;
-  sw.z = z.p;
-  sw.part_rz = part_rz.p;
-  rc = cask_hip_precond_mc_sweeps(precond, &sw, s);                                      // :193, with the shares of r.z
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(p.p, z.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));    // :195
-  hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, mc.n_part_rz, part_rz.p, rs[0], 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
-  HIP_TRY(hipGetLastError());
-
-  DevEvent e0, e1;
-  HIP_TRY(e0.create()); HIP_TRY(e1.create());
-  HIP_TRY(hipEventRecord(e0, s));
-  const int check_every = 16;
-  int h_flags[2] = {0, 0};
-  int launched = 0;
-  double clean_us = 0.0;
-  for (int i = 0; i < maxiters; i++) {
-    double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
-    rc = launch_spmv(*mp, p.p, Ap.p, s, p.p);                                            // :206-208
-    if (rc) return rc;
-    sw.rsold = rsold;                                                                    // :210-212 inside the forward sweeps
-    sw.part_pAp = mp->plan.dot_part.p;
-    sw.n_pAp = dot_part_count(mp->plan);
-    sw.p = p.p;
-    sw.Ap = Ap.p;
-    sw.x = dx.p;
-    sw.done = done;
-    rc = cask_hip_precond_mc_sweeps(precond, &sw, s);                                    // :215, :218
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_cg_update_p, bg, bw, 0, s, n, part_rz.p, mc.n_part_rz, rsold, rsnew, tol * tol, i, z.p, p.p, done,
-                       iters);                                                           // :220-231
-    launched = i + 1;
-    if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
-      HIP_TRY(hipEventRecord(e1, s));
-      HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (h_flags[0]) break;
-      float ms_so_far = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
-      clean_us = ms_so_far * 1e3 / launched;
-    }
-  }
-  HIP_TRY(hipEventRecord(e1, s));
-  hipLaunchKernelGGL(k_permute_out, bg, bw, 0, s, n, mc.d_perm, dx.p, xin.p);
-  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(x, xin.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  if (iterations) *iterations = h_flags[1];
-  if (converged) *converged = h_flags[0] != 0;
-  if (usec_per_iteration) *usec_per_iteration = clean_us > 0 ? clean_us : (launched ? ms * 1e3 / launched : 0.0);
-  return CASK_HIP_OK;
-}
-
 int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x, int32_t maxiters,
                  double tol, int32_t *iterations, int32_t *converged, double *usec_per_iteration) {
   int rc = solver_common_checks(m, rhs, x, maxiters, tol);
@@ -2406,23 +2280,6 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   if (cask_hip_precond_rows(precond) != m->n_rows)
     return fail(CASK_HIP_ERR_INVALID, "the preconditioner was built for a matrix of a different order");
   HIP_TRY(hipSetDevice(m->device));
-  {
-    cask_hip_mc_view mc{};
-    // (the colour-ordered solve multiplies with the preconditioner's cached copy of P A P^T: only when that IS `m`'s
-    // matrix -- same pattern AND values, by content fingerprint.  A caller who preconditions A_new with the factors of
-    // A_old (a lagged or frozen preconditioner: same pattern, other values), or one matrix with another's, gets the
-    // generic pass, which multiplies with `m` as the reference's pcg does)
-    if (cask_hip_precond_mc_view(precond, &mc) && m->n_rows > 0 && m->nnz >= 2 && m->n_rows == m->n_cols &&
-        mc.n == m->n_rows && (int64_t)mc.h_rp[mc.n] == m->nnz && !std::getenv("CASK_HIP_PCG_MC_GENERIC")) {
-      uint64_t fp = 0;
-      rc = matrix_fingerprint(m, &fp);
-      if (rc) return rc;
-      if (fp == mc.fingerprint) {
-        rc = pcg_multicolour(m, precond, mc, rhs, x, maxiters, tol, iterations, converged, usec_per_iteration);
-        if (rc != PCG_MC_NOT_APPLICABLE) return rc;
-      }
-    }
-  }
   const int64_t n = m->n_rows;
   hipStream_t s = m->stream;
   DevBuf<double> dx, db, r, z, p, Ap, partials, partials_rz, scal;

@@ -1358,373 +1358,16 @@ int check_sorted_csr(int32_t n, int64_t nnz, const int32_t *rp, const int32_t *c
 
 }  // namespace
 
-// ---- multicolour ILU(0) (CASK_HIP_PRECOND_ILU0_MC: opt-in, NOT the reference's factors) ----------------------
-// The reference's ILU(0) in natural order chains the rows of a grid-like matrix into tens of thousands of
-// dependency levels (57 436 on the G3_circuit-like system: 32 ms per application, section 8 of DESIGN.md).  A greedy
-// colouring of the matrix graph and the symmetric permutation "colour by colour" make every colour a set of mutually
-// independent rows: ILU(0) of the PERMUTED matrix then solves in 2 x (number of colours) wide launches, one thread
-// per row.  It is a different (usually weaker) preconditioner than natural-order ILU(0) -- a trade of iterations for
-// width -- and is labelled as such everywhere.  Unit lower diagonal (the textbook factorisation).
-struct McFactor {
-  int n = 0, n_colors = 0;
-  std::vector<int> color_ptr;           // rows [color_ptr[c], color_ptr[c+1]) of the permuted order have colour c
-  DevBuf<int> perm;                     // permuted position -> original row
-  DevBuf<int> lrp, lci, urp, uci;       // strict lower / strict upper parts, permuted indices, CSR over permuted rows
-  DevBuf<double> lval, uval, udiag, t, zp;
-  // r4, the colour-ordered PCG (cask_hip_pcg with this preconditioner runs ENTIRELY in the permuted order): the two
-  // strict triangles once more as SLICED ELL -- slices of 64 consecutive rows of one colour, a slice as wide as its
-  // longest row, entries column-major inside the slice (lane l of a wave reads entry k of its row at off + 64 k + l:
-  // coalesced), padded entries point at the zero slot [n] of t / z -- and the permuted matrix itself on the host, from
-  // which the PCG driver builds its product handle on first use
-  std::vector<int> slice_base;          // first slice of every colour (n_colors + 1)
-  DevBuf<int> l_off, u_off;             // per slice: first entry (n_slices + 1)
-  DevBuf<int> l_col, u_col;
-  DevBuf<double> l_val, u_val, alpha;
-  int max_grid = 0;                     // workgroups of the widest colour's sweep (MC_ROWS_PER_WG rows each)
-  std::vector<int> h_prp, h_pci;        // P A P^T (unfactored), CSR with ascending columns
-  std::vector<double> h_pva;
-  cask_hip_matrix *product = nullptr;   // engine handle of P A P^T (owned; built by the PCG driver on first use)
-  uint64_t fingerprint = 0;             // of the arrays this was built from: the PCG driver multiplies with the cached
-                                        //   P A P^T only for a handle whose matrix has the same fingerprint
-  ~McFactor() {
-    if (product) (void)cask_hip_csr_destroy(product);
-  }
-};
-constexpr int MC_WG = 256, MC_ROWS_PER_WG = MC_WG;
-__device__ __forceinline__ double mc_wg_sum(double v, double *red) {   // valid in thread 0
-  v = caskhip::group_sum<64>(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double s = 0.0;
-  if (threadIdx.x == 0)
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
-  return s;
-}
-
-// The forward sweep of one colour inside a PCG pass, everything in colour order:
-//   [x += alpha p ; r -= alpha Ap]  (the rows of this colour; alpha = rsold / (p.Ap) from the product launch's shares,
-//   summed identically by every workgroup)    then    t[i] = r[i] - sum_k L[i,k] t[k]   (k in earlier colours).
-// The x / r update of the whole vector is spread over the C forward launches (every row has exactly one colour), so a
-// pass has no update launch of its own in front of the preconditioner.
-// alpha = rsold / (p.Ap) once per pass (one workgroup sums the product launch's shares): 3 000 sweep workgroups each
-// summing 3 900 shares themselves moved more bytes through L2 than the sweep moves through HBM
-__global__ void k_mc_alpha(const double *rsold, const double *__restrict__ part_pAp, int n_part, double *alpha_out,
-                           const int *done) {
-  __shared__ double red[16];
-  if (done && *done) return;
-  const double d = caskhip::partials_or_scalar(part_pAp, n_part, red);
-  if (threadIdx.x == 0) *alpha_out = *rsold / d;
-}
-__global__ void k_mc_fwd_ell(int lo, int hi, const int *__restrict__ off, const int *__restrict__ col,
-                             const double *__restrict__ val, const double *rsold /* here: the pass's alpha, or NULL */,
-                             const double *__restrict__ part_pAp, int n_part, const double *__restrict__ p,
-                             const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r, double *t,
-                             const int *done) {
-  if (done && *done) return;
-  // one row per thread, many waves per CU: a row is three dependent trips (slice offset -> entries -> gathers) and
-  // nothing else hides them (four rows per thread on a quarter of the grid measured 15.8 us per colour, 3x the bytes' time)
-  const int i = lo + blockIdx.x * MC_WG + threadIdx.x, lane = threadIdx.x & 63;
-  const bool mine = i < hi;
-  const int ic = mine ? i : hi - 1;
-  const int sl = __builtin_amdgcn_readfirstlane((ic - lo) >> 6);
-  const int o = off[sl], w = (off[sl + 1] - o) >> 6;
-  double ri = r[ic], pi = 0.0, api = 0.0, xi = 0.0;
-  if (rsold) {
-    pi = p[ic];
-    api = Ap[ic];
-    xi = x[ic];
-  }
-  if (rsold) {
-    const double alpha = *rsold;
-    xi = fma(alpha, pi, xi);
-    ri = fma(-alpha, api, ri);
-    if (mine) {
-      x[i] = xi;
-      r[i] = ri;
-    }
-  }
-  double s = ri;
-  for (int k0 = 0; k0 < w; k0 += 4) {                         // four entries in flight; absent ones are 0 * t[a real entry]
-    int c[4];
-    double v[4], tv[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = o + 64 * min(k0 + u, w - 1) + lane;
-      c[u] = col[e];
-      v[u] = k0 + u < w ? val[e] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) tv[u] = t[c[u]];
-#pragma unroll
-    for (int u = 0; u < 4; u++) s -= v[u] * tv[u];
-  }
-  if (mine) t[i] = s;
-}
-// The backward sweep of one colour: z[i] = (t[i] - sum_k U[i,k] z[k]) / U[i,i]  (k in later colours), and the
-// workgroup's share of r.z (fixed order: the wave butterflies, then the workgroup's waves).
-__global__ void k_mc_bwd_ell(int lo, int hi, const int *__restrict__ off, const int *__restrict__ col,
-                             const double *__restrict__ val, const double *__restrict__ diag, const double *__restrict__ t,
-                             double *z, const double *__restrict__ r, double *__restrict__ part_rz, const int *done) {
-  __shared__ double red[16];
-  if (done && *done) return;
-  const int i = lo + blockIdx.x * MC_WG + threadIdx.x, lane = threadIdx.x & 63;
-  const bool mine = i < hi;
-  const int ic = mine ? i : hi - 1;
-  const int sl = __builtin_amdgcn_readfirstlane((ic - lo) >> 6);
-  const int o = off[sl], w = (off[sl + 1] - o) >> 6;
-  double s = t[ic];
-  const double di = diag[ic], ri = part_rz ? r[ic] : 0.0;
-  for (int k0 = 0; k0 < w; k0 += 4) {
-    int c[4];
-    double v[4], zv[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = o + 64 * min(k0 + u, w - 1) + lane;
-      c[u] = col[e];
-      v[u] = k0 + u < w ? val[e] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) zv[u] = z[c[u]];
-#pragma unroll
-    for (int u = 0; u < 4; u++) s -= v[u] * zv[u];
-  }
-  s /= di;
-  if (mine) z[i] = s;
-  if (part_rz) {
-    const double sum = mc_wg_sum(mine ? ri * s : 0.0, red);
-    if (threadIdx.x == 0) part_rz[blockIdx.x] = sum;
-  }
-}
-
-// The stand-alone application (cask_hip_precond_apply: r and z in NATURAL order, one thread per row over the CSR copy).
-// forward sweep of one colour: t[i] = r[perm[i]] - sum_k L[i,k] t[k]   (k in earlier colours)
-__global__ void k_mc_forward(int lo, int hi, const int *__restrict__ perm, const int *__restrict__ rp,
-                             const int *__restrict__ ci, const double *__restrict__ val, const double *__restrict__ r,
-                             double *t) {
-  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= hi) return;
-  double s = r[perm[i]];
-  for (int k = rp[i]; k < rp[i + 1]; k++) s -= val[k] * t[ci[k]];
-  t[i] = s;
-}
-// backward sweep of one colour: zp[i] = (t[i] - sum_k U[i,k] zp[k]) / U[i,i]   (k in later colours); z in natural order
-__global__ void k_mc_backward(int lo, int hi, const int *__restrict__ perm, const int *__restrict__ rp,
-                              const int *__restrict__ ci, const double *__restrict__ val, const double *__restrict__ diag,
-                              const double *__restrict__ t, double *zp, double *__restrict__ z) {
-  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= hi) return;
-  double s = t[i];
-  for (int k = rp[i]; k < rp[i + 1]; k++) s -= val[k] * zp[ci[k]];
-  s /= diag[i];
-  zp[i] = s;
-  z[perm[i]] = s;
-}
-
-// Greedy colouring in natural order (pattern must be structurally symmetric), permutation, ILU(0) of P A P^T.
-int build_mc(int n, const int *rp, const int *ci, const double *va, McFactor &f) {
-  // structural symmetry (pcg's systems are symmetric; a one-sided edge would make a "colour" dependent inside)
-  {
-    std::vector<int> cnt((size_t)n + 1, 0);
-    for (int r = 0; r < n; r++)
-      for (int k = rp[r]; k < rp[r + 1]; k++) cnt[ci[k] + 1]++;
-    for (int r = 0; r < n; r++) cnt[r + 1] += cnt[r];
-    std::vector<int> tci((size_t)rp[n]), fill(cnt.begin(), cnt.end() - 1);
-    for (int r = 0; r < n; r++)
-      for (int k = rp[r]; k < rp[r + 1]; k++) tci[fill[ci[k]]++] = r;
-    for (int r = 0; r < n; r++) {
-      if (cnt[r + 1] - cnt[r] != rp[r + 1] - rp[r] || !std::equal(tci.begin() + cnt[r], tci.begin() + cnt[r + 1], ci + rp[r]))
-        return report_failure(CASK_HIP_ERR_INVALID, "the multicolour ILU needs a structurally symmetric matrix");
-    }
-  }
-  std::vector<int> color((size_t)n, -1);
-  int n_colors = 0;
-  {
-    std::vector<int> mark;                                     // mark[c] == r: colour c is taken by a neighbour of row r
-    for (int r = 0; r < n; r++) {
-      for (int k = rp[r]; k < rp[r + 1]; k++) {
-        const int c = ci[k] != r ? color[ci[k]] : -1;
-        if (c >= 0) {
-          if ((int)mark.size() <= c) mark.resize(c + 1, -1);
-          mark[c] = r;
-        }
-      }
-      int c = 0;
-      while (c < (int)mark.size() && mark[c] == r) c++;
-      color[r] = c;
-      n_colors = std::max(n_colors, c + 1);
-    }
-  }
-  f.n = n;
-  f.n_colors = n_colors;
-  f.color_ptr.assign((size_t)n_colors + 1, 0);
-  for (int r = 0; r < n; r++) f.color_ptr[color[r] + 1]++;
-  for (int c = 0; c < n_colors; c++) f.color_ptr[c + 1] += f.color_ptr[c];
-  std::vector<int> perm((size_t)n), inv((size_t)n), fill(f.color_ptr.begin(), f.color_ptr.end() - 1);
-  for (int r = 0; r < n; r++) {                                // stable inside a colour: natural order
-    perm[fill[color[r]]] = r;
-    inv[r] = fill[color[r]]++;
-  }
-  // P A P^T in CSR with ascending columns
-  std::vector<int> prp((size_t)n + 1, 0), pci((size_t)rp[n]);
-  std::vector<double> pva((size_t)rp[n]);
-  for (int i = 0; i < n; i++) prp[i + 1] = prp[i] + (rp[perm[i] + 1] - rp[perm[i]]);
-  {
-    std::vector<std::pair<int, double>> row;
-    for (int i = 0; i < n; i++) {
-      const int r = perm[i];
-      row.clear();
-      for (int k = rp[r]; k < rp[r + 1]; k++) row.emplace_back(inv[ci[k]], va[k]);
-      std::sort(row.begin(), row.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
-      for (size_t j = 0; j < row.size(); j++) {
-        pci[(size_t)prp[i] + j] = row[j].first;
-        pva[(size_t)prp[i] + j] = row[j].second;
-      }
-    }
-  }
-  std::vector<int> prp_keep(prp), pci_keep(pci);            // the permuted matrix itself: the PCG driver's product operand
-  std::vector<double> pva_keep(pva);
-  // ILU(0), IKJ (the sweep of SparseLinearSolvers.hpp:92-113 on the permuted pattern)
-  std::vector<int> diag((size_t)n, -1);
-  for (int i = 0; i < n; i++)
-    for (int k = prp[i]; k < prp[i + 1]; k++)
-      if (pci[k] == i) diag[i] = k;
-  for (int i = 0; i < n; i++)
-    if (diag[i] < 0) return report_failure(CASK_HIP_ERR_INVALID, "the multicolour ILU needs a stored diagonal in every row");
-  for (int i = 1; i < n; i++) {
-    for (int kk = prp[i]; kk < prp[i + 1]; kk++) {
-      const int k = pci[kk];
-      if (k >= i) break;
-      pva[kk] = pva[kk] / pva[diag[k]];
-      const double beta = pva[kk];
-      int pi = kk + 1, pk = diag[k] + 1;
-      const int ei = prp[i + 1], ek = prp[k + 1];
-      while (pi < ei && pk < ek) {
-        if (pci[pi] < pci[pk]) pi++;
-        else if (pci[pi] > pci[pk]) pk++;
-        else {
-          pva[pi] = pva[pi] - pva[pk] * beta;
-          pi++;
-          pk++;
-        }
-      }
-    }
-  }
-  std::vector<int> lrp((size_t)n + 1, 0), urp((size_t)n + 1, 0), lci, uci;
-  std::vector<double> lval, uval, udiag((size_t)n);
-  for (int i = 0; i < n; i++) {
-    for (int k = prp[i]; k < prp[i + 1]; k++) {
-      if (pci[k] < i) { lci.push_back(pci[k]); lval.push_back(pva[k]); }
-      else if (pci[k] > i) { uci.push_back(pci[k]); uval.push_back(pva[k]); }
-      else udiag[i] = pva[k];
-    }
-    lrp[i + 1] = (int)lci.size();
-    urp[i + 1] = (int)uci.size();
-  }
-  // sliced ELL of the two strict triangles (colour-ordered PCG): slices of 64 rows never straddle a colour
-  {
-    f.slice_base.assign((size_t)n_colors + 1, 0);
-    for (int c = 0; c < n_colors; c++)
-      f.slice_base[c + 1] = f.slice_base[c] + (f.color_ptr[c + 1] - f.color_ptr[c] + 63) / 64;
-    const int n_slices = f.slice_base[n_colors];
-    auto slice_up = [&](const std::vector<int> &xrp, const std::vector<int> &xci, const std::vector<double> &xval,
-                        std::vector<int> &off, std::vector<int> &col, std::vector<double> &val) {
-      off.assign((size_t)n_slices + 1, 0);
-      col.clear();
-      val.clear();
-      for (int c = 0; c < n_colors; c++) {
-        for (int lo = f.color_ptr[c], sl = f.slice_base[c]; lo < f.color_ptr[c + 1]; lo += 64, sl++) {
-          const int hi = std::min(lo + 64, f.color_ptr[c + 1]);
-          int w = 0;
-          for (int i = lo; i < hi; i++) w = std::max(w, xrp[i + 1] - xrp[i]);
-          off[sl] = (int)col.size();
-          col.resize(col.size() + (size_t)w * 64, n);          // padding: the zero slot [n] of t / z, value 0
-          val.resize(val.size() + (size_t)w * 64, 0.0);
-          for (int i = lo; i < hi; i++)
-            for (int k = xrp[i], j = 0; k < xrp[i + 1]; k++, j++) {
-              col[(size_t)off[sl] + 64 * j + (i - lo)] = xci[k];
-              val[(size_t)off[sl] + 64 * j + (i - lo)] = xval[k];
-            }
-        }
-      }
-      off[n_slices] = (int)col.size();
-      col.push_back(n);
-      val.push_back(0.0);
-    };
-    std::vector<int> off, col;
-    std::vector<double> val;
-    slice_up(lrp, lci, lval, off, col, val);
-    PC_TRY(f.l_off.upload(off)); PC_TRY(f.l_col.upload(col)); PC_TRY(f.l_val.upload(val));
-    slice_up(urp, uci, uval, off, col, val);
-    PC_TRY(f.u_off.upload(off)); PC_TRY(f.u_col.upload(col)); PC_TRY(f.u_val.upload(val));
-    f.max_grid = 0;
-    for (int c = 0; c < n_colors; c++)
-      f.max_grid = std::max(f.max_grid, (f.color_ptr[c + 1] - f.color_ptr[c] + MC_ROWS_PER_WG - 1) / MC_ROWS_PER_WG);
-  }
-  lci.push_back(0); uci.push_back(0); lval.push_back(0.0); uval.push_back(0.0);
-  PC_TRY(f.perm.upload(perm));
-  PC_TRY(f.lrp.upload(lrp)); PC_TRY(f.lci.upload(lci)); PC_TRY(f.lval.upload(lval));
-  PC_TRY(f.urp.upload(urp)); PC_TRY(f.uci.upload(uci)); PC_TRY(f.uval.upload(uval));
-  PC_TRY(f.udiag.upload(udiag));
-  PC_TRY(f.t.alloc((size_t)n + 1)); PC_TRY(f.zp.alloc((size_t)n + 1)); PC_TRY(f.alpha.alloc(1));
-  PC_TRY(hipMemset(f.t.p + n, 0, sizeof(double)));             // the zero slot padded entries read
-  PC_TRY(hipMemset(f.zp.p + n, 0, sizeof(double)));
-  f.h_prp = std::move(prp_keep); f.h_pci = std::move(pci_keep); f.h_pva = std::move(pva_keep);
-  return CASK_HIP_OK;
-}
-
-// One preconditioner application inside a colour-ordered PCG pass (all vectors in colour order; internal.hpp):
-// C forward launches (with the x / r update of their rows when a->rsold is given), C backward launches (with the
-// shares of r.z when a->part_rz is given: a->n_part_rz of them, colour by colour).
-int mc_sweeps(const McFactor &f, const cask_hip_mc_sweep_args *a, hipStream_t s) {
-  if (!a->z) return report_failure(CASK_HIP_ERR_INVALID, "mc_sweeps: z is NULL");
-  const double *alpha = nullptr;
-  if (a->rsold) {
-    hipLaunchKernelGGL(k_mc_alpha, dim3(1), dim3(MC_WG), 0, s, a->rsold, a->part_pAp, a->n_pAp, f.alpha.p, a->done);
-    alpha = f.alpha.p;
-  }
-  for (int c = 0; c < f.n_colors; c++) {
-    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
-    if (hi <= lo) continue;
-    hipLaunchKernelGGL(k_mc_fwd_ell, dim3((hi - lo + MC_ROWS_PER_WG - 1) / MC_ROWS_PER_WG), dim3(MC_WG), 0, s, lo, hi,
-                       f.l_off.p + f.slice_base[c], f.l_col.p, f.l_val.p, alpha, a->part_pAp, a->n_pAp, a->p, a->Ap, a->x,
-                       a->r, f.t.p, a->done);
-  }
-  int pbase = 0;
-  for (int c = f.n_colors - 1; c >= 0; c--) {
-    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
-    if (hi <= lo) continue;
-    const int grid = (hi - lo + MC_ROWS_PER_WG - 1) / MC_ROWS_PER_WG;
-    hipLaunchKernelGGL(k_mc_bwd_ell, dim3(grid), dim3(MC_WG), 0, s, lo, hi, f.u_off.p + f.slice_base[c], f.u_col.p, f.u_val.p,
-                       f.udiag.p, f.t.p, a->z, a->r, a->part_rz ? a->part_rz + pbase : (double *)nullptr, a->done);
-    pbase += grid;
-  }
-  PC_TRY(hipGetLastError());
-  return CASK_HIP_OK;
-}
-
-int apply_mc(const McFactor &f, const double *d_r, double *d_z, hipStream_t s) {
-  for (int c = 0; c < f.n_colors; c++) {
-    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
-    if (hi > lo)
-      hipLaunchKernelGGL(k_mc_forward, dim3((hi - lo + 255) / 256), dim3(256), 0, s, lo, hi, f.perm.p, f.lrp.p, f.lci.p, f.lval.p,
-                         d_r, f.t.p);
-  }
-  for (int c = f.n_colors - 1; c >= 0; c--) {
-    const int lo = f.color_ptr[c], hi = f.color_ptr[c + 1];
-    if (hi > lo)
-      hipLaunchKernelGGL(k_mc_backward, dim3((hi - lo + 255) / 256), dim3(256), 0, s, lo, hi, f.perm.p, f.urp.p, f.uci.p,
-                         f.uval.p, f.udiag.p, f.t.p, f.zp.p, d_z);
-  }
-  PC_TRY(hipGetLastError());
-  return CASK_HIP_OK;
-}
+// (Rounds 3-5 had a multicolour ILU(0) here -- CASK_HIP_PRECOND_ILU0_MC: greedy colouring, 2 x colours wide launches per
+// application, the whole PCG in colour order.  NOT the reference's factors, and behind Jacobi end to end on the system it
+// was built for (138 passes x 112 us = 15.5 ms against 257 x 48 us = 12.5 ms on G3_circuit-like): removed in ABI 7,
+// docs/experiments.md.)
 
 struct cask_hip_precond {
   int kind = 0, n = 0;
   int device = 0;
   std::vector<double> factored;        // ILU0: the factored values in the input pattern (pc of the reference)
   TriFactor L, U;
-  McFactor mc;                         // ILU0_MC: colour-ordered factors
   DevBuf<double> dinv, tmp, d_r, d_z;  // Jacobi: 1/diag ; ILU0: the intermediate vector ; staging for host vectors
 };
 
@@ -1734,8 +1377,10 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
                             const double *values, cask_hip_precond **out) {
   if (!out) return report_failure(CASK_HIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
-  if (kind != CASK_HIP_PRECOND_JACOBI && kind != CASK_HIP_PRECOND_ILU0 && kind != CASK_HIP_PRECOND_ILU0_UNIT &&
-      kind != CASK_HIP_PRECOND_ILU0_MC)
+  if (kind == CASK_HIP_PRECOND_ILU0_MC_REMOVED)
+    return report_failure(CASK_HIP_ERR_INVALID, "the multicolour ILU(0) (kind 4) was removed in ABI 7: not the reference's factors and "
+                                                "behind Jacobi end to end (docs/experiments.md); use CASK_HIP_PRECOND_JACOBI or _ILU0_UNIT");
+  if (kind != CASK_HIP_PRECOND_JACOBI && kind != CASK_HIP_PRECOND_ILU0 && kind != CASK_HIP_PRECOND_ILU0_UNIT)
     return report_failure(CASK_HIP_ERR_INVALID, "unknown preconditioner kind");
   int rc = check_sorted_csr(n, nnz, row_ptr, col_ind);
   if (rc) return rc;
@@ -1753,20 +1398,6 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
       for (int k = row_ptr[r]; k < row_ptr[r + 1]; k++)
         if (col_ind[k] == r && values[k] != 0.0) dinv[r] = 1.0 / values[k];
     PC_TRY(p->dinv.upload(dinv));
-    *out = p.release();
-    return CASK_HIP_OK;
-  }
-  if (kind == CASK_HIP_PRECOND_ILU0_MC) {
-    rc = build_mc(n, row_ptr, col_ind, values, p->mc);
-    if (rc) return rc;
-    uint64_t fp = 0;
-    for (int64_t r = 0; r <= n; r++) fp += csr_fp_row((uint64_t)r, (uint64_t)row_ptr[r]);
-    for (int64_t k = 0; k < nnz; k++) {
-      uint64_t bits;
-      std::memcpy(&bits, values + k, 8);
-      fp += csr_fp_entry((uint64_t)k, (uint64_t)col_ind[k], bits);
-    }
-    p->mc.fingerprint = fp;
     *out = p.release();
     return CASK_HIP_OK;
   }
@@ -1813,28 +1444,6 @@ int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t 
   return CASK_HIP_OK;
 }
 
-// ---- between this file and the PCG driver (internal.hpp) ------------------------------------------------------
-int cask_hip_precond_mc_view(cask_hip_precond *p, cask_hip_mc_view *v) {
-  if (!p || !v || p->kind != CASK_HIP_PRECOND_ILU0_MC) return 0;
-  v->n = p->mc.n;
-  v->n_colors = p->mc.n_colors;
-  v->fingerprint = p->mc.fingerprint;
-  v->d_perm = p->mc.perm.p;
-  v->h_rp = p->mc.h_prp.data();
-  v->h_ci = p->mc.h_pci.data();
-  v->h_va = p->mc.h_pva.data();
-  v->product = &p->mc.product;
-  v->n_part_rz = 0;
-  for (int c = 0; c < p->mc.n_colors; c++)
-    v->n_part_rz += (p->mc.color_ptr[c + 1] - p->mc.color_ptr[c] + MC_ROWS_PER_WG - 1) / MC_ROWS_PER_WG;
-  return 1;
-}
-int cask_hip_precond_mc_sweeps(cask_hip_precond *p, const cask_hip_mc_sweep_args *a, void *stream) {
-  if (!p || !a || p->kind != CASK_HIP_PRECOND_ILU0_MC) return report_failure(CASK_HIP_ERR_INVALID, "not a multicolour preconditioner");
-  // the sweeps run on the factor's own t (n + 1 entries, zero slot last); z must have its zero slot too
-  return mc_sweeps(p->mc, a, static_cast<hipStream_t>(stream));
-}
-
 int cask_hip_precond_destroy(cask_hip_precond *p) {
   delete p;
   return CASK_HIP_OK;
@@ -1842,8 +1451,8 @@ int cask_hip_precond_destroy(cask_hip_precond *p) {
 
 int cask_hip_precond_factor_values(const cask_hip_precond *p, double *values_out) {
   if (!p || !values_out) return report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
-  if (p->kind == CASK_HIP_PRECOND_JACOBI || p->kind == CASK_HIP_PRECOND_ILU0_MC)
-    return report_failure(CASK_HIP_ERR_INVALID, "only the natural-order ILU0 kinds keep factor values in the input pattern");
+  if (p->kind == CASK_HIP_PRECOND_JACOBI)
+    return report_failure(CASK_HIP_ERR_INVALID, "only the ILU0 kinds keep factor values in the input pattern");
   if (!p->factored.empty()) std::memcpy(values_out, p->factored.data(), p->factored.size() * sizeof(double));
   return CASK_HIP_OK;
 }
@@ -1851,12 +1460,6 @@ int cask_hip_precond_factor_values(const cask_hip_precond *p, double *values_out
 int cask_hip_precond_info(const cask_hip_precond *p, int32_t *levels_lower, int32_t *levels_upper,
                           int32_t *launches_per_apply) {
   if (!p) return report_failure(CASK_HIP_ERR_INVALID, "NULL argument");
-  if (p->kind == CASK_HIP_PRECOND_ILU0_MC) {                  // "levels" = colours: one wide launch each
-    if (levels_lower) *levels_lower = p->mc.n_colors;
-    if (levels_upper) *levels_upper = p->mc.n_colors;
-    if (launches_per_apply) *launches_per_apply = 2 * p->mc.n_colors;
-    return CASK_HIP_OK;
-  }
   const bool ilu = p->kind != CASK_HIP_PRECOND_JACOBI;
   if (levels_lower) *levels_lower = ilu ? p->L.n_levels : 0;
   if (levels_upper) *levels_upper = ilu ? p->U.n_levels : 0;
@@ -1874,7 +1477,6 @@ int cask_hip_precond_apply_device(cask_hip_precond *p, const double *d_r, double
     PC_TRY(hipGetLastError());
     return CASK_HIP_OK;
   }
-  if (p->kind == CASK_HIP_PRECOND_ILU0_MC) return apply_mc(p->mc, d_r, d_z, s);
   // z = U^-1 (L^-1 r)   (ILUPreconditioner::apply, SparseLinearSolvers.hpp:143-151)
   int rc = p->L.solve(d_r, p->tmp.p, s);
   if (rc) return rc;

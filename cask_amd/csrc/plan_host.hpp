@@ -248,10 +248,11 @@ inline void place_seam_blocks(const int *ci, int halo_n_own, std::vector<BlockDe
 }
 
 // -------------------------------------------------------------------------------------------------------- VECTOR
-// Rows a row-mapped kernel with L lanes per row should not walk itself: more than 32 L nonzeros (at least 64) -- the
-// lanes would loop 16+ times over a dependent load -> gather chain while the rest of their wave idles.  They become
-// long-row pieces (a workgroup of 256 strides over <= 4 096 nonzeros; several pieces of one row meet in the fix-up).
-inline int vector_long_row_len(int lanes_per_row) { return std::max(64, 32 * lanes_per_row); }
+// Rows a row-mapped kernel with L lanes per row should not walk itself: more than 16 L nonzeros (at least 32) -- the
+// lanes would loop 4+ times over a dependent load -> gather chain (~2 us a turn) while the rest of their wave idles.  They
+// become long-row pieces (a wave, or a workgroup of 256 when the pieces are long, strides over <= 4 096 nonzeros; several
+// pieces of one row meet in the fix-up).  (First cut, 32 L / at least 64: webbase2 48.8 us at L = 2.)
+inline int vector_long_row_len(int lanes_per_row) { return std::max(32, 16 * lanes_per_row); }
 constexpr int VECTOR_LONG_PIECE = 4096;
 inline void build_vector_long_pieces(const int *rp, int n_rows, int long_len, std::vector<BlockDesc> &longs,
                                      std::vector<SplitRow> &splits, int &n_partial_slots) {

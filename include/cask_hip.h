@@ -27,7 +27,7 @@ extern "C" {
 
 #define CASK_HIP_ABI_VERSION 7   /* 7: variant SLICE (row-mapped slices for short rows + nonzero-mapped blocks for long ones, one launch);
                                   * VECTOR sends rows far longer than its lanes suit to the long-row pieces; SCAN's far_columns = 1 / 2
-                                  * removed (they cut fabric traffic and cost more time than they saved): rejected like the rest;
+                                  * removed (they cut fabric traffic and cost more time than they saved), CASK_HIP_PRECOND_ILU0_MC removed (behind Jacobi): rejected like the rest;
                                   * cask_hip_spmv stages host vectors through pinned / registered memory (cask_hip_host_entry_*);
                                   * 6: measured losers removed -- variant MERGE_PAIR (5, xcd_remap = 2), index16 = 3 / 4 (run records),
                                   * far_columns = 1 / 2 for MERGE: each is rejected with CASK_HIP_ERR_INVALID and a message naming
@@ -350,11 +350,9 @@ typedef struct cask_hip_precond cask_hip_precond;
 #define CASK_HIP_PRECOND_JACOBI    1
 #define CASK_HIP_PRECOND_ILU0      2   /* the reference's: both triangular solves divide by the stored diagonal */
 #define CASK_HIP_PRECOND_ILU0_UNIT 3   /* textbook ILU(0): same factors, L applied with a unit diagonal          */
-#define CASK_HIP_PRECOND_ILU0_MC   4   /* OPT-IN, not the reference's factors: ILU(0) (unit lower diagonal) of the matrix
-                                        * permuted colour by colour (greedy multicolouring of its graph) -- an application
-                                        * is 2 x colours wide launches instead of tens of thousands of dependency levels.
-                                        * Needs a structurally symmetric matrix with a full diagonal; a different, usually
-                                        * weaker preconditioner than natural-order ILU(0)                               */
+#define CASK_HIP_PRECOND_ILU0_MC_REMOVED 4 /* ABI 4-6: ILU(0) of the matrix permuted colour by colour (greedy multicolouring), 2 x colours
+                                        * wide launches per application -- not the reference's factors, and behind Jacobi end to end
+                                        * on the system it was built for.  Removed in ABI 7; the value is rejected, never reused */
 int cask_hip_precond_create(int32_t kind, int32_t n, int64_t nnz, const int32_t *row_ptr,
                             const int32_t *col_ind, const double *values, cask_hip_precond **out);
 int cask_hip_precond_destroy(cask_hip_precond *p);
@@ -373,10 +371,7 @@ int cask_hip_precond_apply_device(cask_hip_precond *p, const double *d_r, double
 int cask_hip_trsolve(int32_t n, int64_t nnz, const int32_t *row_ptr, const int32_t *col_ind,
                      const double *values, int32_t lower, const double *rhs, double *x);
 /* Preconditioned CG on a full symmetric CSR handle; precond == NULL is cask_hip_cg.  The test is
- * r.z <= tol^2 like the reference's.  With a CASK_HIP_PRECOND_ILU0_MC preconditioner built from the handle's own
- * matrix the whole solve runs in the preconditioner's colour order (r4: rhs and the initial guess permuted once on the
- * way in, x once on the way out; the product is the engine's kernel on the permuted matrix): same recurrence, same
- * stopping rule, the iterates of pcg on the permuted system. */
+ * r.z <= tol^2 like the reference's. */
 int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rhs, double *x,
                  int32_t maxiters, double tol, int32_t *iterations, int32_t *converged,
                  double *usec_per_iteration);

@@ -50,9 +50,14 @@ def poison_columns(n_rows, n_cols, rp, ci):
     return picks
 
 
-@pytest.mark.parametrize("name", list(synth.GENERATORS))
-@pytest.mark.parametrize("dp", DESIGN_POINTS, ids=DP_IDS)
-def test_spmv_poisoned_column_reaches_its_rows_only(name, dp):
+_FAMILIES = list(synth.GENERATORS)
+# every design point on two of the five families (which two rotates with the point: every family meets every kernel
+# family several times; all 5 x 32 cost the suite 10 s for nothing a third pairing would find)
+_CASES = [(DESIGN_POINTS[i], _FAMILIES[(i + k) % len(_FAMILIES)]) for i in range(len(DESIGN_POINTS)) for k in (0, 2)]
+
+
+@pytest.mark.parametrize("dp,name", _CASES, ids=[f"{DP_IDS[DESIGN_POINTS.index(dp)]}-{name}" for dp, name in _CASES])
+def test_spmv_poisoned_column_reaches_its_rows_only(dp, name):
     n, rp, ci, va = synth.small(name)
     n_cols = n + 3                                              # three columns nobody references, behind the last real one
     rng = np.random.default_rng(21)

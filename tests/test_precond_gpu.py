@@ -351,89 +351,8 @@ for mode in sys.argv[2:]:
     assert not np.array_equal(outs["lanes"], outs["levels"])            # (a different order of additions)
 
 
-def _multicolour_reference(n, rp, ci, va):
-    """Numpy restatement of CASK_HIP_PRECOND_ILU0_MC for the test: greedy colouring in natural order, permutation
-    colour by colour (natural order inside a colour), oracle.ilu0 on P A P^T, unit lower diagonal."""
-    color = np.full(n, -1)
-    for r in range(n):
-        taken = {color[c] for c in ci[rp[r]:rp[r + 1]] if c != r and color[c] >= 0}
-        c = 0
-        while c in taken:
-            c += 1
-        color[r] = c
-    perm = np.argsort(color, kind="stable")
-    inv = np.empty(n, dtype=np.int64)
-    inv[perm] = np.arange(n)
-    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
-    pa = a[perm][:, perm].tocsr()
-    pa.sort_indices()
-    f = oracle.ilu0(pa.indptr.astype(np.int32), pa.indices.astype(np.int32), pa.data)
-    fa = sp.csr_matrix((f, pa.indices, pa.indptr), shape=(n, n))
-    L = sp.tril(fa, -1).tocsr() + sp.identity(n, format="csr")
-    U = sp.triu(fa).tocsr()
-    return int(color.max()) + 1, perm, L, U
-
-
-def test_multicolour_ilu_apply_and_pcg():
-    """CASK_HIP_PRECOND_ILU0_MC (opt-in, not the reference's factors): the application equals P^T U^-1 L^-1 P r of the
-    colour-ordered ILU(0) restated in numpy, costs 2 x colours launches, is bitwise reproducible, and PCG with it
-    converges to the solution in fewer passes than plain CG."""
-    from scipy.sparse.linalg import spsolve_triangular
-    n, rp, ci, va = synth.small("G3_circuit", factor=64)
-    colours, perm, L, U = _multicolour_reference(n, rp, ci, va)
-    pc = capi.Preconditioner("ilu0_mc", n, rp, ci, va)
-    info = pc.info()
-    assert info["levels_lower"] == colours and info["launches_per_apply"] == 2 * colours and colours <= 12
-    r = np.random.default_rng(3).standard_normal(n)
-    want = np.empty(n)
-    want[perm] = spsolve_triangular(U, spsolve_triangular(L, r[perm], lower=True), lower=False)
-    got = pc.apply(r)
-    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
-    assert np.array_equal(got, pc.apply(r))
-    x0 = np.random.default_rng(6).uniform(-1, 1, n)
-    b = oracle.csr_spmv(rp, ci, va, x0)
-    m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
-    _, it_plain, conv_plain, _ = m.cg(b, tol=1e-9)
-    x, it_mc, conv_mc, _ = m.pcg(pc, b, tol=1e-9)
-    assert conv_plain and conv_mc and it_mc < it_plain, (it_mc, it_plain)
-    np.testing.assert_allclose(x, x0, rtol=1e-6, atol=1e-8)
-    # r4: cask_hip_pcg runs this preconditioner's solve ENTIRELY in colour order (permuted matrix, sliced-ELL sweeps with
-    # the x / r update and the r.z shares fused).  Against the oracle's pcg with the textbook ILU(0) on the PERMUTED
-    # system (which is what a multicolour ILU is): same iteration count, same iterate; and against the round-3 form
-    # (natural-order vectors, generic pass) of the same library.
-    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
-    pa = a[perm][:, perm].tocsr()
-    pa.sort_indices()
-    prp, pci, pva = pa.indptr.astype(np.int32), pa.indices.astype(np.int32), pa.data.astype(np.float64)
-    xo, it_o, conv_o = oracle.pcg_precond(prp, pci, pva, b[perm], kind="ilu0_unit", tol=1e-9, full=True)
-    want_x = np.empty(n)
-    want_x[perm] = xo
-    assert conv_o and abs(it_mc - it_o) <= 1, (it_mc, it_o)
-    np.testing.assert_allclose(x, want_x, rtol=1e-7, atol=1e-9)
-    os.environ["CASK_HIP_PCG_MC_GENERIC"] = "1"
-    try:
-        xg, it_g, conv_g, _ = m.pcg(pc, b, tol=1e-9)
-    finally:
-        del os.environ["CASK_HIP_PCG_MC_GENERIC"]
-    assert conv_g and abs(it_g - it_mc) <= 1
-    np.testing.assert_allclose(x, xg, rtol=1e-7, atol=1e-9)
-    x2, it2, _, _ = m.pcg(pc, b, tol=1e-9)                      # reproducible run to run, and the handle is reused
-    assert it2 == it_mc and np.array_equal(x, x2)
-    m.close()
-    # ADVICE r4 (medium): a LAGGED preconditioner -- the factors of A_old applied to A_new = A_old + 0.5 I, same pattern,
-    # other values.  The colour-ordered fast path multiplies with the preconditioner's cached copy of P A_old P^T; it
-    # must not be taken (content fingerprint), and the solve must be that of A_new: x0 again from b_new = A_new x0.
-    va_new = va.copy()
-    rows = np.repeat(np.arange(n), np.diff(rp))
-    va_new[ci == rows] += 0.5
-    b_new = oracle.csr_spmv(rp, ci, va_new, x0)
-    m_new = capi.CsrMatrix.from_host(n, n, rp, ci, va_new)
-    x_new, it_new, conv_new, _ = m_new.pcg(pc, b_new, tol=1e-9)
-    assert conv_new
-    np.testing.assert_allclose(x_new, x0, rtol=1e-6, atol=1e-8)          # (with A_old's product it converges to A_old^-1 b_new)
-    assert np.abs(oracle.csr_spmv(rp, ci, va_new, x_new) - b_new).max() <= 1e-7 * np.abs(b_new).max()
-    m_new.close()
-    pc.close()
-    # a structurally unsymmetric matrix is refused
-    with pytest.raises(ValueError, match="symmetric"):
-        capi.Preconditioner("ilu0_mc", 2, [0, 2, 3], [0, 1, 1], [2.0, 1.0, 2.0])
+def test_removed_multicolour_ilu_is_rejected_with_a_reason():
+    """ABI 7: CASK_HIP_PRECOND_ILU0_MC (kind 4: ILU(0) of the colour-permuted matrix, not the reference's
+    factors, behind Jacobi end to end -- docs/experiments.md) left the shipped engine; asking for it names the replacements."""
+    with pytest.raises(ValueError, match="removed in ABI 7"):
+        capi.Preconditioner(4, 2, [0, 2, 4], [0, 1, 0, 1], [2.0, 1.0, 1.0, 2.0])

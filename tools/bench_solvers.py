@@ -173,6 +173,5 @@ if __name__ == "__main__":
             run(name, solver, 2000)
     if "pcg" in only or not sys.argv[1:]:
         run_pcg("G3_circuit", "jacobi")
-        run_pcg("G3_circuit", "ilu0_mc")
         if "noilu" not in only:
             run_pcg("G3_circuit", "ilu0_unit")
