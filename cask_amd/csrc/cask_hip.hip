@@ -392,6 +392,11 @@ int build_slice_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   return CASK_HIP_OK;
 }
 
+// VECTOR: which kernel runs L lanes per row -- from 4 lanes the pair-load kernel (16-byte value pairs, VEC_RG row groups per
+// wave in flight), below it the round-1 one (one row per lane group at a time).  (r6: the pair-load kernel at L = 1 / 2 --
+// webbase2 56.8 / 68.7 us against 47.4 / 55.3, G3_circuit-like 37.2 / 52.0 against 38.5 / 61.2: not adopted.)
+constexpr bool vector_pair_kernel(int lanes) { return lanes >= 4; }
+
 int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   cask_hip_params prm;
   int rc = resolve_params(m, requested, prm);
@@ -595,7 +600,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       }
     }
     // L >= 4: the pair-load kernel, VEC_RG row groups per wave (spmv_kernels.hpp)
-    const int rows_per_wg = prm.wg_size / prm.lanes_per_row * (prm.lanes_per_row >= 4 ? VEC_RG : 1);
+    const int rows_per_wg = prm.wg_size / prm.lanes_per_row * (vector_pair_kernel(prm.lanes_per_row) ? VEC_RG : 1);
     pl.grid = (m.n_rows + rows_per_wg - 1) / rows_per_wg;
     int max_width = 0;
     if (tile > 0 && m.nnz > 0) {
@@ -614,7 +619,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
     }
     pl.ldsx = max_width > 0;
     pl.lds_bytes = 8 * max_width;
-    if (prm.lanes_per_row >= 4 && max_width > 0)              // the pair-load kernel parks VEC_XW entries per lane
+    if (vector_pair_kernel(prm.lanes_per_row) && max_width > 0)   // the pair-load kernel parks VEC_XW entries per lane
       pl.lds_bytes = 8 * std::max(max_width, std::min(VEC_XW * prm.wg_size, MAX_LDS_BYTES / 8));
   }
   if (!pl.ldsx && pl.prm.tile_width > 0 && m.nnz > 0) {
@@ -659,7 +664,7 @@ int launch_vector_l(const cask_hip_matrix &m, const double *x, double *y, hipStr
   const bool nt = pl.prm.nontemporal > 0;
 #define CASK_LAUNCH_V(LDSX, NT)                                                                                \
   do {                                                                                                         \
-    if (L >= 4)                                                                                                \
+    if (vector_pair_kernel(L))                                                                                 \
       hipLaunchKernelGGL((k_spmv_vector2<(L >= 4 ? L : 4), LDSX, NT>), grid, block, pl.lds_bytes, s, m.n_rows, pl.grid, \
                          remap, tile, (int)m.nnz, pl.vec_long_rows, pl.xspan.p, m.d_rp, m.d_ci, m.d_val, x, y); \
     else                                                                                                       \
@@ -1698,6 +1703,11 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
   std::vector<Cand> cands;
   const double mean_row = m->n_rows ? std::max(1.0, (double)m->nnz / m->n_rows) : 1.0;
   auto l2 = [](double v) { return std::log2(std::max(v, 1.0)); };
+  // SLICE has something to offer only where short rows exist: with fewer than a quarter of the rows at <= 8 nonzeros its
+  // plan is a SCAN plan with a second copy of the streams (and costs a host sort per point): not a candidate there
+  int64_t short_rows = 0;
+  for (int r = 0; r < m->n_rows; r++) short_rows += m->h_rp[(size_t)r + 1] - m->h_rp[(size_t)r] <= SLICE_KMAX;
+  const bool slice_worth_a_look = 4 * short_rows >= (int64_t)m->n_rows;
   // lanes only matter for VECTOR and items only for the merge families: irrelevant repeats are skipped.
   for (int iv = 0; iv < n_items; iv++)
     for (int iw = 0; iw < n_wg_sizes; iw++)
@@ -1714,7 +1724,7 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
             if (saved_halo && variant != CASK_HIP_VARIANT_MERGE) continue;
             if (variant == CASK_HIP_VARIANT_VECTOR && iv != 0) continue;
             if (is_merge && !slice && il != 0) continue;
-            if (slice && (lanes[il] < 1 || lanes[il] > SLICE_KMAX || (items[iv] != 4 && items[iv] != 8))) continue;
+            if (slice && (!slice_worth_a_look || lanes[il] < 1 || lanes[il] > SLICE_KMAX || (items[iv] != 4 && items[iv] != 8))) continue;
             if (variant == CASK_HIP_VARIANT_MERGE_WAVE && it != 0) continue;   // no x tile in that kernel
             Cand c{};
             c.pt.params = saved;
