@@ -95,6 +95,11 @@ struct Plan {
   // the plan's own column stream (LDS slots)
   DevBuf<unsigned> scan_meta;
   DevBuf<int> scan_rowmap, scan_ci;
+  // padded SCAN plan (r6): the plan's own copies of the streams, block b at b * wg_size * items_per_thread; the first
+  // n_regular blocks of `blocks` are the nonzero-mapped ones, the long-row pieces follow
+  DevBuf<double> scan_pval;
+  DevBuf<int> scan_pci;
+  int n_regular = 0;
   // SLICE (slice_kernel.hpp): the row-mapped slices (descriptors, slot map, the plan's copies of the short rows' values
   // and columns in plane order) and the long rows' sub-matrix (its values; blocks / scan_meta / scan_rowmap / scan_ci above
   // describe it)
@@ -278,6 +283,16 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   // (16-byte loads), and the workgroup loads exactly cap elements
   plan::build_merge_blocks(m.h_rp.data(), m.n_rows, cap - 1, 1 << 30, (long)cap * LONG_PIECE_FACTOR, wg, blocks, nullptr, splits,
                            n_long, n_slots, false);
+  // padded plan (scan_kernel.hpp scan_block_padded): the stream addresses of a block are a function of its index -- the
+  // descriptor trip leaves the front of every workgroup's life.  CASK_HIP_SCAN_PAD=0: the unpadded plan (the A/B).
+  // Measured (profiles/r06_scan_pad.txt): with 8 items per thread and an x window 15.20-15.27 -> 14.72-14.78 us on webbase2,
+  // 21.11-21.18 -> 20.90-20.95 on webbase-1M-like; without a window or with 4 items per thread it LOSES 2-6 %: padded there
+  // only.  CASK_HIP_SCAN_PAD=0: never (the A/B).
+  static const bool pad_off = std::getenv("CASK_HIP_SCAN_PAD") && std::atoi(std::getenv("CASK_HIP_SCAN_PAD")) == 0;
+  const bool windowed = m.n_cols < SCAN_LDS_BIT && plan::scan_window_xp(prm.tile_width > 0 ? prm.tile_width : 0, wg, ipt) > 0;
+  const bool pad = !pad_off && ipt >= 8 && windowed && m.nnz > 0 && (int64_t)blocks.size() * cap < ((int64_t)1 << 31);
+  int n_regular = (int)blocks.size();
+  if (pad) n_regular = plan::regular_blocks_first(blocks);
   pl.n_long_rows = n_long;
   pl.n_split_rows = (int)splits.size();
   pl.grid = pl.n_blocks = (int)blocks.size();
@@ -299,20 +314,36 @@ int build_scan_plan(cask_hip_matrix &m, const cask_hip_params &prm) {
   // x window (tile_width): per block the contiguous column range of at most W entries that covers most of its nonzeros,
   // staged in LDS (in the product area: no LDS of its own); a nonzero inside it streams an LDS slot instead of a column
   int xp = (m.nnz > 0 && m.n_cols < SCAN_LDS_BIT) ? plan::scan_window_xp(prm.tile_width > 0 ? prm.tile_width : 0, wg, ipt) : 0;
-  if (xp > 0) {
+  std::vector<int> sci;
+  if (xp > 0 || pad) {
     int rc = ensure_host_col_ind(m);
     if (rc) return rc;
-    std::vector<int> sci(m.h_ci);
+  }
+  if (xp > 0) {
+    sci = m.h_ci;
     sci.push_back(0);                                         // the kernel's last 8-byte pair of an odd nnz
     const int W = 2 * xp * wg;
     if (plan::build_scan_window(m.h_ci.data(), m.nnz, blocks, W, sci) > 0) {
-      HIP_TRY(pl.scan_ci.upload(sci));
+      if (!pad) HIP_TRY(pl.scan_ci.upload(sci));              // (a padded plan streams its own copy below)
       pl.prm.tile_width = W;
       pl.xu = xp;
     } else {
+      sci.clear();
       for (BlockDesc &d : blocks)
         if (!(d.kind_g & KIND_LONG)) d.cmin = d.cwidth = 0;
     }
+  }
+  if (pad) {
+    std::vector<int> pci, src;
+    plan::build_padded_streams(blocks, n_regular, cap, m.h_ci.data(), sci.empty() ? nullptr : sci.data(), pci, src);
+    HIP_TRY(pl.scan_pci.upload(pci));
+    HIP_TRY(pl.scan_pval.alloc(src.size()));
+    DevBuf<int> dsrc;
+    HIP_TRY(dsrc.upload(src));
+    gather_values((int64_t)src.size(), dsrc.p, m.d_val, pl.scan_pval.p, m.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m.stream));                  // (the index array dies here)
+    pl.n_regular = n_regular;
   }
   HIP_TRY(pl.blocks.upload(blocks));
   pl.lds_bytes = 8 * (cap + wg + 4) + 24 * 8;                 // (the window lives in the product area)
@@ -422,6 +453,9 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   pl.scan_meta.release();
   pl.scan_rowmap.release();
   pl.scan_ci.release();
+  pl.scan_pval.release();
+  pl.scan_pci.release();
+  pl.n_regular = 0;
   pl.slices.release();
   pl.slice_slot.release();
   pl.slice_val.release();
@@ -649,6 +683,8 @@ int clone_plan(cask_hip_matrix &dst, const cask_hip_matrix &src) {
   HIP_TRY(d.xspan.copy_from(s.xspan));
   HIP_TRY(d.scan_meta.copy_from(s.scan_meta)); HIP_TRY(d.scan_rowmap.copy_from(s.scan_rowmap));
   HIP_TRY(d.scan_ci.copy_from(s.scan_ci));
+  HIP_TRY(d.scan_pval.copy_from(s.scan_pval)); HIP_TRY(d.scan_pci.copy_from(s.scan_pci));
+  d.n_regular = s.n_regular;
   // SLICE: the plan's copies of the value stream are the same bits in every copy of the matrix
   HIP_TRY(d.slices.copy_from(s.slices)); HIP_TRY(d.slice_slot.copy_from(s.slice_slot)); HIP_TRY(d.slice_ci.copy_from(s.slice_ci));
   HIP_TRY(d.slice_val.copy_from(s.slice_val)); HIP_TRY(d.long_val.copy_from(s.long_val));
@@ -819,6 +855,11 @@ int launch_spmv(cask_hip_matrix &m, const double *x, double *y, hipStream_t s, c
     l.meta = pl.scan_meta.p;
     l.rowmap = pl.scan_rowmap.p;
     l.partials = pl.partials.p;
+    if (!slice && pl.scan_pval.p) {
+      l.pad_val = pl.scan_pval.p;
+      l.pad_ci = pl.scan_pci.p;
+      l.n_regular = pl.n_regular;
+    }
     if (slice) {
       l.n_slice_blocks = pl.n_slice_blocks;
       l.slice_k = pl.slice_k;

@@ -313,6 +313,32 @@ inline void build_scan_meta(const int *rp, std::vector<BlockDesc> &blocks, int w
   }
 }
 
+// Padded SCAN plan: the nonzero-mapped blocks to the front of the list (stable: row order kept), the long-row pieces and
+// zero-fill pieces behind them; returns the number of regular blocks.  (The kernel tells the two apart by block index.)
+inline int regular_blocks_first(std::vector<BlockDesc> &blocks) {
+  auto mid = std::stable_partition(blocks.begin(), blocks.end(), [](const BlockDesc &d) { return !(d.kind_g & KIND_LONG); });
+  return (int)(mid - blocks.begin());
+}
+
+// ... and its streams: regular block b owns slots [b * cap, (b + 1) * cap) -- its nonzeros in order (columns from `sci`, the
+// window-slot stream, when there is one), then padding: source -1 (value +0.0) and the block's first PLAIN column (a gather
+// of its own, never a window slot: a padded product is 0 * x[col] in a slot no run covers).  pci gets two spare entries.
+inline void build_padded_streams(const std::vector<BlockDesc> &blocks, int n_regular, int cap, const int *ci, const int *sci,
+                                 std::vector<int> &pci, std::vector<int> &src) {
+  pci.assign((size_t)n_regular * cap + 2, 0);
+  src.assign((size_t)n_regular * cap, -1);
+  for (int b = 0; b < n_regular; b++) {
+    const BlockDesc &d = blocks[(size_t)b];
+    const size_t at = (size_t)b * cap;
+    for (int i = 0; i < d.nnz_count; i++) {
+      pci[at + i] = (sci ? sci : ci)[(size_t)d.nnz_start + i];
+      src[at + i] = d.nnz_start + i;
+    }
+    const int pad_col = d.nnz_count > 0 ? ci[(size_t)d.nnz_start] : 0;
+    for (int i = d.nnz_count; i < cap; i++) pci[at + i] = pad_col;
+  }
+}
+
 // 16-byte window loads per thread for a wanted window of `want_w` entries: 0 (none), 2, 4 or 8.  The window SHARES the
 // product area's LDS (scan_kernel.hpp: dead once every thread holds its x values), so it is at most ipt * wg entries wide
 // (xp <= ipt / 2) and costs no LDS -- with 16 KB of its own a 2 048-entry window took a 256 x 8 block from 8 to 4

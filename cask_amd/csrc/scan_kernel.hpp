@@ -89,6 +89,91 @@ __device__ __forceinline__ void scan_long_piece(const BlockDesc &d, const int *_
   }
 }
 
+// Phase 2 of a SCAN block (the products are parked in LDS, one pad double in front of every thread-owned run of IPT): thread-owned
+// runs guided by the row-end word, carries joined by a segmented scan in DPP, row sums staged by ordinal and swept out.
+template <int IPT>
+__device__ __forceinline__ void scan_row_sums(const BlockDesc &d, int lead, unsigned mw, double *prod, double *wval, int *wflag,
+                                              const int *__restrict__ rp, const int *__restrict__ rowmap, double *__restrict__ y) {
+  const int WG = blockDim.x, tid = threadIdx.x;
+  // ---- phase 2: thread-owned runs ---------------------------------------------------------------------------
+  const unsigned flags = mw & 0xffffu;
+  const int ord = (int)(mw >> 16);
+  const int k0 = tid * IPT;
+  const bool holes = (d.kind_g & KIND_HOLES) != 0;            // workgroup-uniform
+  const int *rmap = rowmap + d.aux;                           // holes: [number of non-empty rows, their local rows ...]
+  double p[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; j++) p[j] = prod[lead + 1 + (IPT + 1) * tid + j];
+#pragma unroll
+  for (int j = 0; j < IPT; j++)
+    if (k0 + j >= d.nnz_count) p[j] = 0.0;                    // behind the block's last nonzero
+  __syncthreads();                                            // every run is in registers: the product area is free
+  // row sums go to rsum[ordinal] (the product area again) and leave for y in one coalesced sweep at the end:
+  // stored from here, lane by lane, a block's ~700 row sums were ~90 partly filled store instructions per wave
+  // (3.8 of the launch's 27 us on the webbase-like matrix)
+  double *rsum = prod;
+  double acc = 0.0, head = 0.0;
+  int i = 0;
+#pragma unroll
+  for (int j = 0; j < IPT; j++) {
+    acc += p[j];
+    if ((flags >> j) & 1u) {
+      if (i == 0) head = acc;                                 // completes a row earlier threads may have begun
+      else rsum[ord + i] = acc;
+      i++;
+      acc = 0.0;
+    }
+  }
+  // segmented inclusive scan over the wave, (f, s) = (a row ends in lanes [.., lane], sum of the tails since), all
+  // in DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source read the identity: bound_ctrl),
+  // then lane 15 of each row to the next row (row_bcast15, rows 1 and 3) and lane 31 to the upper half (row_bcast31)
+  const int lane = tid & 63, wave = tid >> 6;
+  int f = flags != 0;
+  double s = acc;
+#define CASK_SCAN_STEP(CTRL, ROWMASK)                                                                     \
+  do {                                                                                                    \
+    int lo = __double2loint(s), hi = __double2hiint(s);                                                   \
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);                                    \
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);                                    \
+    const int f2 = __builtin_amdgcn_update_dpp(0, f, CTRL, ROWMASK, 0xf, true);                           \
+    const double s2 = __hiloint2double(hi, lo);                                                           \
+    if (!f) s += s2;                                                                                      \
+    f |= f2;                                                                                              \
+  } while (0)
+  CASK_SCAN_STEP(0x111, 0xf);                                 // row_shr:1
+  CASK_SCAN_STEP(0x112, 0xf);                                 // row_shr:2
+  CASK_SCAN_STEP(0x114, 0xf);                                 // row_shr:4
+  CASK_SCAN_STEP(0x118, 0xf);                                 // row_shr:8
+  CASK_SCAN_STEP(0x142, 0xa);                                 // row_bcast15 -> rows 1, 3
+  CASK_SCAN_STEP(0x143, 0xc);                                 // row_bcast31 -> rows 2, 3
+#undef CASK_SCAN_STEP
+  if (lane == 63) {
+    wval[wave] = s;
+    wflag[wave] = f;
+  }
+  // what the lanes in front of this one leave (exclusive): lane - 1's inclusive pair (wave_shr:1; lane 0: identity)
+  const double es = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s), 0x138, 0xf, 0xf, true),
+                                     __builtin_amdgcn_update_dpp(0, __double2loint(s), 0x138, 0xf, 0xf, true));
+  const int ef = __builtin_amdgcn_update_dpp(0, f, 0x138, 0xf, 0xf, true);
+  __syncthreads();
+  if (flags) {                                                // this thread closes a row begun before its run
+    double carry = 0.0;                                       // what the waves in front leave
+    for (int w = 0; w < wave; w++) carry = wflag[w] ? wval[w] : carry + wval[w];
+    rsum[ord] = (ef ? es : carry + es) + head;
+  }
+  __syncthreads();
+  if (holes) {
+    const int n_ends = rmap[0];
+    for (int r = tid; r < n_ends; r += WG) y[d.row_start + rmap[1 + r]] = rsum[r];
+    if (!(d.kind_g & KIND_NOFILL))                            // (sub-matrix blocks: the other rows are somebody else's)
+      for (int r = tid; r < d.n_rows; r += WG)                // the block's empty rows (every y entry is written once)
+        if (rp[d.row_start + r] == rp[d.row_start + r + 1]) y[d.row_start + r] = 0.0;
+  } else {
+    for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = rsum[r];
+  }
+  CASK_STAMP(4);
+}
+
 // Column references of the plan's own column stream (plans with an x window; otherwise the caller's col_ind is
 // streamed as it is):  without SCAN_LDS_BIT: x[c];  with it: slot c & 0xffff of the block's x window in LDS.
 // r5: the x window SHARES the product area's LDS (it is dead once every thread holds its x values: one more barrier) --
@@ -216,83 +301,143 @@ __device__ __forceinline__ void scan_block(int hw_block, const BlockDesc *__rest
   __syncthreads();
   CASK_STAMP(3);
 
-  // ---- phase 2: thread-owned runs ---------------------------------------------------------------------------
-  const unsigned flags = mw & 0xffffu;
-  const int ord = (int)(mw >> 16);
-  const int k0 = tid * IPT;
-  const bool holes = (d.kind_g & KIND_HOLES) != 0;            // workgroup-uniform
-  const int *rmap = rowmap + d.aux;                           // holes: [number of non-empty rows, their local rows ...]
-  double p[IPT];
+  scan_row_sums<IPT>(d, lead, mw, prod, wval, wflag, rp, rowmap, y);
+}
+
+// ---- the descriptor out of the stream's way (r6) -----------------------------------------------------------------------
+// A block's first act used to be a cold 32-byte descriptor read, and its streams could not be requested before that read
+// had returned -- behind the streams every OTHER block had already queued: 3.2 us for the median workgroup of the
+// webbase2 launch, 7 us for the slowest tenth, of a 10.4 us life (profiles/r06_scan_pad.txt).  Here the plan owns PADDED
+// copies of the value and column streams: block b's nonzeros live at b * CAP .. (the rest of its CAP slots: value +0.0, a
+// column of its own -- blocks are cut at <= CAP - 1 nonzeros and snapped to rows of ~3, so 0.1 % is padding), every
+// stream address is a function of the block index, and the workgroup requests its streams and its row-end words AT
+// ENTRY, the descriptor alongside.  The descriptor is first needed for the x window (requested when it arrives, parked
+// when the streams ahead of it have landed: loads return in order) and for the rows at the very end.  No lead element, no
+// clamped pairs, no foreign halves: padded streams start on an even element and end inside the block's own slots.
+// Long-row pieces keep their descriptor-first path and sit BEHIND the regular blocks in the block list (hardware blocks
+// >= n_regular), so that "is this a long piece" is a comparison of the block index, not a field of the descriptor.
+// (The same idea LOST on the merge kernel in round 2 -- 8.21 -> 8.61 us on cant-like: there the descriptor trip is ~1 us
+// and the window / row-offset loads it gates are on the critical path.)
+template <int IPT, bool NT, int XP>
+__device__ __forceinline__ void scan_block_padded(int hw_block, const BlockDesc *__restrict__ blocks, int n_regular, int remap,
+                                                  int n_cols, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                  const double *__restrict__ val, const int *__restrict__ pci,
+                                                  const double *__restrict__ pval, const unsigned *__restrict__ meta,
+                                                  const int *__restrict__ rowmap, const double *__restrict__ x,
+                                                  double *__restrict__ y, double *__restrict__ partials) {
+  static_assert(IPT % 2 == 0 && IPT <= 16, "items per thread: even (16-byte loads), at most 16 (row-end bits)");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int WG = blockDim.x, CAP = WG * IPT, tid = threadIdx.x;
+  double *prod = reinterpret_cast<double *>(smem);
+  double *wval = prod + CAP + WG + 4;
+  int *wflag = reinterpret_cast<int *>(wval + 16);
+  static_assert(XP == 0 || 2 * XP <= IPT + 1, "the window must fit the product area");
+  double *xs = prod;
+  CASK_STAMP(0);
+  if (hw_block >= n_regular) {                                // a long-row piece (or a run of empty rows): descriptor first
+    const BlockDesc d = blocks[hw_block];
+    scan_long_piece<NT>(d, ci, val, x, y, partials, prod);
+    return;
+  }
+  const int lb = logical_block(hw_block, n_regular, remap);
+  // The descriptor as the FIRST VECTOR load of the wave (every lane the same 32 bytes: one request).  A scalar load would
+  // be the natural thing, but the compiler sinks it to its first use and waits there (`s_waitcnt lgkmcnt(0)` in the
+  // middle of the stream requests: scalar loads return out of order, so it cannot wait for less) -- a vector load issued
+  // first is simply the first to come back (vmcnt retires in order), and using it waits for nothing behind it.
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  int zero = 0;
+  asm volatile("" : "+v"(zero));                              // (opaque: keeps the address per-lane, i.e. the load a vector load)
+  const int4v *dp = reinterpret_cast<const int4v *>(blocks + lb) + zero;
+  const int4v dlo = dp[0], dhi = dp[1];
+  // streams and row-end words: addresses from the block index alone
+  const dbl2 *val2 = reinterpret_cast<const dbl2 *>(pval) + (size_t)lb * (CAP / 2);
+  const int2v *ci2 = reinterpret_cast<const int2v *>(pci) + (size_t)lb * (CAP / 2);
+  dbl2 v[IPT / 2];
+  int2v c[IPT / 2];
 #pragma unroll
-  for (int j = 0; j < IPT; j++) p[j] = prod[lead + 1 + (IPT + 1) * tid + j];
+  for (int u = 0; u < IPT / 2; u++) {
+    v[u] = stream_load<NT>(val2 + u * WG + tid);
+    c[u] = stream_load<NT>(ci2 + u * WG + tid);
+  }
+  const unsigned mw = stream_load<NT>(meta + (size_t)lb * WG + tid);
+  CASK_STAMP(1);
+  BlockDesc d;
+  d.row_start = __builtin_amdgcn_readfirstlane(dlo.x);
+  d.n_rows = __builtin_amdgcn_readfirstlane(dlo.y);
+  d.nnz_start = __builtin_amdgcn_readfirstlane(dlo.z);
+  d.nnz_count = __builtin_amdgcn_readfirstlane(dlo.w);
+  d.cmin = __builtin_amdgcn_readfirstlane(dhi.x);
+  d.cwidth = __builtin_amdgcn_readfirstlane(dhi.y);
+  d.kind_g = __builtin_amdgcn_readfirstlane(dhi.z);
+  d.aux = __builtin_amdgcn_readfirstlane(dhi.w);
+  if (XP > 0) {
+    const dbl2 *x2 = reinterpret_cast<const dbl2 *>(x);
+    const int p0 = d.cmin >> 1, plim = (n_cols - 1) >> 1;
+    dbl2 xw[XP > 0 ? XP : 1];
 #pragma unroll
-  for (int j = 0; j < IPT; j++)
-    if (k0 + j >= d.nnz_count) p[j] = 0.0;                    // behind the block's last nonzero
-  __syncthreads();                                            // every run is in registers: the product area is free
-  // row sums go to rsum[ordinal] (the product area again) and leave for y in one coalesced sweep at the end:
-  // stored from here, lane by lane, a block's ~700 row sums were ~90 partly filled store instructions per wave
-  // (3.8 of the launch's 27 us on the webbase-like matrix)
-  double *rsum = prod;
-  double acc = 0.0, head = 0.0;
-  int i = 0;
+    for (int u = 0; u < XP; u++) xw[u] = x2[min(p0 + min(u * WG + tid, max(d.cwidth / 2 - 1, 0)), plim)];   // unconditional, clamped
+    dbl2 *xs2 = reinterpret_cast<dbl2 *>(xs);
 #pragma unroll
-  for (int j = 0; j < IPT; j++) {
-    acc += p[j];
-    if ((flags >> j) & 1u) {
-      if (i == 0) head = acc;                                 // completes a row earlier threads may have begun
-      else rsum[ord + i] = acc;
-      i++;
-      acc = 0.0;
+    for (int u = 0; u < XP; u++)
+      if ((u * WG + tid) * 2 < d.cwidth) xs2[u * WG + tid] = xw[u];
+    __syncthreads();
+  }
+  dbl2 xv[IPT / 2];
+  if (XP > 0) {
+    int gx[IPT / 2], gy[IPT / 2];
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      gx[u] = (c[u].x & SCAN_LDS_BIT) ? d.cmin : c[u].x;
+      gy[u] = (c[u].y & SCAN_LDS_BIT) ? d.cmin : c[u].y;
+    }
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = x[gx[u]];
+      xv[u].y = x[gy[u]];
+    }
+    dbl2 xl[IPT / 2];
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xl[u].x = xs[(c[u].x & SCAN_LDS_BIT) ? (c[u].x & 0xffff) : 0];
+      xl[u].y = xs[(c[u].y & SCAN_LDS_BIT) ? (c[u].y & 0xffff) : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = (c[u].x & SCAN_LDS_BIT) ? xl[u].x : xv[u].x;
+      xv[u].y = (c[u].y & SCAN_LDS_BIT) ? xl[u].y : xv[u].y;
+    }
+    __syncthreads();                                          // every thread has its x values: the window's LDS is the products' now
+  } else {
+#pragma unroll
+    for (int u = 0; u < IPT / 2; u++) {
+      xv[u].x = x[c[u].x];
+      xv[u].y = x[c[u].y];
     }
   }
-  // segmented inclusive scan over the wave, (f, s) = (a row ends in lanes [.., lane], sum of the tails since), all
-  // in DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source read the identity: bound_ctrl),
-  // then lane 15 of each row to the next row (row_bcast15, rows 1 and 3) and lane 31 to the upper half (row_bcast31)
-  const int lane = tid & 63, wave = tid >> 6;
-  int f = flags != 0;
-  double s = acc;
-#define CASK_SCAN_STEP(CTRL, ROWMASK)                                                                     \
-  do {                                                                                                    \
-    int lo = __double2loint(s), hi = __double2hiint(s);                                                   \
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);                                    \
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);                                    \
-    const int f2 = __builtin_amdgcn_update_dpp(0, f, CTRL, ROWMASK, 0xf, true);                           \
-    const double s2 = __hiloint2double(hi, lo);                                                           \
-    if (!f) s += s2;                                                                                      \
-    f |= f2;                                                                                              \
-  } while (0)
-  CASK_SCAN_STEP(0x111, 0xf);                                 // row_shr:1
-  CASK_SCAN_STEP(0x112, 0xf);                                 // row_shr:2
-  CASK_SCAN_STEP(0x114, 0xf);                                 // row_shr:4
-  CASK_SCAN_STEP(0x118, 0xf);                                 // row_shr:8
-  CASK_SCAN_STEP(0x142, 0xa);                                 // row_bcast15 -> rows 1, 3
-  CASK_SCAN_STEP(0x143, 0xc);                                 // row_bcast31 -> rows 2, 3
-#undef CASK_SCAN_STEP
-  if (lane == 63) {
-    wval[wave] = s;
-    wflag[wave] = f;
-  }
-  // what the lanes in front of this one leave (exclusive): lane - 1's inclusive pair (wave_shr:1; lane 0: identity)
-  const double es = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s), 0x138, 0xf, 0xf, true),
-                                     __builtin_amdgcn_update_dpp(0, __double2loint(s), 0x138, 0xf, 0xf, true));
-  const int ef = __builtin_amdgcn_update_dpp(0, f, 0x138, 0xf, 0xf, true);
-  __syncthreads();
-  if (flags) {                                                // this thread closes a row begun before its run
-    double carry = 0.0;                                       // what the waves in front leave
-    for (int w = 0; w < wave; w++) carry = wflag[w] ? wval[w] : carry + wval[w];
-    rsum[ord] = (ef ? es : carry + es) + head;
+#ifdef CASK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CASK_STAMP(2);
+#endif
+  constexpr int SH = IPT == 2 ? 1 : IPT == 4 ? 2 : IPT == 8 ? 3 : 4;
+#pragma unroll
+  for (int u = 0; u < IPT / 2; u++) {
+    const int e = 2 * (u * WG + tid);
+    const dbl2 pr = v[u] * xv[u];
+    prod[e + ((e + IPT) >> SH)] = pr.x;
+    prod[e + 1 + ((e + 1 + IPT) >> SH)] = pr.y;
   }
   __syncthreads();
-  if (holes) {
-    const int n_ends = rmap[0];
-    for (int r = tid; r < n_ends; r += WG) y[d.row_start + rmap[1 + r]] = rsum[r];
-    if (!(d.kind_g & KIND_NOFILL))                            // (sub-matrix blocks: the other rows are somebody else's)
-      for (int r = tid; r < d.n_rows; r += WG)                // the block's empty rows (every y entry is written once)
-        if (rp[d.row_start + r] == rp[d.row_start + r + 1]) y[d.row_start + r] = 0.0;
-  } else {
-    for (int r = tid; r < d.n_rows; r += WG) y[d.row_start + r] = rsum[r];
-  }
-  CASK_STAMP(4);
+  CASK_STAMP(3);
+  scan_row_sums<IPT>(d, 0, mw, prod, wval, wflag, rp, rowmap, y);
+}
+
+template <int IPT, bool NT, int XP>
+__global__ void k_spmv_scan_pad(const BlockDesc *__restrict__ blocks, int n_regular, int remap, int n_cols,
+                                const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                const int *__restrict__ pci, const double *__restrict__ pval,
+                                const unsigned *__restrict__ meta, const int *__restrict__ rowmap,
+                                const double *__restrict__ x, double *__restrict__ y, double *__restrict__ partials) {
+  scan_block_padded<IPT, NT, XP>(blockIdx.x, blocks, n_regular, remap, n_cols, rp, ci, val, pci, pval, meta, rowmap, x, y, partials);
 }
 
 template <int IPT, bool NT, int XP>

@@ -10,6 +10,17 @@ static void launch_scan_ix(const ScanLaunch &l, const double *x, double *y, hipS
     (void)grid; (void)block; (void)x; (void)y; (void)s;
     return;
   } else {
+    if constexpr (IPT >= 8) {                                 // padded plans exist for 8 and 16 items per thread (cask_hip.hip build_scan_plan)
+      if (l.pad_val) {
+        if (l.nontemporal)
+          hipLaunchKernelGGL((k_spmv_scan_pad<IPT, true, XP>), grid, block, l.lds_bytes, s, l.blocks, l.n_regular, l.remap, l.n_cols,
+                             l.rp, l.ci, l.val, l.pad_ci, l.pad_val, l.meta, l.rowmap, x, y, l.partials);
+        else
+          hipLaunchKernelGGL((k_spmv_scan_pad<IPT, false, XP>), grid, block, l.lds_bytes, s, l.blocks, l.n_regular, l.remap, l.n_cols,
+                             l.rp, l.ci, l.val, l.pad_ci, l.pad_val, l.meta, l.rowmap, x, y, l.partials);
+        return;
+      }
+    }
     if (l.nontemporal)
       hipLaunchKernelGGL((k_spmv_scan<IPT, true, XP>), grid, block, l.lds_bytes, s, l.blocks, l.grid, l.remap, l.nnz, l.n_cols,
                          l.rp, l.ci, l.val, l.meta, l.rowmap, x, y, l.partials);

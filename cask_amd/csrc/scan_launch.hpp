@@ -20,6 +20,11 @@ struct ScanLaunch {
   const unsigned *meta;            // [block][thread] row-end words
   const int *rowmap;               // KIND_HOLES blocks: at blocks[b].aux the number of non-empty rows, then their local rows
   double *partials;                // long-row pieces of split rows
+  // padded plan (r6, scan_kernel.hpp scan_block_padded): the first n_regular blocks stream the plan's padded copies
+  // (block b at b * wg_size * items_per_thread), the long-row pieces behind them the arrays above; NULL = the unpadded plan
+  const int *pad_ci;
+  const double *pad_val;
+  int n_regular;
   // SLICE (n_slice_blocks > 0): `grid` nonzero-mapped blocks over the plan's copy of the long rows (blocks / ci / val /
   // meta / rowmap / nnz above describe THAT sub-matrix), then n_slice_blocks row-mapped blocks
   int n_slice_blocks, slice_k;

@@ -101,7 +101,7 @@ __global__ void k_spmv_slice(const BlockDesc *__restrict__ blocks, int n_scan, i
 // dst[i] = src[idx[i]]: the plan's copies of the value stream in slice / sub-matrix order (once per plan)
 __global__ void k_gather_f64(int64_t n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dst[i] = src[idx[i]];
+    dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.0;                   // (a padded stream's spare slots: index -1)
 }
 
 }  // namespace caskhip

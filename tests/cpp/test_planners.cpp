@@ -241,6 +241,36 @@ static void scan_plans(const Csr &a) {
       std::vector<int> rowmap;
       plan::build_scan_meta(a.rp.data(), blocks, wg, ipt, meta, rowmap);
       check_scan_words(a.rp.data(), blocks, wg, ipt, meta, rowmap, false);
+      {                                                       // the padded plan: regular blocks first, streams a function of the index
+        std::vector<BlockDesc> pb(blocks);
+        const int n_regular = plan::regular_blocks_first(pb);
+        CHECK(n_regular >= 0 && (size_t)n_regular <= pb.size());
+        for (size_t b = 0; b < pb.size(); b++) CHECK(((pb[b].kind_g & KIND_LONG) != 0) == ((int)b >= n_regular));
+        for (int b = 1; b < n_regular; b++) CHECK(pb[(size_t)b].row_start > pb[(size_t)b - 1].row_start);   // row order kept
+        std::vector<SplitRow> none;
+        check_blocks(a, pb, nullptr, splits, cap - 1, false, n_slots);                                   // still a partition
+        if (a.nnz() > 0 && (int64_t)n_regular * cap < (1LL << 28)) {
+          std::vector<int> pci, src;
+          plan::build_padded_streams(pb, n_regular, cap, a.ci.data(), nullptr, pci, src);
+          CHECK(pci.size() == (size_t)n_regular * cap + 2 && src.size() == (size_t)n_regular * cap);
+          std::vector<char> hit((size_t)a.nnz(), 0);
+          for (int b = 0; b < n_regular; b++)
+            for (int i = 0; i < cap; i++) {
+              const size_t at = (size_t)b * cap + i;
+              const int e = src[at];
+              if (i < pb[(size_t)b].nnz_count) {
+                CHECK(e == pb[(size_t)b].nnz_start + i && pci[at] == a.ci[(size_t)e]);
+                if (e >= 0 && e < a.nnz()) hit[(size_t)e]++;
+              } else {
+                CHECK(e == -1 && pci[at] >= 0 && pci[at] < a.m);                                         // padding: a real column, no source
+              }
+            }
+          for (const BlockDesc &d : pb)
+            if (d.kind_g & KIND_LONG)
+              for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++) hit[(size_t)k]++;
+          for (int64_t k = 0; k < a.nnz(); k++) CHECK(hit[(size_t)k] == 1);
+        }
+      }
       const int xp = plan::scan_window_xp(2048, wg, ipt);
       CHECK(xp == 0 || (2 * xp <= ipt + 1 && 2 * xp * wg <= 65536));
       if (xp > 0 && a.nnz() > 0) {
