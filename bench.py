@@ -1166,6 +1166,14 @@ def run_spmv(cx, weak):
             hx, hy = np.ascontiguousarray(x_host[:mats[0].n_cols]), np.zeros(mats[0].n_rows)
             lib, px, py = capi.load(), hx.ctypes.data_as(ctypes.c_void_p), hy.ctypes.data_as(ctypes.c_void_p)
             host_entry = {}
+            # (bench.py pins its own main thread for the MKL baseline -- OMP_PROC_BIND binds it when an OpenMP runtime starts;
+            # a client's thread is not pinned, so the pin is lifted for this measurement and put back afterwards)
+            pinned = os.sched_getaffinity(0)
+            try:
+                os.sched_setaffinity(0, range(os.cpu_count() or 1))
+            except OSError:
+                pass
+            host_entry["caller_cpus"] = len(os.sched_getaffinity(0))
             for mode in ("pageable", "auto"):
                 prev = capi.host_entry_mode(mode)
                 for _ in range(10):
@@ -1178,6 +1186,10 @@ def run_spmv(cx, weak):
                     best = min(best, (time.perf_counter() - t0) / 40)
                 capi.host_entry_mode(prev)
                 host_entry[mode + "_usec"] = round(best * 1e6, 1)
+            try:
+                os.sched_setaffinity(0, pinned)
+            except OSError:
+                pass
             host_entry["vector_bytes_each_way"] = int(8 * mats[0].n_cols)
             host_entry["note"] = ("cask_hip_spmv per call, best of 5 loops of 40, x and y allocated once: `pageable` = hipMemcpyAsync "
                                   "from / to the caller's memory (ABI <= 6), `auto` = the default (64 KiB .. 4 MiB of vectors: threaded "

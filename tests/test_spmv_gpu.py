@@ -128,8 +128,7 @@ def test_baseline_configs_full_size(name):
                dict(variant="merge_wave"), dict(variant="merge", wg_size=512, items_per_thread=8),
                dict(variant="vector", lanes_per_row=8, tile_width=-1), dict(variant="scan"),
                dict(variant="scan", tile_width=-1), dict(variant="scan", items_per_thread=4, wg_size=512, tile_width=4096),
-               dict(variant="slice"), dict(variant="slice", lanes_per_row=2, wg_size=512, items_per_thread=4, tile_width=-1),
-               dict(variant="slice", lanes_per_row=8, tile_width=2048)):
+               dict(variant="slice", lanes_per_row=2 if name.startswith("webbase") else 8, tile_width=2048)):
         m = capi.CsrMatrix.from_host(n, n, rp, ci, va, capi.make_params(**dp))
         y1, y2 = m.spmv(x1), m.spmv(x2)
         y12 = m.spmv(2.0 * x1 - 0.5 * x2)
@@ -638,7 +637,7 @@ def test_slice_plan_shapes_and_bits():
     of one nonzero carry the SAME BITS whatever K is; the plan reports K, the long rows' window, and a grid of nonzero-mapped
     + row-mapped workgroups; run to run bitwise reproducible; also as a captured graph with a changing operand."""
     import torch
-    n, rp, ci, va = synth.webbase2_like()
+    n, rp, ci, va = synth.small("webbase2", factor=4)            # 250 000 rows (the full size: test_baseline_configs_full_size)
     lens = np.diff(rp)
     x = np.random.default_rng(23).uniform(-1, 1, n)
     want = oracle.csr_spmv(rp, ci, va, x)
@@ -686,7 +685,7 @@ def test_vector_long_rows_take_the_long_row_path():
     """r6: the row-mapped VECTOR family hands rows of more than max(32, 16 L) nonzeros to long-row
     pieces (k_spmv_long + the fix-up for rows of several pieces), as the merge plans do -- it let L lanes walk a
     4 700-entry row before (260-300 us on the webbase look-alikes)."""
-    n, rp, ci, va = synth.webbase_like()
+    n, rp, ci, va = synth.small("webbase-1M", factor=2)
     lens = np.diff(rp)
     x = np.random.default_rng(24).uniform(-1, 1, n)
     want = oracle.csr_spmv(rp, ci, va, x)

@@ -56,8 +56,9 @@ for arch in doc["best_architectures"]:
         gbs = b / arch["measured_usec"] * 1e-3
         arch["hbm_gbs_measured"] = round(gbs, 1)
         arch["pct_hbm_peak_measured"] = round(100.0 * gbs / 8000.0, 2)
+    factor = t["calibration"].get("factor")
     arch["traffic_method"] = ("rocprofv3 --pmc, three separate passes at this design point: FETCH_SIZE x calibration factor "
-                              f'{t["calibration"]["factor"]:.4f} + WRITE_SIZE; cross-check: L2->memory read requests by size')
+                              f'{factor if factor is None else round(factor, 4)} + WRITE_SIZE; cross-check: L2->memory read requests by size')
 out.write_text(json.dumps(doc, indent=2))
 for a in doc["best_architectures"]:
     print(a["matrices"][0], a["name"], a["measured_usec"], "us  algorithmic", a["measured_gbs_algorithmic"], "GB/s  measured",

@@ -45,7 +45,7 @@ res = {"tag": tag, "calibration": {"kernel": "k_oneshot<8,true> (tools/membench.
                                                                         64 * cal_sizes["TCC_EA0_RDREQ_64B_sum"] +
                                                                         128 * cal_sizes["TCC_EA0_RDREQ_128B_sum"])
                                                                   if all(v is not None for v in cal_sizes.values()) else None)}}
-for kern in ("k_spmv_merge<", "k_spmv_scan<", "k_spmv_vector2<", "k_spmv_vector<", "k_spmv_merge_wave<"):
+for kern in ("k_spmv_merge<", "k_spmv_scan_pad<", "k_spmv_scan<", "k_spmv_slice<", "k_spmv_vector2<", "k_spmv_vector<", "k_spmv_merge_wave<"):
     f, nf = counter(f"pmc_{tag}_{workload}{suffix}_FETCH_SIZE", kern, "FETCH_SIZE")
     w, nw = counter(f"pmc_{tag}_{workload}{suffix}_WRITE_SIZE", kern, "WRITE_SIZE")
     if f is None:
