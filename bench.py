@@ -551,6 +551,13 @@ def rccl_census(cx, dist, capi, local_rank):
             print(f"[bench] {world} ranks on {info['distinct_device_indices']} distinct devices ({devices}): refusing to time a "
                   "multi-GPU run that is not one (set CASK_BENCH_SHARE_DEVICE=1 for a dry run on a shared device)",
                   file=sys.stderr, flush=True)
+        # an orderly end on EVERY rank (all of them hold the same gathered `info`): a rank that simply exits while a peer's
+        # gloo threads still hold its sockets can make that peer abort (SIGABRT instead of status 4: seen once in r6)
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
         raise SystemExit(EXIT_NOT_DISTINCT)
     return info
 

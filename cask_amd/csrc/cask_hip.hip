@@ -1810,7 +1810,10 @@ int cask_hip_tune(cask_hip_matrix *m, const int32_t *variants, int32_t n_variant
   for (size_t oi = 0; oi < order.size(); oi++) {
     Cand &c = cands[order[oi]];
     const int f = c.family;
-    if (prune && oi >= n_prior && fam_points[f] >= 2 && best >= 0 && fam_best[f] > 1.5 * best_us) {
+    // (SLICE -- a measured loss on every matrix of round 6, and a host sort per point -- goes when its two best guesses are 10 %
+    // behind, the other families at 50 %)
+    const double behind = f == (CASK_HIP_VARIANT_SLICE & 7) ? 1.10 : 1.5;
+    if (prune && oi >= n_prior && fam_points[f] >= 2 && best >= 0 && fam_best[f] > behind * best_us) {
       // ... unless the family is still on its way down: its latest point beat everything it had by > 10 %
       const bool improving = fam_last[f] == fam_best[f] && fam_prev_best[f] > 0 && fam_last[f] < 0.9 * fam_prev_best[f];
       if (!improving) continue;                               // stays valid = 0, usec = -1
