@@ -81,7 +81,7 @@ struct Plan {
   DevBuf<unsigned short> ci16;     // MERGE with an x tile: LDS slot of each nonzero's column (2 B/nnz), or
   bool packed12 = false;           //   12-byte records of eight 12-bit slots per thread, [block][thread] (1.5 B/nnz)
   double slot_bytes_per_nnz = 0.0; //   what the slot stream costs (reported)
-  DevBuf<int> xchunk;              // MERGE with ci16: first column of each 64-column tile chunk, maxch per block
+  DevBuf<int> xchunk;              // MERGE with ci16: first column of each 16-column tile chunk, maxch per block, [t >> 4][u] (plan::build_chunk_table)
   bool one_window = false;         // every tiled block's chunks are consecutive (KIND_CONTIG): paired window loads
   int maxch = 0;
   bool any_skew = false;           // MERGE: some block is flagged KIND_SKEW (selects the kernel with the second pass)
@@ -536,7 +536,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
       const int max_slots = std::min(tile, xu_cap * prm.wg_size);
       std::vector<std::vector<int>> chunk_starts;
       std::vector<unsigned short> ci16;
-      plan::build_chunk_tiles(m.h_ci.data(), m.nnz, blocks, max_slots / 64, chunk_starts, ci16);
+      plan::build_chunk_tiles(m.h_ci.data(), m.nnz, blocks, max_slots, chunk_starts, ci16);
       pl.prm.far_columns = -1;
       if (m.halo_addr) plan::place_seam_blocks(m.h_ci.data(), m.halo_n_own, blocks, chunk_starts, prm.xcd_remap > 0);
       int max_used = 0;                                       // slots of the fullest tile
@@ -546,11 +546,10 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
         int xu = 1;
         while (xu * prm.wg_size < max_used) xu *= 2;
         pl.xu = xu;
-        pl.maxch = xu * prm.wg_size / 64;
+        pl.maxch = xu * prm.wg_size / plan::TILE_SUB;
         pl.prm.tile_width = xu * prm.wg_size;
-        std::vector<int> xchunk((size_t)pl.grid * pl.maxch, 0);
-        for (size_t b = 0; b < chunk_starts.size(); b++)
-          std::copy(chunk_starts[b].begin(), chunk_starts[b].end(), xchunk.begin() + b * pl.maxch);
+        std::vector<int> xchunk;
+        plan::build_chunk_table(blocks, chunk_starts, prm.wg_size, xu, xchunk);
         HIP_TRY(pl.xchunk.upload(xchunk));
         pl.one_window = true;
         for (const BlockDesc &d : blocks)

@@ -231,10 +231,45 @@ __device__ __forceinline__ void pass_own_rows(const SolverPass &sp, const PassSc
   }
 }
 
+// Chunked tiles: the first columns of the 16-column chunks a WAVE loads -- 4 lane groups x XU turns, consecutive in the
+// block's table ([tid >> 4][u]: plan::build_chunk_table).  merge_workgroup fetches them with scalar loads NEXT TO the
+// descriptor's (one wait for both: behind the descriptor they were a second dependent trip at the head of every
+// workgroup, +5-7 % on the atmosmodd-like launch); a lane picks its group's entry with masks, not selects -- selects of
+// loaded values made the compiler branch per lane group and wait in every branch.
+template <int XU>
+struct ChunkTab {
+  static constexpr int N = XU > 0 ? XU : 1;
+  int e[4 * N];
+};
+template <int XU>
+__device__ __forceinline__ void chunk_table_fetch(const int *__restrict__ my_chunks, int tid, ChunkTab<XU> &tab) {
+  constexpr int N = ChunkTab<XU>::N;
+  const int *t = my_chunks + __builtin_amdgcn_readfirstlane(tid >> 6) * 4 * N;   // wave-uniform: scalar loads
+#pragma unroll
+  for (int i = 0; i < 4 * N; i++) tab.e[i] = t[i];
+}
+// (keeps the fetch where it was written: the values exist here, i.e. the loads were issued above)
+template <int XU>
+__device__ __forceinline__ void chunk_table_pin(ChunkTab<XU> &tab) {
+  constexpr int N = ChunkTab<XU>::N;
+#pragma unroll
+  for (int i = 0; i < 4 * N; i += 4)
+    asm volatile("" : "+s"(tab.e[i]), "+s"(tab.e[i + 1]), "+s"(tab.e[i + 2]), "+s"(tab.e[i + 3]));
+}
+template <int XU>
+__device__ __forceinline__ void chunk_starts_of(const ChunkTab<XU> &tab, int tid, int (&st)[XU > 0 ? XU : 1]) {
+  constexpr int N = ChunkTab<XU>::N;
+  const int g = (tid >> 4) & 3;
+  const int m0 = -(int)(g == 0), m1 = -(int)(g == 1), m2 = -(int)(g == 2), m3 = -(int)(g == 3);
+#pragma unroll
+  for (int u = 0; u < N; u++)
+    st[u] = (tab.e[u] & m0) | (tab.e[N + u] & m1) | (tab.e[2 * N + u] & m2) | (tab.e[3 * N + u] & m3);
+}
+
 template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SEAM, int EXT, bool ALIAS>
 __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                            const int *__restrict__ rp, const int *__restrict__ ci,
-                                           const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                           const unsigned *__restrict__ ci16, const ChunkTab<XU> &xchunk,
                                            const double *__restrict__ val, const double *__restrict__ x,
                                            double *prod, int *roff, double *xs, const XHalo &halo,
                                            const double *__restrict__ w, double *wl, int lb,
@@ -254,22 +289,22 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
   // one valid element cannot cross a page, so it is memory-safe).
   const int npairs = (total + 1) >> 1;
 
-  // x tile.  With 16-bit indices the tile is a SET of column ranges cut into 64-column chunks
-  // (xchunk[c] = first column of chunk c; built on the host): chunk c = u*(WG/64) + wave lands in
-  // LDS slots [64c, 64c+64), and a nonzero's 16-bit index is its slot.  One contiguous window is
-  // the special case of consecutive chunks; stencil-like matrices (a few narrow bands far apart)
-  // fit the same way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
+  // x tile.  With 16-bit indices the tile is either ONE window [cmin, cmin + cwidth) (KIND_CONTIG) or the SET of
+  // 128-byte lines of x the block touches: 16-column chunks (their first columns in the block's table, built on the
+  // host: plan::build_chunk_tiles / build_chunk_table); chunk s = u*(WG/16) + (tid >> 4) lands in LDS slots
+  // [16 s, 16 s + 16), and a nonzero's 16-bit index is its slot -- stencil-like matrices (a few narrow bands far apart)
+  // and stray columns fit that way.  Without 16-bit indices the tile is the contiguous window [cmin, cmin+cwidth).
   double xw[XU > 0 ? XU : 1];
   double xb[(COMP && XU > 0) ? XU : 1];                       // COMP: the same entries of the second operand
   uint64_t xsrc[XU > 0 ? XU : 1];
   if (XU > 0) {
     if (SEAM) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
       const bool chunked = C16 && !(d.kind_g & KIND_CONTIG);
-      int col[XU > 0 ? XU : 1];
+      int col[XU > 0 ? XU : 1], st[XU > 0 ? XU : 1];
+      if (chunked) chunk_starts_of<XU>(xchunk, tid, st);      // workgroup-uniform
 #pragma unroll
       for (int u = 0; u < XU; u++) {
-        col[u] = min(chunked ? xchunk[u * wpw + wave] + lane : d.cmin + u * WG + tid, n_cols - 1);
+        col[u] = min(chunked ? st[u] + (tid & 15) : d.cmin + u * WG + tid, n_cols - 1);
         xsrc[u] = halo_entry(col[u], halo);
       }
 #pragma unroll
@@ -297,10 +332,11 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
         }
       }
     } else if (C16 && !(d.kind_g & KIND_CONTIG)) {            // workgroup-uniform
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, wpw = WG >> 6;
+      int st[XU > 0 ? XU : 1];
+      chunk_starts_of<XU>(xchunk, tid, st);
 #pragma unroll
       for (int u = 0; u < XU; u++) {
-        const int c = min(xchunk[u * wpw + wave] + lane, xlim);
+        const int c = min(st[u] + (tid & 15), xlim);
         xw[u] = x[c];
         if (COMP) xb[COMP ? u : 0] = x[c + sp.b_off];
       }
@@ -503,7 +539,7 @@ __device__ __forceinline__ void merge_load(const BlockDesc &d, int n_cols, int x
 template <int IPT, int XU, bool NT, bool C16, bool C12, bool WIDE, bool SKEW, int EXT, bool ALIAS>
 __device__ __forceinline__ void merge_block(const BlockDesc &d, int n_cols, int xlim, int max_gpair,
                                             const int *__restrict__ rp, const int *__restrict__ ci,
-                                            const unsigned *__restrict__ ci16, const int *__restrict__ xchunk,
+                                            const unsigned *__restrict__ ci16, const ChunkTab<XU> &xchunk,
                                             const double *__restrict__ val, const double *__restrict__ x,
                                             double *__restrict__ y, double *prod, int *roff, double *xs, double *wl,
                                             const XHalo &halo, const DotEpilogue &dot, int lb,
@@ -590,8 +626,12 @@ __device__ __forceinline__ void merge_workgroup(int hw_block, const BlockDesc *_
 
   CASK_STAMP(0);
   const int lb = logical_block(hw_block, n_blocks, remap);
+  ChunkTab<XU> tab = {};
+  constexpr bool CHUNKED = C16 && !WIDE && XU > 0;            // WIDE plans: every tiled block is a window
+  if (CHUNKED) chunk_table_fetch<XU>(xchunk + (size_t)lb * maxch, tid, tab);
   const BlockDesc d = blocks[lb];
-  const int *my_chunks = C16 ? xchunk + (size_t)lb * maxch : nullptr;
+  if (CHUNKED) chunk_table_pin<XU>(tab);
+  const ChunkTab<0> no_tab = {};
 
   const SolverPass sp = pass_of(pass_arg);                    // EXT < 2: all zeros, every use folds away
   PassScalars ps{0.0, 0.0, false, false};
@@ -689,10 +729,10 @@ __device__ __forceinline__ void merge_workgroup(int hw_block, const BlockDesc *_
   const int xlim = (EXT ? min(n_cols, halo.n_own) : n_cols) - 1;
   const bool tiled = XU > 0 && d.cwidth > 0 && d.cwidth <= XU * WG;   // workgroup-uniform
   if (tiled) {
-    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, XU, NT, C16, C12, WIDE, SKEW, EXT, ALIAS>(d, n_cols, xlim, max_gpair, rp, ci, ci16, tab, val, x, y, prod, roff,
                                                                xs, wl, halo, dot, lb, sp, ps);
   } else {
-    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, my_chunks, val, x, y, prod, roff,
+    merge_block<IPT, 0, NT, false, false, false, SKEW, EXT, false>(d, n_cols, xlim, max_gpair, rp, ci, ci16, no_tab, val, x, y, prod, roff,
                                                             xs, wl, halo, dot, lb, sp, ps);
   }
   CASK_STAMP(5);

@@ -117,10 +117,16 @@ inline void build_merge_blocks(const int *rp, int n_rows, int cap, int max_rows,
 }
 
 // x tile as a set of column ranges: for every block collect the distinct columns it references, join
-// columns closer than GAP into ranges, cut the ranges into 64-column chunks.  A block whose chunks
-// fit `max_chunks` is "tiled": its nonzeros get 16-bit LDS slot indices (chunk*64 + offset) and its
-// chunk start columns go to chunk_starts.  d.cwidth = slots used (0 = not tiled).
-inline void build_chunk_tiles(const int *ci, int64_t nnz, std::vector<BlockDesc> &blocks, int max_chunks,
+// columns closer than GAP into ranges, cut the ranges into 64-column chunks.  A block whose chunks are ONE run of
+// consecutive chunks is a window (KIND_CONTIG: the kernel computes its addresses from cmin; chunk_starts holds the
+// 64-column starts).  Any other block (r6) gets the set of 128-byte LINES of x it touches instead: 16-column chunks on
+// multiples of 16 (TILE_SUB), chunk_starts holds their starts -- a stray column then costs one line of x, not the four
+// of a 64-column chunk: on the G3_circuit-like matrix (a 5-point grid + 1 % random long-range edges: ~8 stray columns
+// in a block of ~400 rows) the windows of a launch shrink from 28.6 to 16.3 MB of distinct lines, 12 of the launch's
+// 128 MB (tools/chunk_model.py; measured: DESIGN.md section 5).  A block whose chunks fit `max_slots` is "tiled": its
+// nonzeros get 16-bit LDS slot indices (chunk * width + offset).  d.cwidth = slots used (0 = not tiled).
+constexpr int TILE_SUB = 16;
+inline void build_chunk_tiles(const int *ci, int64_t nnz, std::vector<BlockDesc> &blocks, int max_slots,
                               std::vector<std::vector<int>> &chunk_starts, std::vector<unsigned short> &ci16) {
   constexpr int GAP = 32;
   ci16.assign((size_t)nnz + 8, 0);
@@ -143,21 +149,48 @@ inline void build_chunk_tiles(const int *ci, int64_t nnz, std::vector<BlockDesc>
         for (int c = uniq[i] & ~1; c <= uniq[j]; c += 64) starts.push_back(c);   // even starts: the kernel loads the tile in 16-byte pairs
         i = j + 1;
       }
-      if ((int)starts.size() > max_chunks) continue;          // does not fit: the block gathers from L2
-      d.cmin = starts.empty() ? 0 : starts.front();
-      d.cwidth = (int)starts.size() * 64;
       bool contiguous = !starts.empty();
       for (size_t c = 1; c < starts.size(); c++) contiguous = contiguous && starts[c] == starts[c - 1] + 64;
+      int width = 64;
+      if (!contiguous) {                                      // the lines of x the block touches
+        width = TILE_SUB;
+        starts.clear();
+        for (int c : uniq)
+          if (starts.empty() || (c & ~(TILE_SUB - 1)) != starts.back()) starts.push_back(c & ~(TILE_SUB - 1));
+      }
+      if ((int)starts.size() * width > max_slots) continue;   // does not fit: the block gathers from L2
+      d.cmin = starts.empty() ? 0 : starts.front();
+      d.cwidth = (int)starts.size() * width;
       if (contiguous) d.kind_g |= KIND_CONTIG;
       for (int k = k0; k < k1; k++) {
         const int c = ci[k];
         const int idx = (int)(std::upper_bound(starts.begin(), starts.end(), c) - starts.begin()) - 1;
-        ci16[k] = (unsigned short)(idx * 64 + (c - starts[idx]));
+        ci16[k] = (unsigned short)(idx * width + (c - starts[idx]));
       }
       chunk_starts[b] = starts;
     }
   };
   for_block_ranges(blocks.size(), nnz, work);
+}
+
+// The chunk table of a tiled merge plan as the kernel reads it (merge_load): slot u * wg + t of a block's window belongs
+// to 16-column chunk s = u * (wg / 16) + (t >> 4); a thread fetches the starts of ITS xu chunks with one or two 16-byte
+// loads, so the table is stored [t >> 4][u].  Chunks a block does not use repeat its first one (their loads hit a line
+// the block reads anyway).  Windows (KIND_CONTIG) and untiled blocks leave their part of the table unread.
+inline void build_chunk_table(const std::vector<BlockDesc> &blocks, const std::vector<std::vector<int>> &chunk_starts, int wg,
+                              int xu, std::vector<int> &table) {
+  const int groups = wg / TILE_SUB, per_block = groups * xu;
+  table.assign(blocks.size() * (size_t)per_block, 0);
+  for (size_t b = 0; b < blocks.size(); b++) {
+    const BlockDesc &d = blocks[b];
+    if ((d.kind_g & (KIND_LONG | KIND_CONTIG)) || d.cwidth <= 0) continue;
+    const std::vector<int> &st = chunk_starts[b];
+    int *t = table.data() + b * (size_t)per_block;
+    for (int s = 0; s < per_block; s++) {
+      const int u = s / groups, g = s % groups;
+      t[g * xu + u] = s < (int)st.size() ? st[(size_t)s] : st[0];
+    }
+  }
 }
 
 // 12-bit packed slots for the IPT = 8 merge kernel: record (b*wg + t) holds the eight slots thread t of block b

@@ -138,19 +138,50 @@ static void merge_plans(const Csr &a) {
         std::vector<BlockDesc> tb(blocks);
         std::vector<std::vector<int>> chunk_starts;
         std::vector<unsigned short> ci16;
-        plan::build_chunk_tiles(a.ci.data(), a.nnz(), tb, tile / 64, chunk_starts, ci16);
+        plan::build_chunk_tiles(a.ci.data(), a.nnz(), tb, tile, chunk_starts, ci16);
         CHECK(ci16.size() == (size_t)a.nnz() + 8 && chunk_starts.size() == tb.size());
+        int max_used = 0;
         for (size_t b = 0; b < tb.size(); b++) {
           const BlockDesc &d = tb[b];
           if ((d.kind_g & KIND_LONG) || d.cwidth == 0) continue;
-          CHECK(d.cwidth <= tile && d.cwidth == 64 * (int)chunk_starts[b].size() && (d.cmin & 1) == 0);
+          max_used = std::max(max_used, d.cwidth);
+          // a window: 64-column chunks from an even column; anything else: the 16-column lines of x the block touches
+          const int width = (d.kind_g & KIND_CONTIG) ? 64 : plan::TILE_SUB;
+          CHECK(d.cwidth <= tile && d.cwidth == width * (int)chunk_starts[b].size() && (d.cmin & 1) == 0);
+          std::vector<char> used(chunk_starts[b].size(), 0);
           for (int k = d.nnz_start; k < d.nnz_start + d.nnz_count; k++) {
             const int slot = ci16[(size_t)k];
             CHECK(slot < d.cwidth);
-            if (slot < d.cwidth) CHECK(chunk_starts[b][(size_t)slot / 64] + slot % 64 == a.ci[(size_t)k]);
+            if (slot < d.cwidth) {
+              CHECK(chunk_starts[b][(size_t)(slot / width)] + slot % width == a.ci[(size_t)k]);
+              used[(size_t)(slot / width)] = 1;
+            }
           }
           if (d.kind_g & KIND_CONTIG)
             for (size_t c = 0; c < chunk_starts[b].size(); c++) CHECK(chunk_starts[b][c] == d.cmin + 64 * (int)c);
+          else
+            for (size_t c = 0; c < chunk_starts[b].size(); c++) {   // lines: aligned, ascending, every one of them needed
+              CHECK(chunk_starts[b][c] % plan::TILE_SUB == 0 && used[c]);
+              if (c) CHECK(chunk_starts[b][c] > chunk_starts[b][c - 1]);
+            }
+        }
+        if (max_used > 0 && wg >= plan::TILE_SUB) {           // the table as merge_load reads it: thread t, turn u -> slot u * wg + t
+          int xu = 1;
+          while (xu * wg < max_used) xu *= 2;
+          std::vector<int> table;
+          plan::build_chunk_table(tb, chunk_starts, wg, xu, table);
+          const int per_block = xu * wg / plan::TILE_SUB;
+          CHECK(table.size() == tb.size() * (size_t)per_block);
+          for (size_t b = 0; b < tb.size(); b++) {
+            const BlockDesc &d = tb[b];
+            if ((d.kind_g & (KIND_LONG | KIND_CONTIG)) || d.cwidth == 0) continue;
+            for (int u = 0; u < xu; u++)
+              for (int t = 0; t < wg; t++) {
+                const int slot = u * wg + t, got = table[b * (size_t)per_block + (size_t)(t >> 4) * xu + u] + (t & 15);
+                const size_t s = (size_t)slot / plan::TILE_SUB;
+                CHECK(got == (s < chunk_starts[b].size() ? chunk_starts[b][s] : chunk_starts[b][0]) + slot % plan::TILE_SUB);
+              }
+          }
         }
         if (ipt == 8 && tile <= 4096) {
           std::vector<unsigned short> packed;
@@ -188,7 +219,7 @@ static void merge_plans(const Csr &a) {
         for (const BlockDesc &d : sb) after.insert(((long)d.row_start << 32) | (unsigned)d.nnz_start);
         CHECK(before == after);
         for (size_t b = 0; b < sb.size(); b++)
-          if (!(sb[b].kind_g & KIND_LONG) && sb[b].cwidth > 0) CHECK((int)cs[b].size() * 64 == sb[b].cwidth);
+          if (!(sb[b].kind_g & KIND_LONG) && sb[b].cwidth > 0) CHECK((int)cs[b].size() * ((sb[b].kind_g & KIND_CONTIG) ? 64 : plan::TILE_SUB) == sb[b].cwidth);
       }
       // the pipelined plan: long pieces in their own list
       std::vector<BlockDesc> wb, wl;
