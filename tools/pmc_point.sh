@@ -14,7 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE RDREQ; do
   ctr=$c
   if [ $c = RDREQ ]; then ctr="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; fi
-  [ -d $out/pmc_${tag}_calib_$c ] || rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
+  # (the calibration of this tag is reused only while its counter file is there: tools/profile_round.sh deletes the CSVs it has summarised)
+  [ -n "$(find $out/pmc_${tag}_calib_$c -name '*counter_collection.csv' 2>/dev/null | head -n 1)" ] || rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
   rm -rf $out/pmc_${tag}_${w}_${label}_$c
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_${label}_$c -- python3 $root/bench.py --workload $w --steps 40 --warmup 10 --launch eager --no-cpu-baseline --no-others "$@" > /dev/null 2> $out/pmc_${tag}_${w}_${label}_$c.err
 done
