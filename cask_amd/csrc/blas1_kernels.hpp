@@ -15,6 +15,20 @@ namespace caskhip {
 
 constexpr int BLAS_WG = 256;
 constexpr int BLAS_MAX_PARTIALS = 1024;
+// Pairs a lane of an update launch requests before it waits for the scalars (the launches' common shape: below), by the
+// number of vectors the launch walks -- every one of them has to stay within 128 VGPRs: 4 waves per SIMD, i.e. the
+// whole 1 024-workgroup grid resident at once.
+constexpr int UPD_AHEAD = 4, UPD_AHEAD_4V = 3, UPD_AHEAD_5V = 3;
+// The launches of a solver (r6): SOLVER_GRID_MAX workgroups of SOLVER_WG threads -- one workgroup per CU of an MI355X, 16
+// waves each.  Every workgroup of an update launch starts by adding up ALL the partial sums the launch before it left
+// (fixed order: no atomics, no extra launch), i.e. every workgroup reads the same few KB through the same L2 channels:
+// with 1 024 workgroups of 256 threads the 3 888 sums of a G3_circuit-like product launch were 31 KB x 1 024 readers
+// (~2 us at the head of k_cg_update_r: 9.2 us for bytes that stream in 6.8); a quarter of the readers, and a quarter
+// of the sums for the launch that follows.
+constexpr int SOLVER_WG = 1024, SOLVER_GRID_MAX = 256;
+// Partial sums a lane requests ahead of everything, in 16-byte pairs: an update launch leaves <= SOLVER_GRID_MAX (1 pair a
+// lane), a product launch one per workgroup (the BASELINE matrices: 1 958 ... 4 314 = 3 pairs a lane of 1 024).
+constexpr int SUMS_OF_UPDATE = 1, SUMS_OF_PRODUCT = 3;
 
 __device__ __forceinline__ double wg_sum(double v, double *red) {
   v = group_sum<64>(v);
@@ -194,6 +208,19 @@ __device__ __forceinline__ void store_one(double *p, double v, int sys_scope) {
   else *p = v;
 }
 
+// The four update launches of a classic pass share one shape (r6):
+//   * a lane's first UPD_AHEAD pairs are requested BEFORE the scalars are waited for.  The scalars are sums of partial
+//     sums (a dependent L2 round trip + a workgroup reduction at the head of every workgroup, ~1 us); the vector loads
+//     do not depend on them -- and a pair requested only once alpha is known is one more dependent trip: with 1 024
+//     workgroups a lane of the G3_circuit-like system owns 3 pairs, and with only the first one ahead (r4)
+//     k_cg_update_r took 9.2 us for bytes that stream in 6.8.  Loads are unconditional with clamped indices (a load
+//     under a condition whose result is merged with a default makes the compiler wait at the merge), all inside the
+//     one launch-uniform branch `n2 > 0`: nothing is loaded from a vector that has no pair.
+//   * same pairs in the same order as the plain grid-stride loop: the sums have the same bits.
+#define CASK_UPD_INDEX                                                                                                \
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x, last = n2 - 1;                                 \
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x
+
 // CG, second launch of a pass: alpha = rsold / (p.Ap) ; r -= alpha Ap ; shares of r.r
 // (SparseLinearSolvers.hpp:208, 212, 218).  x += alpha p (:210) is applied by the next product launch, which
 // reads p anyway; alpha is left in *alpha_out for it.
@@ -206,34 +233,39 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
   const dbl2 *Ap2 = reinterpret_cast<const dbl2 *>(Ap);
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r);
   const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: the shares are of r.z with z = dinv * r (never stored)
-  // every lane's first pair is requested BEFORE the partial sums are waited for: the sums are a dependent L2 round
-  // trip at the head of every workgroup (~1 us), the vector loads do not depend on alpha
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));
-  const dbl2 zero2 = {0.0, 0.0};
-  const dbl2 av0 = n2 ? Ap2[i0] : zero2;
-  const dbl2 rv0 = n2 ? r2[i0] : zero2;
-  dbl2 dv0 = zero2;
-  if constexpr (JAC) dv0 = n2 ? d2[i0] : zero2;
-  const double alpha = *rsold / partials_or_scalar(part_pAp, n_part, red);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (bool first = true; i < n2; i += stride, first = false) {
-    const dbl2 av = first ? av0 : Ap2[i];
-    dbl2 rv = first ? rv0 : r2[i];
-    rv.x = fma(-alpha, av.x, rv.x);
-    rv.y = fma(-alpha, av.y, rv.y);
-    store_pair(r2 + i, rv, sys_scope);
-    if constexpr (JAC) {
-      const dbl2 dv = first ? dv0 : d2[i];
-      acc0 = fma(rv.x, rv.x * dv.x, acc0);
-      acc1 = fma(rv.y, rv.y * dv.y, acc1);
-    } else {
-      acc0 = fma(rv.x, rv.x, acc0);
-      acc1 = fma(rv.y, rv.y, acc1);
+  CASK_UPD_INDEX;
+  double alpha, acc0 = 0.0, acc1 = 0.0;
+  const PartialsAhead<SUMS_OF_PRODUCT> sums = partials_request<SUMS_OF_PRODUCT>(part_pAp, n_part);
+  if (n2 > 0) {
+    dbl2 av[UPD_AHEAD], rv[UPD_AHEAD], dv[JAC ? UPD_AHEAD : 1];
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD; k++) {
+      const int64_t j = min(i + k * stride, last);
+      av[k] = Ap2[j];
+      rv[k] = r2[j];
+      if constexpr (JAC) dv[k] = d2[j];
     }
+    alpha = *rsold / partials_finish(sums, part_pAp, n_part, red);
+    auto one = [&](int64_t j, dbl2 a, dbl2 rr, dbl2 d) {
+      rr.x = fma(-alpha, a.x, rr.x);
+      rr.y = fma(-alpha, a.y, rr.y);
+      store_pair(r2 + j, rr, sys_scope);
+      if constexpr (JAC) {
+        acc0 = fma(rr.x, rr.x * d.x, acc0);
+        acc1 = fma(rr.y, rr.y * d.y, acc1);
+      } else {
+        acc0 = fma(rr.x, rr.x, acc0);
+        acc1 = fma(rr.y, rr.y, acc1);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD; k++)
+      if (i + k * stride < n2) one(i + k * stride, av[k], rv[k], dv[JAC ? k : 0]);
+    for (int64_t j = i + UPD_AHEAD * stride; j < n2; j += stride) one(j, Ap2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
+  } else {
+    alpha = *rsold / partials_finish(sums, part_pAp, n_part, red);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   if (owns_tail(n)) {
     const double rn = fma(-alpha, Ap[n - 1], r[n - 1]);
     store_one(r + (n - 1), rn, sys_scope);
@@ -253,28 +285,40 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
   if (*done) return;
   const dbl2 *q2 = reinterpret_cast<const dbl2 *>(q), *qt2 = reinterpret_cast<const dbl2 *>(qt);
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
-  const dbl2 zero2 = {0.0, 0.0};
-  const dbl2 qv0 = n2 ? q2[i0] : zero2, qtv0 = n2 ? qt2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2, rtv0 = n2 ? rt2[i0] : zero2;
-  const double alpha = *rho / partials_or_scalar(part_ptq, n_part, red);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
-  double a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
-  for (bool first = true; i < n2; i += stride, first = false) {
-    const dbl2 qv = first ? qv0 : q2[i], qtv = first ? qtv0 : qt2[i];
-    dbl2 rv = first ? rv0 : r2[i], rtv = first ? rtv0 : rt2[i];
-    rv.x = fma(-alpha, qv.x, rv.x);
-    rv.y = fma(-alpha, qv.y, rv.y);
-    rtv.x = fma(-alpha, qtv.x, rtv.x);
-    rtv.y = fma(-alpha, qtv.y, rtv.y);
-    store_pair(r2 + i, rv, sys_scope);
-    store_pair(rt2 + i, rtv, sys_scope);
-    a_rr0 = fma(rv.x, rv.x, a_rr0);
-    a_rr1 = fma(rv.y, rv.y, a_rr1);
-    a_rho0 = fma(rtv.x, rv.x, a_rho0);
-    a_rho1 = fma(rtv.y, rv.y, a_rho1);
+  CASK_UPD_INDEX;
+  double alpha, a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
+  const PartialsAhead<SUMS_OF_PRODUCT> sums = partials_request<SUMS_OF_PRODUCT>(part_ptq, n_part);
+  if (n2 > 0) {
+    dbl2 qv[UPD_AHEAD_4V], qtv[UPD_AHEAD_4V], rv[UPD_AHEAD_4V], rtv[UPD_AHEAD_4V];
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD_4V; k++) {
+      const int64_t j = min(i + k * stride, last);
+      qv[k] = q2[j];
+      qtv[k] = qt2[j];
+      rv[k] = r2[j];
+      rtv[k] = rt2[j];
+    }
+    alpha = *rho / partials_finish(sums, part_ptq, n_part, red);
+    auto one = [&](int64_t j, dbl2 qa, dbl2 qta, dbl2 ra, dbl2 rta) {
+      ra.x = fma(-alpha, qa.x, ra.x);
+      ra.y = fma(-alpha, qa.y, ra.y);
+      rta.x = fma(-alpha, qta.x, rta.x);
+      rta.y = fma(-alpha, qta.y, rta.y);
+      store_pair(r2 + j, ra, sys_scope);
+      store_pair(rt2 + j, rta, sys_scope);
+      a_rr0 = fma(ra.x, ra.x, a_rr0);
+      a_rr1 = fma(ra.y, ra.y, a_rr1);
+      a_rho0 = fma(rta.x, ra.x, a_rho0);
+      a_rho1 = fma(rta.y, ra.y, a_rho1);
+    };
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD_4V; k++)
+      if (i + k * stride < n2) one(i + k * stride, qv[k], qtv[k], rv[k], rtv[k]);
+    for (int64_t j = i + UPD_AHEAD_4V * stride; j < n2; j += stride) one(j, q2[j], qt2[j], r2[j], rt2[j]);
+  } else {
+    alpha = *rho / partials_finish(sums, part_ptq, n_part, red);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   if (owns_tail(n)) {
     const double rn = fma(-alpha, q[n - 1], r[n - 1]);
     const double rtn = fma(-alpha, qt[n - 1], rt[n - 1]);
@@ -304,32 +348,47 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *x2 = reinterpret_cast<dbl2 *>(x);
   const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: p = z + beta p with z = dinv * r recomputed here
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
-  const dbl2 zero2 = {0.0, 0.0};
-  const dbl2 pv0 = n2 ? p2[i0] : zero2, xv0 = n2 ? x2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2;
-  dbl2 dv0 = zero2;
-  if constexpr (JAC) dv0 = n2 ? d2[i0] : zero2;
-  const double rsnew = partials_or_scalar(part_rr, n_part, red);
-  const bool stop = rsnew <= tol2;
-  const double a = *alpha, beta = stop ? 0.0 : rsnew / *rsold;
-  for (bool first = true; i < n2; i += stride, first = false) {
-    dbl2 pv = first ? pv0 : p2[i], xv = first ? xv0 : x2[i];
-    xv.x = fma(a, pv.x, xv.x);
-    xv.y = fma(a, pv.y, xv.y);
-    x2[i] = xv;
-    if (!stop) {                                              // launch-uniform
-      dbl2 rv = first ? rv0 : r2[i];
-      if constexpr (JAC) {
-        const dbl2 dv = first ? dv0 : d2[i];
-        rv.x *= dv.x;
-        rv.y *= dv.y;
-      }
-      pv.x = fma(beta, pv.x, rv.x);
-      pv.y = fma(beta, pv.y, rv.y);
-      store_pair(p2 + i, pv, sys_scope);
+  CASK_UPD_INDEX;
+  double rsnew, a, beta;
+  bool stop;
+  const PartialsAhead<SUMS_OF_UPDATE> sums = partials_request<SUMS_OF_UPDATE>(part_rr, n_part);
+  if (n2 > 0) {
+    dbl2 pv[UPD_AHEAD], xv[UPD_AHEAD], rv[UPD_AHEAD], dv[JAC ? UPD_AHEAD : 1];
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD; k++) {
+      const int64_t j = min(i + k * stride, last);
+      pv[k] = p2[j];
+      xv[k] = x2[j];
+      rv[k] = r2[j];
+      if constexpr (JAC) dv[k] = d2[j];
     }
+    rsnew = partials_finish(sums, part_rr, n_part, red);
+    stop = rsnew <= tol2;
+    a = *alpha;
+    beta = stop ? 0.0 : rsnew / *rsold;
+    auto one = [&](int64_t j, dbl2 pp, dbl2 xx, dbl2 rr, dbl2 d) {
+      xx.x = fma(a, pp.x, xx.x);
+      xx.y = fma(a, pp.y, xx.y);
+      x2[j] = xx;
+      if (!stop) {                                            // launch-uniform
+        if constexpr (JAC) {
+          rr.x *= d.x;
+          rr.y *= d.y;
+        }
+        pp.x = fma(beta, pp.x, rr.x);
+        pp.y = fma(beta, pp.y, rr.y);
+        store_pair(p2 + j, pp, sys_scope);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD; k++)
+      if (i + k * stride < n2) one(i + k * stride, pv[k], xv[k], rv[k], dv[JAC ? k : 0]);
+    for (int64_t j = i + UPD_AHEAD * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
+  } else {
+    rsnew = partials_finish(sums, part_rr, n_part, red);
+    stop = rsnew <= tol2;
+    a = *alpha;
+    beta = stop ? 0.0 : rsnew / *rsold;
   }
   if (owns_tail(n)) {
     const double pn = p[n - 1];
@@ -352,32 +411,48 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
   if (done_by_earlier_launch(done, iter)) return;
   const dbl2 *r2 = reinterpret_cast<const dbl2 *>(r), *rt2 = reinterpret_cast<const dbl2 *>(rt);
   dbl2 *p2 = reinterpret_cast<dbl2 *>(p), *pt2 = reinterpret_cast<dbl2 *>(pt), *x2 = reinterpret_cast<dbl2 *>(x);
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i0 = min(i, max(n2 - 1, (int64_t)0));        // first pairs requested before the sums (see k_cg_update_r)
-  const dbl2 zero2 = {0.0, 0.0};
-  const dbl2 pv0 = n2 ? p2[i0] : zero2, xv0 = n2 ? x2[i0] : zero2, rv0 = n2 ? r2[i0] : zero2, rtv0 = n2 ? rt2[i0] : zero2,
-             ptv0 = n2 ? pt2[i0] : zero2;
-  const double rr = partials_or_scalar(part_rr, n_part, red);
-  const bool stop = rr <= tol2;
-  double rho_new = 0.0;
-  if (!stop) rho_new = partials_or_scalar(part_rho, n_part, red);
-  const double a = *alpha, beta = stop ? 0.0 : rho_new / *rho;
-  for (bool first = true; i < n2; i += stride, first = false) {
-    dbl2 pv = first ? pv0 : p2[i], xv = first ? xv0 : x2[i];
-    xv.x = fma(a, pv.x, xv.x);
-    xv.y = fma(a, pv.y, xv.y);
-    x2[i] = xv;
-    if (!stop) {
-      const dbl2 rv = first ? rv0 : r2[i], rtv = first ? rtv0 : rt2[i];
-      dbl2 ptv = first ? ptv0 : pt2[i];
-      pv.x = fma(beta, pv.x, rv.x);
-      pv.y = fma(beta, pv.y, rv.y);
-      ptv.x = fma(beta, ptv.x, rtv.x);
-      ptv.y = fma(beta, ptv.y, rtv.y);
-      store_pair(p2 + i, pv, sys_scope);
-      store_pair(pt2 + i, ptv, sys_scope);
+  CASK_UPD_INDEX;
+  double rho_new = 0.0, a, beta;
+  bool stop;
+  const PartialsAhead<SUMS_OF_UPDATE> sums = partials_request<SUMS_OF_UPDATE>(part_rr, n_part), sums_rho = partials_request<SUMS_OF_UPDATE>(part_rho, n_part);
+  auto scalars = [&]() {
+    const double rr = partials_finish(sums, part_rr, n_part, red);
+    stop = rr <= tol2;
+    if (!stop) rho_new = partials_finish(sums_rho, part_rho, n_part, red);
+    a = *alpha;
+    beta = stop ? 0.0 : rho_new / *rho;
+  };
+  if (n2 > 0) {
+    dbl2 pv[UPD_AHEAD_5V], xv[UPD_AHEAD_5V], rv[UPD_AHEAD_5V], rtv[UPD_AHEAD_5V], ptv[UPD_AHEAD_5V];
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD_5V; k++) {
+      const int64_t j = min(i + k * stride, last);
+      pv[k] = p2[j];
+      xv[k] = x2[j];
+      rv[k] = r2[j];
+      rtv[k] = rt2[j];
+      ptv[k] = pt2[j];
     }
+    scalars();
+    auto one = [&](int64_t j, dbl2 pp, dbl2 xx, dbl2 ra, dbl2 rta, dbl2 pta) {
+      xx.x = fma(a, pp.x, xx.x);
+      xx.y = fma(a, pp.y, xx.y);
+      x2[j] = xx;
+      if (!stop) {
+        pp.x = fma(beta, pp.x, ra.x);
+        pp.y = fma(beta, pp.y, ra.y);
+        pta.x = fma(beta, pta.x, rta.x);
+        pta.y = fma(beta, pta.y, rta.y);
+        store_pair(p2 + j, pp, sys_scope);
+        store_pair(pt2 + j, pta, sys_scope);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < UPD_AHEAD_5V; k++)
+      if (i + k * stride < n2) one(i + k * stride, pv[k], xv[k], rv[k], rtv[k], ptv[k]);
+    for (int64_t j = i + UPD_AHEAD_5V * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], rt2[j], pt2[j]);
+  } else {
+    scalars();
   }
   if (owns_tail(n)) {
     const double pn = p[n - 1];
@@ -391,6 +466,7 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
     if (stop) *done = done_tag(iter); else { *rho_out = rho_new; *iters = iter; }
   }
 }
+#undef CASK_UPD_INDEX
 
 // Row-sharded solvers: this rank's partial sums -> one scalar each (fixed order), ready for the all-reduce.
 // One workgroup; up to two quantities per launch (BiCG's r.r and rt.r travel in one collective).

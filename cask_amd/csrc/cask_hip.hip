@@ -940,6 +940,11 @@ int blas_grid(int64_t n) {
   const int64_t want = (n / 2 + BLAS_WG - 1) / BLAS_WG;
   return (int)std::max<int64_t>(1, std::min<int64_t>(BLAS_MAX_PARTIALS, want));
 }
+// ... of a solver's launches (blas1_kernels.hpp: SOLVER_WG)
+int solver_grid(int64_t n) {
+  const int64_t want = (n / 2 + SOLVER_WG - 1) / SOLVER_WG;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(SOLVER_GRID_MAX, want));
+}
 
 // A solver re-reads the matrix every iteration.  When matrix + vectors fit the 256 MiB Infinity Cache,
 // cached loads can beat the streaming ("nt") ones the one-shot product prefers -- or lose to them: on
@@ -2081,8 +2086,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
   int *done = flags.p, *iters = flags.p + 1;
-  const int g = blas_grid(n);
-  const dim3 bg(g), bw(BLAS_WG);
+  const int g = solver_grid(n);
+  const dim3 bg(g), bw(SOLVER_WG);
   const double tol2 = tol * tol;
   int rc;
 
@@ -2344,8 +2349,8 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   double *rs[2] = {scal.p, scal.p + 1};
   int *done = flags.p, *iters = flags.p + 1;
-  const int g = blas_grid(n);
-  const dim3 bg(g), bw(BLAS_WG);
+  const int g = solver_grid(n);
+  const dim3 bg(g), bw(SOLVER_WG);
   rc = launch_spmv(*m, dx.p, r.p, s);                                                   // :189-190
   if (rc) return rc;
   hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,

@@ -160,6 +160,55 @@ __device__ __forceinline__ double partials_or_scalar(const double *__restrict__ 
   return n > 0 ? sum_partials(p, n, red) : *p;
 }
 
+// The same in two steps, for a launch that has other loads to issue while the sums are on their way: loads return in
+// the order they were issued, so whatever everything else waits for is REQUESTED FIRST (PartialsAhead<U>: the first U
+// pairs per lane = 2 U blockDim.x partial sums, or the scalar), the bulk loads follow, and partials_finish then waits for
+// exactly these (sums beyond the first 2 U blockDim.x are fetched there).  Same additions in the same order as
+// sum_partials: same bits.
+template <int U>
+struct PartialsAhead {
+  dbl2 v[U];
+};
+template <int U>
+__device__ __forceinline__ PartialsAhead<U> partials_request(const double *__restrict__ p, int n) {
+  PartialsAhead<U> a;
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p);
+  const int n2 = n >> 1, tid = threadIdx.x, wg = blockDim.x;
+  if (n > 1) {                                                // launch-uniform
+#pragma unroll
+    for (int u = 0; u < U; u++) a.v[u] = p2[min(u * wg + tid, n2 - 1)];
+  } else {
+    a.v[0].x = p[0];                                          // n == 0: the scalar; n == 1: the only partial sum
+  }
+  return a;
+}
+template <int U>
+__device__ __forceinline__ double partials_finish(const PartialsAhead<U> &a, const double *__restrict__ p, int n, double *red) {
+  if (n <= 0) return a.v[0].x;
+  const dbl2 *p2 = reinterpret_cast<const dbl2 *>(p);
+  const int n2 = n >> 1, tid = threadIdx.x, wg = blockDim.x;
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (u * wg + tid < n2) acc += a.v[u].x + a.v[u].y;
+  for (int i0 = U * wg; i0 < n2; i0 += 8 * wg) {
+    dbl2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p2[min(i0 + u * wg + tid, n2 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u * wg + tid < n2) acc += v[u].x + v[u].y;
+  }
+  if ((n & 1) && tid == 0) acc += n > 1 ? p[n - 1] : a.v[0].x;
+  acc = group_sum<64>(acc);
+  __syncthreads();                                  // red may still be read by a previous use
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+  return s;
+}
+
 // Contiguous row blocks per XCD: hardware deals workgroups round-robin over the
 // 8 XCDs (MI355X_MICROARCH "Workgroup dispatch"), so hardware block b lands on
 // XCD b%8.  Map it to a logical block so that each XCD walks one contiguous
