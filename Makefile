@@ -69,7 +69,7 @@ build/obj/%.o: cask_amd/csrc/%.hip
 -include $(ENGINEOBJ:.o=.d)
 $(LIBDIR)/libcask_hip.so: $(ENGINEOBJ)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINEOBJ)
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,-s -o $@ $(ENGINEOBJ)   # (-s: no static symbol table -- 0.2 MB of template names; the C ABI is in .dynsym)
 
 oracle:
 	$(MAKE) -C oracle _build/libcask_oracle.so

@@ -15,20 +15,23 @@ namespace caskhip {
 
 constexpr int BLAS_WG = 256;
 constexpr int BLAS_MAX_PARTIALS = 1024;
-// Pairs a lane of an update launch requests before it waits for the scalars (the launches' common shape: below), by the
-// number of vectors the launch walks -- every one of them has to stay within 128 VGPRs: 4 waves per SIMD, i.e. the
-// whole 1 024-workgroup grid resident at once.
-constexpr int UPD_AHEAD = 4, UPD_AHEAD_4V = 3, UPD_AHEAD_5V = 3;
-// The launches of a solver (r6): SOLVER_GRID_MAX workgroups of SOLVER_WG threads -- one workgroup per CU of an MI355X, 16
-// waves each.  Every workgroup of an update launch starts by adding up ALL the partial sums the launch before it left
-// (fixed order: no atomics, no extra launch), i.e. every workgroup reads the same few KB through the same L2 channels:
-// with 1 024 workgroups of 256 threads the 3 888 sums of a G3_circuit-like product launch were 31 KB x 1 024 readers
-// (~2 us at the head of k_cg_update_r: 9.2 us for bytes that stream in 6.8); a quarter of the readers, and a quarter
-// of the sums for the launch that follows.
+// The launches of a solver come in two shapes (r6), chosen by the vector length (solver_shape, cask_hip.hip):
+//   BIG   (more than SOLVER_GRID_MAX x SOLVER_WG pairs: n > 524 288) -- SOLVER_GRID_MAX workgroups of SOLVER_WG threads: one
+//         workgroup per CU of an MI355X, 16 waves each.  Every workgroup of an update launch starts by adding up ALL the
+//         partial sums the launch before it left (fixed order: no atomics, no extra launch), i.e. every workgroup reads
+//         the same few KB through the same L2 channels: with 1 024 workgroups of 256 threads the 3 888 sums of a
+//         G3_circuit-like product launch were 31 KB x 1 024 readers (~2 us at the head of k_cg_update_r: 9.2 us for bytes
+//         that stream in 6.8); a quarter of the readers, and a quarter of the sums for the launch that follows.
+//   SMALL (anything shorter) -- up to BLAS_MAX_PARTIALS workgroups of BLAS_WG threads, a pair per lane: a cant-like system
+//         (31 225 pairs) on 31 workgroups of 1 024 was 7 % slower per CG pass than on 122 of 256.
+// UpdShape<BIG>: pairs a lane requests before it waits for the scalars, by the number of vectors the launch walks (every
+// kernel within 128 VGPRs: 4 waves per SIMD, the whole BIG grid resident at once), and the partial sums it requests ahead
+// of everything, in 16-byte pairs per lane (an update launch leaves one sum per workgroup, a product launch one per
+// workgroup of the plan: 1 958 ... 4 314 on the BASELINE matrices).
 constexpr int SOLVER_WG = 1024, SOLVER_GRID_MAX = 256;
-// Partial sums a lane requests ahead of everything, in 16-byte pairs: an update launch leaves <= SOLVER_GRID_MAX (1 pair a
-// lane), a product launch one per workgroup (the BASELINE matrices: 1 958 ... 4 314 = 3 pairs a lane of 1 024).
-constexpr int SUMS_OF_UPDATE = 1, SUMS_OF_PRODUCT = 3;
+template <bool BIG> struct UpdShape;
+template <> struct UpdShape<true>  { static constexpr int AHEAD = 4, AHEAD_4V = 3, AHEAD_5V = 3, SUMS_OF_UPDATE = 1, SUMS_OF_PRODUCT = 3; };
+template <> struct UpdShape<false> { static constexpr int AHEAD = 1, AHEAD_4V = 1, AHEAD_5V = 1, SUMS_OF_UPDATE = 2, SUMS_OF_PRODUCT = 8; };
 
 __device__ __forceinline__ double wg_sum(double v, double *red) {
   v = group_sum<64>(v);
@@ -209,7 +212,7 @@ __device__ __forceinline__ void store_one(double *p, double v, int sys_scope) {
 }
 
 // The four update launches of a classic pass share one shape (r6):
-//   * a lane's first UPD_AHEAD pairs are requested BEFORE the scalars are waited for.  The scalars are sums of partial
+//   * a lane's first AHEAD pairs (UpdShape) are requested BEFORE the scalars are waited for.  The scalars are sums of partial
 //     sums (a dependent L2 round trip + a workgroup reduction at the head of every workgroup, ~1 us); the vector loads
 //     do not depend on them -- and a pair requested only once alpha is known is one more dependent trip: with 1 024
 //     workgroups a lane of the G3_circuit-like system owns 3 pairs, and with only the first one ahead (r4)
@@ -224,7 +227,7 @@ __device__ __forceinline__ void store_one(double *p, double v, int sys_scope) {
 // CG, second launch of a pass: alpha = rsold / (p.Ap) ; r -= alpha Ap ; shares of r.r
 // (SparseLinearSolvers.hpp:208, 212, 218).  x += alpha p (:210) is applied by the next product launch, which
 // reads p anyway; alpha is left in *alpha_out for it.
-template <bool JAC>
+template <bool JAC, bool BIG>
 __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__restrict__ part_pAp, int n_part,
                               const double *__restrict__ Ap, double *__restrict__ r, double *__restrict__ part_rr,
                               double *alpha_out, const int *done, int sys_scope, const double *__restrict__ dinv) {
@@ -235,11 +238,11 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
   const dbl2 *d2 = reinterpret_cast<const dbl2 *>(dinv);      // JAC: the shares are of r.z with z = dinv * r (never stored)
   CASK_UPD_INDEX;
   double alpha, acc0 = 0.0, acc1 = 0.0;
-  const PartialsAhead<SUMS_OF_PRODUCT> sums = partials_request<SUMS_OF_PRODUCT>(part_pAp, n_part);
+  const PartialsAhead<UpdShape<BIG>::SUMS_OF_PRODUCT> sums = partials_request<UpdShape<BIG>::SUMS_OF_PRODUCT>(part_pAp, n_part);
   if (n2 > 0) {
-    dbl2 av[UPD_AHEAD], rv[UPD_AHEAD], dv[JAC ? UPD_AHEAD : 1];
+    dbl2 av[UpdShape<BIG>::AHEAD], rv[UpdShape<BIG>::AHEAD], dv[JAC ? UpdShape<BIG>::AHEAD : 1];
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD; k++) {
+    for (int k = 0; k < UpdShape<BIG>::AHEAD; k++) {
       const int64_t j = min(i + k * stride, last);
       av[k] = Ap2[j];
       rv[k] = r2[j];
@@ -259,9 +262,9 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
       }
     };
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD; k++)
+    for (int k = 0; k < UpdShape<BIG>::AHEAD; k++)
       if (i + k * stride < n2) one(i + k * stride, av[k], rv[k], dv[JAC ? k : 0]);
-    for (int64_t j = i + UPD_AHEAD * stride; j < n2; j += stride) one(j, Ap2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
+    for (int64_t j = i + UpdShape<BIG>::AHEAD * stride; j < n2; j += stride) one(j, Ap2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
   } else {
     alpha = *rsold / partials_finish(sums, part_pAp, n_part, red);
   }
@@ -277,6 +280,7 @@ __global__ void k_cg_update_r(int64_t n, const double *rsold, const double *__re
 }
 
 // BiCG, last launch of a pass: alpha = rho / (pt.q) ; r -= alpha q ; rt -= alpha qt ; shares of r.r and rt.r
+template <bool BIG>
 __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__restrict__ part_ptq, int n_part,
                                 const double *__restrict__ q, const double *__restrict__ qt,
                                 double *__restrict__ r, double *__restrict__ rt, double *__restrict__ part_rr,
@@ -287,11 +291,11 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
   dbl2 *r2 = reinterpret_cast<dbl2 *>(r), *rt2 = reinterpret_cast<dbl2 *>(rt);
   CASK_UPD_INDEX;
   double alpha, a_rr0 = 0.0, a_rr1 = 0.0, a_rho0 = 0.0, a_rho1 = 0.0;
-  const PartialsAhead<SUMS_OF_PRODUCT> sums = partials_request<SUMS_OF_PRODUCT>(part_ptq, n_part);
+  const PartialsAhead<UpdShape<BIG>::SUMS_OF_PRODUCT> sums = partials_request<UpdShape<BIG>::SUMS_OF_PRODUCT>(part_ptq, n_part);
   if (n2 > 0) {
-    dbl2 qv[UPD_AHEAD_4V], qtv[UPD_AHEAD_4V], rv[UPD_AHEAD_4V], rtv[UPD_AHEAD_4V];
+    dbl2 qv[UpdShape<BIG>::AHEAD_4V], qtv[UpdShape<BIG>::AHEAD_4V], rv[UpdShape<BIG>::AHEAD_4V], rtv[UpdShape<BIG>::AHEAD_4V];
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD_4V; k++) {
+    for (int k = 0; k < UpdShape<BIG>::AHEAD_4V; k++) {
       const int64_t j = min(i + k * stride, last);
       qv[k] = q2[j];
       qtv[k] = qt2[j];
@@ -312,9 +316,9 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
       a_rho1 = fma(rta.y, ra.y, a_rho1);
     };
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD_4V; k++)
+    for (int k = 0; k < UpdShape<BIG>::AHEAD_4V; k++)
       if (i + k * stride < n2) one(i + k * stride, qv[k], qtv[k], rv[k], rtv[k]);
-    for (int64_t j = i + UPD_AHEAD_4V * stride; j < n2; j += stride) one(j, q2[j], qt2[j], r2[j], rt2[j]);
+    for (int64_t j = i + UpdShape<BIG>::AHEAD_4V * stride; j < n2; j += stride) one(j, q2[j], qt2[j], r2[j], rt2[j]);
   } else {
     alpha = *rho / partials_finish(sums, part_ptq, n_part, red);
   }
@@ -338,7 +342,7 @@ __global__ void k_bicg_update_r(int64_t n, const double *rho, const double *__re
 //   x += alpha p (SparseLinearSolvers.hpp:210; alpha as k_cg_update_r left it) ; rsnew = r.r ; converged if
 //   rsnew <= tol^2 (:220-226, nothing after it) ; else iterations = iter, p = r + (rsnew/rsold) p (:229-231).
 // x is updated here and not next to r because this launch reads p anyway: one pass over p less per iteration.
-template <bool JAC>
+template <bool JAC, bool BIG>
 __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, int n_part, const double *rsold,
                                double *rsnew_out, const double *alpha, double tol2, int iter,
                                const double *__restrict__ r, double *__restrict__ p, double *__restrict__ x,
@@ -351,11 +355,11 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
   CASK_UPD_INDEX;
   double rsnew, a, beta;
   bool stop;
-  const PartialsAhead<SUMS_OF_UPDATE> sums = partials_request<SUMS_OF_UPDATE>(part_rr, n_part);
+  const PartialsAhead<UpdShape<BIG>::SUMS_OF_UPDATE> sums = partials_request<UpdShape<BIG>::SUMS_OF_UPDATE>(part_rr, n_part);
   if (n2 > 0) {
-    dbl2 pv[UPD_AHEAD], xv[UPD_AHEAD], rv[UPD_AHEAD], dv[JAC ? UPD_AHEAD : 1];
+    dbl2 pv[UpdShape<BIG>::AHEAD], xv[UpdShape<BIG>::AHEAD], rv[UpdShape<BIG>::AHEAD], dv[JAC ? UpdShape<BIG>::AHEAD : 1];
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD; k++) {
+    for (int k = 0; k < UpdShape<BIG>::AHEAD; k++) {
       const int64_t j = min(i + k * stride, last);
       pv[k] = p2[j];
       xv[k] = x2[j];
@@ -381,9 +385,9 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
       }
     };
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD; k++)
+    for (int k = 0; k < UpdShape<BIG>::AHEAD; k++)
       if (i + k * stride < n2) one(i + k * stride, pv[k], xv[k], rv[k], dv[JAC ? k : 0]);
-    for (int64_t j = i + UPD_AHEAD * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
+    for (int64_t j = i + UpdShape<BIG>::AHEAD * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], JAC ? d2[j] : dbl2{0.0, 0.0});
   } else {
     rsnew = partials_finish(sums, part_rr, n_part, red);
     stop = rsnew <= tol2;
@@ -402,6 +406,7 @@ __global__ void k_cg_update_px(int64_t n, const double *__restrict__ part_rr, in
 }
 
 // BiCG: x += alpha p ; converged if r.r <= tol^2 ; else beta = rho_new/rho, p = r + beta p, pt = rt + beta pt
+template <bool BIG>
 __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, const double *__restrict__ part_rho,
                                  int n_part, const double *rho, double *rho_out, const double *alpha, double tol2,
                                  int iter, const double *__restrict__ r, const double *__restrict__ rt,
@@ -414,7 +419,7 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
   CASK_UPD_INDEX;
   double rho_new = 0.0, a, beta;
   bool stop;
-  const PartialsAhead<SUMS_OF_UPDATE> sums = partials_request<SUMS_OF_UPDATE>(part_rr, n_part), sums_rho = partials_request<SUMS_OF_UPDATE>(part_rho, n_part);
+  const PartialsAhead<UpdShape<BIG>::SUMS_OF_UPDATE> sums = partials_request<UpdShape<BIG>::SUMS_OF_UPDATE>(part_rr, n_part), sums_rho = partials_request<UpdShape<BIG>::SUMS_OF_UPDATE>(part_rho, n_part);
   auto scalars = [&]() {
     const double rr = partials_finish(sums, part_rr, n_part, red);
     stop = rr <= tol2;
@@ -423,9 +428,9 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
     beta = stop ? 0.0 : rho_new / *rho;
   };
   if (n2 > 0) {
-    dbl2 pv[UPD_AHEAD_5V], xv[UPD_AHEAD_5V], rv[UPD_AHEAD_5V], rtv[UPD_AHEAD_5V], ptv[UPD_AHEAD_5V];
+    dbl2 pv[UpdShape<BIG>::AHEAD_5V], xv[UpdShape<BIG>::AHEAD_5V], rv[UpdShape<BIG>::AHEAD_5V], rtv[UpdShape<BIG>::AHEAD_5V], ptv[UpdShape<BIG>::AHEAD_5V];
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD_5V; k++) {
+    for (int k = 0; k < UpdShape<BIG>::AHEAD_5V; k++) {
       const int64_t j = min(i + k * stride, last);
       pv[k] = p2[j];
       xv[k] = x2[j];
@@ -448,9 +453,9 @@ __global__ void k_bicg_update_px(int64_t n, const double *__restrict__ part_rr, 
       }
     };
 #pragma unroll
-    for (int k = 0; k < UPD_AHEAD_5V; k++)
+    for (int k = 0; k < UpdShape<BIG>::AHEAD_5V; k++)
       if (i + k * stride < n2) one(i + k * stride, pv[k], xv[k], rv[k], rtv[k], ptv[k]);
-    for (int64_t j = i + UPD_AHEAD_5V * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], rt2[j], pt2[j]);
+    for (int64_t j = i + UpdShape<BIG>::AHEAD_5V * stride; j < n2; j += stride) one(j, p2[j], x2[j], r2[j], rt2[j], pt2[j]);
   } else {
     scalars();
   }

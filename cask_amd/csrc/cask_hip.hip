@@ -940,11 +940,24 @@ int blas_grid(int64_t n) {
   const int64_t want = (n / 2 + BLAS_WG - 1) / BLAS_WG;
   return (int)std::max<int64_t>(1, std::min<int64_t>(BLAS_MAX_PARTIALS, want));
 }
-// ... of a solver's launches (blas1_kernels.hpp: SOLVER_WG)
-int solver_grid(int64_t n) {
-  const int64_t want = (n / 2 + SOLVER_WG - 1) / SOLVER_WG;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(SOLVER_GRID_MAX, want));
+// ... of a solver's launches (blas1_kernels.hpp: the BIG and the SMALL shape)
+struct SolverShape { int grid, wg; bool big; };
+SolverShape solver_shape(int64_t n) {
+  const int64_t pairs = n / 2;
+  if (pairs > (int64_t)SOLVER_GRID_MAX * SOLVER_WG) return SolverShape{SOLVER_GRID_MAX, SOLVER_WG, true};
+  return SolverShape{blas_grid(n), BLAS_WG, false};
 }
+// an update launch in the instantiation of the shape
+#define CASK_LAUNCH_UPD(big, kernel, ...)                                      \
+  do {                                                                          \
+    if (big) hipLaunchKernelGGL(kernel<true>, __VA_ARGS__);                     \
+    else     hipLaunchKernelGGL(kernel<false>, __VA_ARGS__);                    \
+  } while (0)
+#define CASK_LAUNCH_UPD_J(big, kernel, jac, ...)                               \
+  do {                                                                          \
+    if (big) hipLaunchKernelGGL((kernel<jac, true>), __VA_ARGS__);              \
+    else     hipLaunchKernelGGL((kernel<jac, false>), __VA_ARGS__);             \
+  } while (0)
 
 // A solver re-reads the matrix every iteration.  When matrix + vectors fit the 256 MiB Infinity Cache,
 // cached loads can beat the streaming ("nt") ones the one-shot product prefers -- or lose to them: on
@@ -2086,8 +2099,9 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
   int *done = flags.p, *iters = flags.p + 1;
-  const int g = solver_grid(n);
-  const dim3 bg(g), bw(SOLVER_WG);
+  const SolverShape shape = solver_shape(n);
+  const int g = shape.grid;
+  const dim3 bg(g), bw(shape.wg);
   const double tol2 = tol * tol;
   int rc;
 
@@ -2232,10 +2246,10 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     // r -= alpha q (and rt -= alpha qt) with the shares of r.r (and rt.r); alpha stays on the device for the launch
     // that applies x += alpha p: the next product (composed passes) or the p update below (classic passes)
     if (bicg)
-      hipLaunchKernelGGL(k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
+      CASK_LAUNCH_UPD(shape.big, k_bicg_update_r, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, qt.p, r, rt, part_a.p, part_b.p,
                          scal.p + SC_ALPHA, (const int *)done, st.sys_scope);
     else
-      hipLaunchKernelGGL(k_cg_update_r<false>, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
+      CASK_LAUNCH_UPD_J(shape.big, k_cg_update_r, false, bg, bw, 0, s, n, rsold, dot_part, n_dot, q.p, r, part_a.p, scal.p + SC_ALPHA,
                          (const int *)done, st.sys_scope, (const double *)nullptr);     // :208, :212, :218
     const double *chk_part = part_a.p, *rho_part = part_b.p;
     int n_chk = g;
@@ -2255,10 +2269,10 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
     }
     if (!st.composed) {
       if (bicg)
-        hipLaunchKernelGGL(k_bicg_update_px, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA,
+        CASK_LAUNCH_UPD(shape.big, k_bicg_update_px, bg, bw, 0, s, n, chk_part, rho_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA,
                            tol2, i, r, rt, slot(SLOT_P0), slot(SLOT_PT0), d_x, done, iters, st.sys_scope);
       else
-        hipLaunchKernelGGL(k_cg_update_px<false>, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA, tol2, i, r,
+        CASK_LAUNCH_UPD_J(shape.big, k_cg_update_px, false, bg, bw, 0, s, n, chk_part, n_chk, rsold, rsnew, scal.p + SC_ALPHA, tol2, i, r,
                            slot(SLOT_P0), d_x, done, iters, st.sys_scope, (const double *)nullptr);   // :210, :220-231
     }
     if (!st.composed && st.sharded && !st.exchange) {
@@ -2349,8 +2363,9 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   double *rs[2] = {scal.p, scal.p + 1};
   int *done = flags.p, *iters = flags.p + 1;
-  const int g = solver_grid(n);
-  const dim3 bg(g), bw(SOLVER_WG);
+  const SolverShape shape = solver_shape(n);
+  const int g = shape.grid;
+  const dim3 bg(g), bw(shape.wg);
   rc = launch_spmv(*m, dx.p, r.p, s);                                                   // :189-190
   if (rc) return rc;
   hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, 1.0, db.p, 1.0, -1.0, (const double *)nullptr, (const double *)nullptr,
@@ -2389,9 +2404,9 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
       // Jacobi: z = dinv * r is never stored.  r -= alpha Ap with the shares of r.z (:212-218), then rsnew, the test,
       // p = z + beta p with z recomputed and the x update this pass owes (:210, :220-231): 3 launches and 10 vector
       // passes per iteration instead of 4 and 12
-      hipLaunchKernelGGL(k_cg_update_r<true>, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, Ap.p, r.p, partials_rz.p, scal.p + 2,
+      CASK_LAUNCH_UPD_J(shape.big, k_cg_update_r, true, bg, bw, 0, s, n, rsold, pAp_part, n_pAp, Ap.p, r.p, partials_rz.p, scal.p + 2,
                          (const int *)done, 0, jacobi);
-      hipLaunchKernelGGL(k_cg_update_px<true>, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, scal.p + 2, tol * tol, i, r.p,
+      CASK_LAUNCH_UPD_J(shape.big, k_cg_update_px, true, bg, bw, 0, s, n, partials_rz.p, g, rsold, rsnew, scal.p + 2, tol * tol, i, r.p,
                          p.p, dx.p, done, iters, 0, jacobi);
     } else {
       // x += alpha p ; r -= alpha Ap  (:210-212; the r.r shares this kernel also leaves are not used here)
