@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE RDREQ; do
   ctr=$c
   if [ $c = RDREQ ]; then ctr="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; fi
-  [ -d $out/pmc_${tag}_calib_$c ] || rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
+  [ -n "$(find $out/pmc_${tag}_calib_$c -name '*counter_collection.csv' 2>/dev/null | head -n 1)" ] || rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_calib_$c -- $root/build/membench > /dev/null 2> $out/pmc_${tag}_calib_$c.err
   rm -rf $out/pmc_${tag}_${w}_${sv}_$c
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${tag}_${w}_${sv}_$c -- python3 $root/bench.py --workload $w --solver $sv --steps 40 --warmup 4 --windows 3 --no-cpu-baseline > /dev/null 2> $out/pmc_${tag}_${w}_${sv}_$c.err
 done
