@@ -218,3 +218,47 @@ def test_solvers_on_scan_plans():
             assert conv == want_conv and abs(it - want_it) <= 2, (name, dp, it, want_it)
             np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
 
+
+
+def _tridiagonal(n, lower, diag, upper):
+    """A well-conditioned tridiagonal system in CSR (a handful of passes to convergence whatever n is)."""
+    rows = np.repeat(np.arange(n), 3)[1:-1]
+    cols = (rows + np.tile([-1, 0, 1], n)[1:-1])
+    vals = np.tile([lower, diag, upper], n)[1:-1].astype(float)
+    vals = vals * (1.0 + 0.01 * np.cos(np.arange(vals.size)))            # not a constant stencil
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp, rows + 1, 1)
+    return np.cumsum(rp).astype(np.int32), cols.astype(np.int32), vals
+
+
+@pytest.mark.parametrize("n", [524_288, 524_290, 524_291, 1_048_577, 2_097_154, 2_200_003])
+def test_solver_launch_shapes_around_their_edges(n):
+    """The update launches come in two shapes (blas1_kernels.hpp, r6): up to 1 024 workgroups of 256 threads with a pair
+    per lane up to 262 144 pairs, 256 workgroups of 1 024 beyond -- there a lane requests its first 4 (3) pairs ahead of
+    the scalars and walks the rest in a loop.  Sizes on both sides of the switch, odd and even, and past 4 pairs per lane
+    (the BASELINE systems stay under 3.1), CG and BiCG, against the oracle; twice: the same bits."""
+    for solver, (lo, up) in (("cg", (-1.0, -1.0)), ("bicg", (-1.3, -0.6))):
+        rp, ci, va = _tridiagonal(n, lo, 4.0, up)
+        if solver == "cg":                                               # symmetric: the upper entry of row i = the lower of row i + 1
+            up_idx = np.arange(1, va.size - 1, 3)[: n - 1]
+            va[up_idx] = va[up_idx + 1]
+        x0 = np.cos(0.001 * np.arange(n))
+        b = oracle.csr_spmv(rp, ci, va, x0)
+        want, want_it, want_conv = (oracle.cg_full if solver == "cg" else oracle.bicg)(rp, ci, va, b, tol=1e-8)
+        m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+        got, it, conv, _ = (m.cg if solver == "cg" else m.bicg)(b, tol=1e-8)
+        again, it2, _, _ = (m.cg if solver == "cg" else m.bicg)(b, tol=1e-8)
+        m.close()
+        assert want_conv and conv and abs(it - want_it) <= 1, (solver, n, it, want_it)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(got, x0, rtol=1e-6, atol=1e-7)
+        assert it2 == it and np.array_equal(got, again)
+        if solver == "cg" and n in (524_291, 2_200_003):                 # ... and the Jacobi instantiations of the same launches
+            want, want_it, want_conv = oracle.pcg_precond(rp, ci, va, b, kind="jacobi", tol=1e-8, full=True)
+            pc = capi.Preconditioner("jacobi", n, rp, ci, va)
+            m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+            got, it, conv, _ = m.pcg(pc, b, tol=1e-8)
+            m.close()
+            pc.close()
+            assert want_conv and conv and abs(it - want_it) <= 1, ("pcg jacobi", n, it, want_it)
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
