@@ -942,9 +942,13 @@ int blas_grid(int64_t n) {
 }
 // ... of a solver's launches (blas1_kernels.hpp: the BIG and the SMALL shape)
 struct SolverShape { int grid, wg; bool big; };
-SolverShape solver_shape(int64_t n) {
+// sharded: the scalars arrive all-reduced (no partial sums to add up: what BIG is for), and ranks that share a device in a
+// rehearsal are time-sliced against each other -- SMALL there.  CASK_HIP_SOLVER_SHAPE=big|small: development A/B.
+SolverShape solver_shape(int64_t n, bool sharded) {
   const int64_t pairs = n / 2;
-  if (pairs > (int64_t)SOLVER_GRID_MAX * SOLVER_WG) return SolverShape{SOLVER_GRID_MAX, SOLVER_WG, true};
+  bool big = !sharded && pairs > (int64_t)SOLVER_GRID_MAX * SOLVER_WG;
+  if (const char *e = std::getenv("CASK_HIP_SOLVER_SHAPE")) big = std::strcmp(e, "big") == 0 ? true : std::strcmp(e, "small") == 0 ? false : big;
+  if (big) return SolverShape{SOLVER_GRID_MAX, SOLVER_WG, true};
   return SolverShape{blas_grid(n), BLAS_WG, false};
 }
 // an update launch in the instantiation of the shape
@@ -2099,7 +2103,7 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
   int *done = flags.p, *iters = flags.p + 1;
-  const SolverShape shape = solver_shape(n);
+  const SolverShape shape = solver_shape(n, st.sharded);
   const int g = shape.grid;
   const dim3 bg(g), bw(shape.wg);
   const double tol2 = tol * tol;
@@ -2363,7 +2367,7 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
   double *rs[2] = {scal.p, scal.p + 1};
   int *done = flags.p, *iters = flags.p + 1;
-  const SolverShape shape = solver_shape(n);
+  const SolverShape shape = solver_shape(n, false);
   const int g = shape.grid;
   const dim3 bg(g), bw(shape.wg);
   rc = launch_spmv(*m, dx.p, r.p, s);                                                   // :189-190
