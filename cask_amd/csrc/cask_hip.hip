@@ -122,6 +122,8 @@ struct SolverWorkspace {
 };
 
 // Pinned, GPU-mapped host memory (the staging buffers of the host-vector entry point).
+constexpr int HOST_DONE_DEFAULT = 1;   // 0: hipStreamSynchronize, 1: the completion word (cask_hip_spmv: -4.5 us a call, profiles/r06_host_entry.txt)
+
 struct PinBuf {
   double *p = nullptr, *dev = nullptr;   // host address / the address the GPU uses for it
   size_t n = 0;
@@ -165,6 +167,8 @@ struct cask_hip_matrix {
   hipStream_t stream = nullptr;    // for the host-vector entry points and timing
   DevBuf<double> d_x, d_y;         // staging for cask_hip_spmv
   PinBuf pin_x, pin_y;             // ... and its pinned host side (the staged entry: host_entry below)
+  PinBuf pin_done;                 // a word the GPU stores behind a product of the host entry: the CPU polls it instead of waiting for a signal
+  uint64_t done_seq = 0;
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
   ~cask_hip_matrix() {
@@ -1355,6 +1359,12 @@ int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint6
 }  // extern "C"
 namespace {
 
+// Completion word of the host entry: stored (system scope) by a one-thread launch BEHIND the product on the handle's stream.
+// The product's y went to pinned host memory before this launch began (stream order, the kernel-end release), and posted
+// writes of one device reach host memory in order: a CPU that sees the word sees y.
+__global__ void k_done_word(unsigned long long *word, unsigned long long seq) {
+  __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_pull_f64(int64_t n, const double *__restrict__ src, double *__restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = __builtin_nontemporal_load(src + i);
@@ -1564,7 +1574,32 @@ int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
   int rc = launch_spmv(*m, m->d_x.p, y_target, m->stream);
   if (rc) return rc;
   if (yb && y_target == m->d_y.p) HIP_TRY(hipMemcpyAsync(y, m->d_y.p, yb, hipMemcpyDeviceToHost, m->stream));
-  HIP_TRY(hipStreamSynchronize(m->stream));
+  // How the CPU learns that y is there.  hipStreamSynchronize waits for the queue's completion signal; when y already
+  // lands in host memory (staged / in place) a word stored behind the product and polled by the caller gets there
+  // earlier (profiles/r06_host_entry.txt).  The poll is bounded: a launch that faulted never stores the word, and
+  // hipStreamSynchronize is what reports it.  CASK_HIP_HOST_DONE=sync|word: development A/B.
+  static const int done_mode = [] {
+    const char *e = std::getenv("CASK_HIP_HOST_DONE");
+    return e && std::strcmp(e, "sync") == 0 ? 0 : e && std::strcmp(e, "word") == 0 ? 1 : HOST_DONE_DEFAULT;
+  }();
+  bool waited = false;
+  if (done_mode == 1 && yb && y_target != m->d_y.p && m->pin_done.ensure(1) == hipSuccess) {
+    const unsigned long long seq = ++m->done_seq;
+    hipLaunchKernelGGL(k_done_word, dim3(1), dim3(1), 0, m->stream, reinterpret_cast<unsigned long long *>(m->pin_done.dev), seq);
+    if (hipGetLastError() == hipSuccess) {
+      const volatile unsigned long long *word = reinterpret_cast<const volatile unsigned long long *>(m->pin_done.p);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; !waited; spins++) {
+        if (*word == seq) { waited = true; break; }
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+  }
+  if (!waited) HIP_TRY(hipStreamSynchronize(m->stream));
   if (yb && !y_dev && y_target != m->d_y.p) copy_pool().copy(y, m->pin_y.p, yb, 1);
   return CASK_HIP_OK;
 }
