@@ -974,6 +974,36 @@ SolverShape solver_shape(int64_t n, bool sharded) {
 // iterations 16-31 run with streaming loads, 32-47 with cached loads, and from 48 on the faster of the
 // two.  The load policy changes no arithmetic, so the iterates are the same either way; the plan is
 // restored when the solver returns.
+// Completion word of the host entry: stored (system scope) by a one-thread launch BEHIND the product on the handle's stream.
+// The product's y went to pinned host memory before this launch began (stream order, the kernel-end release), and posted
+// writes of one device reach host memory in order: a CPU that sees the word sees y.
+__global__ void k_done_word(unsigned long long *word, unsigned long long seq) {
+  __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// CASK_HIP_HOST_DONE=sync|word (development A/B): how the CPU waits for something the GPU leaves in host memory
+bool host_done_word() {
+  static const int mode = [] {
+    const char *e = std::getenv("CASK_HIP_HOST_DONE");
+    return e && std::strcmp(e, "sync") == 0 ? 0 : e && std::strcmp(e, "word") == 0 ? 1 : HOST_DONE_DEFAULT;
+  }();
+  return mode == 1;
+}
+// Poll a word in pinned host memory until it holds seq; false after `limit_ms` (the caller then synchronises: a launch that
+// faulted never stores the word, and the synchronisation is what reports it).
+bool poll_word(const volatile unsigned long long *word, unsigned long long seq, int limit_ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (*word == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit_ms)) return false;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
 struct SolverLoadPolicy {
   cask_hip_matrix *m, *mt;
   int saved = 0, saved_t = 0;
@@ -1359,12 +1389,6 @@ int cask_hip_csr_set_halo_sources(cask_hip_matrix *m, int32_t n_own, const uint6
 }  // extern "C"
 namespace {
 
-// Completion word of the host entry: stored (system scope) by a one-thread launch BEHIND the product on the handle's stream.
-// The product's y went to pinned host memory before this launch began (stream order, the kernel-end release), and posted
-// writes of one device reach host memory in order: a CPU that sees the word sees y.
-__global__ void k_done_word(unsigned long long *word, unsigned long long seq) {
-  __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 __global__ void k_pull_f64(int64_t n, const double *__restrict__ src, double *__restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = __builtin_nontemporal_load(src + i);
@@ -1578,26 +1602,12 @@ int cask_hip_spmv(cask_hip_matrix *m, const double *x, double *y) {
   // lands in host memory (staged / in place) a word stored behind the product and polled by the caller gets there
   // earlier (profiles/r06_host_entry.txt).  The poll is bounded: a launch that faulted never stores the word, and
   // hipStreamSynchronize is what reports it.  CASK_HIP_HOST_DONE=sync|word: development A/B.
-  static const int done_mode = [] {
-    const char *e = std::getenv("CASK_HIP_HOST_DONE");
-    return e && std::strcmp(e, "sync") == 0 ? 0 : e && std::strcmp(e, "word") == 0 ? 1 : HOST_DONE_DEFAULT;
-  }();
   bool waited = false;
-  if (done_mode == 1 && yb && y_target != m->d_y.p && m->pin_done.ensure(1) == hipSuccess) {
+  if (host_done_word() && yb && y_target != m->d_y.p && m->pin_done.ensure(1) == hipSuccess) {
     const unsigned long long seq = ++m->done_seq;
     hipLaunchKernelGGL(k_done_word, dim3(1), dim3(1), 0, m->stream, reinterpret_cast<unsigned long long *>(m->pin_done.dev), seq);
-    if (hipGetLastError() == hipSuccess) {
-      const volatile unsigned long long *word = reinterpret_cast<const volatile unsigned long long *>(m->pin_done.p);
-      const auto t0 = std::chrono::steady_clock::now();
-      for (unsigned spins = 0; !waited; spins++) {
-        if (*word == seq) { waited = true; break; }
-        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    if (hipGetLastError() == hipSuccess)
+      waited = poll_word(reinterpret_cast<const volatile unsigned long long *>(m->pin_done.p), seq, 20);
   }
   if (!waited) HIP_TRY(hipStreamSynchronize(m->stream));
   if (yb && !y_dev && y_target != m->d_y.p) copy_pool().copy(y, m->pin_y.p, yb, 1);
