@@ -113,6 +113,40 @@ struct Plan {
 
 // Buffers of a solve, kept on the handle between solves of the same shape (a solver called in a loop -- or timed
 // over a few passes -- must not pay a dozen allocations per call).
+// A solver's checkpoint without a gap in the GPU's work (r6).  Every 16 passes the host wants the two flags; copying them and
+// waiting for the stream left the GPU idle from the copy's completion until the next pass was launched (~15 us per
+// checkpoint: 0.9 us per pass).  Deferred: the flags go to PINNED memory behind an event, the host launches ONE more pass and
+// only then waits for that event -- the GPU is busy with the pass while the copy's completion travels (waiting behind the
+// pass's product alone -- 8-20 us -- covered it on the large systems only).  A converged solve has launched one pass more:
+// its product(s) overwrite q, its update launches return on the done flag (blas1_kernels.hpp).
+struct DeferredFlags {
+  int *host = nullptr;                                        // pinned: [0] done, [1] iterations
+  DevEvent arrived;
+  int pending = 0;                                            // the number of passes launched at the checkpoint in flight; 0: none
+  ~DeferredFlags() {
+    if (host) (void)hipHostFree(host);
+  }
+  hipError_t create() {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), 2 * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) { host = nullptr; return e; }
+    host[0] = host[1] = 0;
+    return arrived.create();
+  }
+  hipError_t request(const int *d_flags, int launched, hipStream_t s) {
+    hipError_t e = hipMemcpyAsync(host, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(arrived, s);
+    if (e == hipSuccess) pending = launched;
+    return e;
+  }
+  hipError_t wait(int h_flags[2]) {
+    hipError_t e = hipEventSynchronize(arrived);
+    h_flags[0] = host[0];
+    h_flags[1] = host[1];
+    pending = 0;
+    return e;
+  }
+};
+
 struct SolverWorkspace {
   int64_t n = -1, S = 0, n_full = 0;
   int n_slots = 0;
@@ -171,6 +205,7 @@ struct cask_hip_matrix {
   uint64_t done_seq = 0;
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
+  std::unique_ptr<DeferredFlags> checkpoint;   // (created by the first solve that defers: a pinned allocation is ~100 us)
   ~cask_hip_matrix() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1004,6 +1039,17 @@ bool poll_word(const volatile unsigned long long *word, unsigned long long seq, 
 #endif
   }
 }
+bool ensure_checkpoint(cask_hip_matrix *m) {
+  if (m->checkpoint) return true;
+  std::unique_ptr<DeferredFlags> c(new DeferredFlags);
+  if (c->create() != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  m->checkpoint = std::move(c);
+  return true;
+}
+
 struct SolverLoadPolicy {
   cask_hip_matrix *m, *mt;
   int saved = 0, saved_t = 0;
@@ -2200,6 +2246,10 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   HIP_TRY(hipEventRecord(e0, s));
   const int check_every = 16;
   int h_flags[2] = {0, 0};
+  const bool can_defer = !st.composed && !st.sharded && ensure_checkpoint(m);
+  DeferredFlags none;
+  DeferredFlags &deferred = can_defer ? *m->checkpoint : none;
+  deferred.pending = 0;
   int launched = 0;
   double clean_us = 0.0;
   SolverLoadPolicy load_policy(m, bicg ? st.At : nullptr, bicg ? 8 : 5);
@@ -2331,6 +2381,15 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       if (rc) return rc;
     }
     launched = i + 1;
+    if (deferred.pending) {                                   // the checkpoint of the pass before: its flags travelled while this pass was launched
+      const int at = deferred.pending;
+      HIP_TRY(deferred.wait(h_flags));
+      load_policy.decide(at);
+      if (h_flags[0]) break;                                  // (the pass just launched: its product(s) overwrote q, its updates return on the flag)
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / at;
+    }
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       if (st.composed) {                                      // the test of pass i belongs to the next product launch:
         rc = composed_products(i + 1, i + 1 == maxiters ? 1 : 2);   // run it now, without the product
@@ -2338,6 +2397,12 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
       }
       HIP_TRY(hipEventRecord(e1, s));
       load_policy.record(launched, s);
+      // classic passes on one GPU: deferred (DeferredFlags); a composed pass tests in its NEXT product launch and a sharded
+      // one is paced by its collectives: those wait here
+      if (can_defer && i + 1 < maxiters) {
+        HIP_TRY(deferred.request(flags.p, launched, s));
+        continue;
+      }
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       load_policy.decide(launched);
@@ -2435,6 +2500,11 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
   double clean_us = 0.0;
   const bool fused = plan_fuses_dot(m->plan);
   const double *jacobi = cask_hip_precond_jacobi_scale(precond);   // 1/diag on the device, or NULL for the ILU kinds
+  // (a Jacobi pass is launches that return on the done flag; an ILU application is not)
+  const bool can_defer = jacobi != nullptr && ensure_checkpoint(m);
+  DeferredFlags none;
+  DeferredFlags &deferred = can_defer ? *m->checkpoint : none;
+  deferred.pending = 0;
   SolverLoadPolicy load_policy(m, nullptr, 6);
   for (int i = 0; i < maxiters; i++) {
     double *rsold = rs[i & 1], *rsnew = rs[(i + 1) & 1];
@@ -2470,9 +2540,22 @@ int cask_hip_pcg(cask_hip_matrix *m, cask_hip_precond *precond, const double *rh
                          iters);
     }
     launched = i + 1;
+    if (deferred.pending) {                                   // the checkpoint of the pass before: its flags travelled while this pass was launched
+      const int at = deferred.pending;
+      HIP_TRY(deferred.wait(h_flags));
+      load_policy.decide(at);
+      if (h_flags[0]) break;                                  // (the pass just launched: its product overwrote Ap, its updates return on the flag)
+      float ms_so_far = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_so_far, e0, e1));
+      clean_us = ms_so_far * 1e3 / at;
+    }
     if ((i + 1) % check_every == 0 || i + 1 == maxiters) {
       HIP_TRY(hipEventRecord(e1, s));
       load_policy.record(launched, s);
+      if (can_defer && i + 1 < maxiters) {
+        HIP_TRY(deferred.request(flags.p, launched, s));
+        continue;
+      }
       HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       load_policy.decide(launched);
