@@ -120,6 +120,58 @@ __global__ void k_axpby(int64_t n, double alpha, const double *__restrict__ x, d
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = alpha * x[n - 1] + b * y[n - 1];
 }
 
+// Set-up of a CG / BiCG solve in one launch (r6; it was three to five device-to-device copies, an axpby and a dot launch, each
+// copy a runtime blit with ~7 us around it): r = b - q ; copies of r where the solver wants them (rt, p, pt: NULL = not
+// wanted) ; shares of r.r.  r = -q + b and the shares are formed exactly as k_axpby / k_dot_partial formed them (same
+// expressions, same grid-stride order): same bits.
+__global__ void k_solver_residual(int64_t n, const double *__restrict__ b, const double *__restrict__ q, double *__restrict__ r,
+                                  double *__restrict__ c0, double *__restrict__ c1, double *__restrict__ c2,
+                                  double *__restrict__ partials) {
+  __shared__ double red[16];
+  const int64_t n2 = n >> 1;
+  const dbl2 *b2 = reinterpret_cast<const dbl2 *>(b), *q2 = reinterpret_cast<const dbl2 *>(q);
+  dbl2 *r2 = reinterpret_cast<dbl2 *>(r), *c02 = reinterpret_cast<dbl2 *>(c0), *c12 = reinterpret_cast<dbl2 *>(c1),
+       *c22 = reinterpret_cast<dbl2 *>(c2);
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const dbl2 u = q2[i];
+    dbl2 w = b2[i];
+    w.x = -1.0 * u.x + 1.0 * w.x;
+    w.y = -1.0 * u.y + 1.0 * w.y;
+    r2[i] = w;
+    if (c0) c02[i] = w;
+    if (c1) c12[i] = w;
+    if (c2) c22[i] = w;
+    acc0 = fma(w.x, w.x, acc0);
+    acc1 = fma(w.y, w.y, acc1);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double w = -1.0 * q[n - 1] + 1.0 * b[n - 1];
+    r[n - 1] = w;
+    if (c0) c0[n - 1] = w;
+    if (c1) c1[n - 1] = w;
+    if (c2) c2[n - 1] = w;
+    acc0 = fma(w, w, acc0);
+  }
+  const double sum = wg_sum(acc0 + acc1, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = sum;
+}
+// ... and the initial guess into the one or two slots the first product reads it from
+__global__ void k_copy2(int64_t n, const double *__restrict__ src, double *__restrict__ d0, double *__restrict__ d1) {
+  const int64_t n2 = n >> 1;
+  const dbl2 *s2 = reinterpret_cast<const dbl2 *>(src);
+  dbl2 *a2 = reinterpret_cast<dbl2 *>(d0), *b2 = reinterpret_cast<dbl2 *>(d1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const dbl2 v = s2[i];
+    a2[i] = v;
+    if (d1) b2[i] = v;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    d0[n - 1] = src[n - 1];
+    if (d1) d1[n - 1] = src[n - 1];
+  }
+}
+
 // The update kernels walk the vectors in 16-byte pairs (vectors are the solver's own 256-byte
 // aligned allocations); element n-1 of an odd n is handled by the workgroup/lane that owns the
 // slot after the last pair, so the summation order is a function of n and the grid only.

@@ -2217,25 +2217,21 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   // ---- r = b - A x0 ; p = r ; rsold = r.r   (SparseLinearSolvers.hpp:189-198); BiCG: rt = r, rho = rt.r
   // x0 travels through slot P1 (peers read it there); in composed mode that slot is pass 0's "old direction",
   // which beta = 0 wipes out, so any finite content does.
-  HIP_TRY(hipMemcpyAsync(slot(SLOT_P1), d_x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  if (bicg) HIP_TRY(hipMemcpyAsync(slot(SLOT_PT1), d_x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  // (r6: the set-up is two launches besides the product -- k_copy2, k_solver_residual -- instead of three to five runtime copies,
+  //  an axpby and a dot launch: ~30-60 us of a solve, profiles/r06_update_launches.txt (6))
+  hipLaunchKernelGGL(k_copy2, bg, bw, 0, s, n, d_x, slot(SLOT_P1), bicg ? slot(SLOT_PT1) : (double *)nullptr);
   if (st.sharded && !st.exchange) {                           // every rank's x0 is in place before anyone's halo loads
     rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
     if (rc) return rc;
   }
   rc = product(m, SLOT_P1, q.p, nullptr, x_full);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(r, d_rhs, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_axpby, bg, bw, 0, s, n, -1.0, q.p, 1.0, 1.0, (const double *)nullptr, (const double *)nullptr, r,
-                     (const int *)nullptr);                   // r = -q + r
-  if (bicg) HIP_TRY(hipMemcpyAsync(rt, r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_dot_partial, bg, bw, 0, s, n, r, r, part_a.p, (const int *)nullptr);
+  // r = b - q ; rt = r (BiCG) ; classic passes keep p (and pt) materialised in slot P0 ; the shares of r.r
+  hipLaunchKernelGGL(k_solver_residual, bg, bw, 0, s, n, d_rhs, (const double *)q.p, r, bicg ? rt : (double *)nullptr,
+                     !st.composed ? slot(SLOT_P0) : (double *)nullptr,
+                     (!st.composed && bicg) ? slot(SLOT_PT0) : (double *)nullptr, part_a.p);
   hipLaunchKernelGGL(k_dot_final, dim3(1), bw, 0, s, g, part_a.p, scal.p + SC_RS0, 0, 0.0, (int *)nullptr, (int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
-  if (!st.composed) {                                         // classic passes keep p (and pt) materialised in slot P0
-    HIP_TRY(hipMemcpyAsync(slot(SLOT_P0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (bicg) HIP_TRY(hipMemcpyAsync(slot(SLOT_PT0), r, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  }
   rc = run_allreduce(st, scal.p + SC_RS0, 1, s);              // also: every rank's r (and p) is final before the first pass
   if (rc) return rc;
 
