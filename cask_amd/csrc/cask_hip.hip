@@ -206,6 +206,7 @@ struct cask_hip_matrix {
   std::unique_ptr<cask_hip_matrix> transpose;
   std::unique_ptr<SolverWorkspace> solver_ws;
   std::unique_ptr<DeferredFlags> checkpoint;   // (created by the first solve that defers: a pinned allocation is ~100 us)
+  int solver_load_choice = 0;      // what SolverLoadPolicy measured on this handle's last trial: 1 streaming, -1 cached loads, 0 not yet
   ~cask_hip_matrix() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -473,6 +474,7 @@ int build_plan(cask_hip_matrix &m, const cask_hip_params &requested) {
   if (rc) return rc;
   Plan &pl = m.plan;
   pl.prm = prm;
+  m.solver_load_choice = 0;                                   // (a new plan: the solvers measure their load policy again)
   pl.blocks.release();
   pl.long_blocks.release();
   pl.ci16.release();
@@ -1062,6 +1064,10 @@ struct SolverLoadPolicy {
     const int64_t working_set = per_matrix * (mt ? 2 : 1) + 8 * (int64_t)m->n_rows * n_vectors;
     choosing = m->requested.nontemporal == 0 && working_set < (int64_t)(224 << 20) && !m->plan.any_skew &&
                !(mt && mt->plan.any_skew);
+    if (choosing && m->solver_load_choice != 0) {             // measured by an earlier solve on this handle (r6): no second trial
+      set(m->solver_load_choice);
+      choosing = false;
+    }
     if (choosing)
       for (auto &e : ev)
         if (hipEventCreate(&e) != hipSuccess) choosing = false;
@@ -1086,6 +1092,7 @@ struct SolverLoadPolicy {
       set(-1);
     else
       set(1);
+    m->solver_load_choice = m->plan.prm.nontemporal < 0 ? -1 : 1;
     choosing = false;
   }
   ~SolverLoadPolicy() {
