@@ -157,7 +157,14 @@ __global__ void k_solver_residual(int64_t n, const double *__restrict__ b, const
   if (threadIdx.x == 0) partials[blockIdx.x] = sum;
 }
 // ... and the initial guess into the one or two slots the first product reads it from
-__global__ void k_copy2(int64_t n, const double *__restrict__ src, double *__restrict__ d0, double *__restrict__ d1) {
+// (also zeroes the solver's scalars and flags: first launch of a solve, in front of everything that reads them -- two runtime
+//  memsets less)
+__global__ void k_copy2(int64_t n, const double *__restrict__ src, double *__restrict__ d0, double *__restrict__ d1,
+                        double *zero_scalars, int n_scalars, int *zero_flags, int n_flags) {
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < n_scalars; i += blockDim.x) zero_scalars[i] = 0.0;
+    for (int i = threadIdx.x; i < n_flags; i += blockDim.x) zero_flags[i] = 0;
+  }
   const int64_t n2 = n >> 1;
   const dbl2 *s2 = reinterpret_cast<const dbl2 *>(src);
   dbl2 *a2 = reinterpret_cast<dbl2 *>(d0), *b2 = reinterpret_cast<dbl2 *>(d1);

@@ -2198,9 +2198,7 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   DevBuf<double> &q = ws.q, &qt = ws.qt, &part_a = ws.part_a, &part_b = ws.part_b, &part_c = ws.part_c, &scal = ws.scal,
                  &x_full = ws.x_full, &x_full_t = ws.x_full_t;
   DevBuf<int> &flags = ws.flags;
-  HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  HIP_TRY(hipMemsetAsync(scal.p, 0, SC_COUNT * sizeof(double), s));
-  int *done = flags.p, *iters = flags.p + 1;
+  int *done = flags.p, *iters = flags.p + 1;                   // (zeroed, with the scalars, by the first launch below: k_copy2)
   const SolverShape shape = solver_shape(n, st.sharded);
   const int g = shape.grid;
   const dim3 bg(g), bw(shape.wg);
@@ -2226,7 +2224,8 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   // which beta = 0 wipes out, so any finite content does.
   // (r6: the set-up is two launches besides the product -- k_copy2, k_solver_residual -- instead of three to five runtime copies,
   //  an axpby and a dot launch: ~30-60 us of a solve, profiles/r06_update_launches.txt (6))
-  hipLaunchKernelGGL(k_copy2, bg, bw, 0, s, n, d_x, slot(SLOT_P1), bicg ? slot(SLOT_PT1) : (double *)nullptr);
+  hipLaunchKernelGGL(k_copy2, bg, bw, 0, s, n, d_x, slot(SLOT_P1), bicg ? slot(SLOT_PT1) : (double *)nullptr, scal.p, (int)SC_COUNT,
+                     flags.p, 2);
   if (st.sharded && !st.exchange) {                           // every rank's x0 is in place before anyone's halo loads
     rc = run_allreduce(st, scal.p + SC_DOT, 1, s);
     if (rc) return rc;
@@ -2418,8 +2417,13 @@ int cask_hip_solve_device(cask_hip_matrix *m, cask_hip_matrix *mt_in, const cask
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, s));
-  HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (can_defer) {                                            // (the pinned buffer: no staging copy; the event behind it is the last thing queued)
+    HIP_TRY(deferred.request(flags.p, launched, s));
+    HIP_TRY(deferred.wait(h_flags));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   if (iterations) *iterations = h_flags[1];
