@@ -175,7 +175,9 @@ int cask_hip_csr_get_info(const cask_hip_matrix *m, cask_hip_csr_info *out);
  *   staged (the default for 64 KiB .. 4 MiB of vectors; smaller and larger ones go the pageable way, which is as fast
  *     there): x is copied into the handle's pinned staging buffer by a few host threads
  *     (one core moves 500 KB in 25-35 us: most of what a call used to cost), pulled over PCIe by a copy kernel in front of
- *     the product, and the product writes y straight into pinned host memory; one synchronisation, a threaded copy out.
+ *     the product, and the product writes y straight into pinned host memory; a threaded copy out.  The caller learns that y
+ *     is there from a word a one-thread launch stores behind the product (polled; 4.5 us earlier than the queue's signal;
+ *     bounded -- after 20 ms the call synchronises, which is also what reports a fault).
  *     Safe for any pointer: the caller's memory is only ever touched by the CPU.
  *   registered: a vector inside a range given to cask_hip_host_register is read / written by the GPU in place (no host
  *     copy at all).  That is a CONTRACT, not a cache: the range must stay mapped until cask_hip_host_unregister -- a GPU
