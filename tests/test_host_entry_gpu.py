@@ -127,3 +127,42 @@ def test_entry_point_follows_a_replanned_handle(restore_mode):
         call(m, x, y)
         oracle.assert_almost_equal(y, want, what=str(dp))
     m.close()
+
+
+@pytest.mark.parametrize("done", ["word", "sync"])
+def test_completion_word_and_the_signal_agree(done):
+    """How the CPU learns that y is there (cask_hip.hip, r6): a word stored behind the product and polled (the default) or
+    hipStreamSynchronize (CASK_HIP_HOST_DONE=sync; read once per process, hence the subprocess).  200 back-to-back calls
+    with an operand that changes every call, staged and in place: every result is that call's product."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    code = f"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, {str(repo)!r})
+import oracle
+from cask_amd import capi, synth
+n, rp, ci, va = synth.small("cant", factor=4)
+m = capi.CsrMatrix.from_host(n, n, rp, ci, va)
+L = capi.load()
+base = oracle.csr_spmv(rp, ci, va, np.ones(n))
+for registered in (False, True):
+    x, y = np.ones(n), np.zeros(n)
+    if registered:
+        capi.host_register(x); capi.host_register(y)
+    else:
+        capi.host_entry_mode("staged")
+    for k in range(1, 201):
+        x[:] = float(k)
+        assert L.cask_hip_spmv(m._h, x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p)) == 0
+        oracle.assert_almost_equal(y, k * base, what=f"call {{k}} registered={{registered}}")
+    if registered:
+        capi.host_unregister(x); capi.host_unregister(y)
+m.close()
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, CASK_HIP_HOST_DONE=done))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
